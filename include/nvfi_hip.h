@@ -1,0 +1,124 @@
+/*
+ * nvfi_hip.h - C ABI of the MI355X-native NVFi hot path (libnvfi_hip.so, hand-written HIP for gfx950).
+ *
+ * The reference has no FFI layer: its hot path is Python calling ATen ops.  This ABI is what the
+ * host-side mirror (nvfi_amd/models) binds through ctypes; each entry point names the reference
+ * interface it replaces.  Plain pointers and sizes only: every pointer below is a DEVICE pointer
+ * unless stated, `stream` is a hipStream_t passed as void*, the caller owns every buffer, nothing
+ * is allocated inside (workspace sizes are queried first).  All calls are asynchronous on
+ * `stream`.  Return value: 0 = ok, otherwise an error code; nvfi_last_error() gives the text.
+ *
+ * Layouts: factor planes are CHANNEL-LAST, [H][W][C] fp32 (the physical layout of a torch
+ * (1,C,H,W) tensor in torch.channels_last); Linear weights are (out,in) row-major as in torch.
+ */
+#ifndef NVFI_HIP_H
+#define NVFI_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVFI_ABI_VERSION 1
+
+/* Field description: TensorVMKeyframeTimeKplane state that reaches the hot path
+ * (reference models/tensorf_keyframe.py:37-134, models/tensorf_base.py:133-227). */
+typedef struct nvfi_field_desc {
+    int32_t G[3];            /* gridSize x,y,z */
+    int32_t K;               /* num_keyframes */
+    int32_t Cd, Ca, app_dim; /* 24, 48, 32 in every shipped config */
+    int32_t n_samples;       /* nSamples (tensorf_base.py:223) */
+    int32_t use_vel;         /* cfg.use_vel */
+    int32_t gate_sur;        /* 0 VelocityAABB(eps), 1 VelocityAABBSur (velocity_field.py:21-51) */
+    int32_t has_amask;       /* alphaMask present (used in eval only, tensorf_keyframe.py:656) */
+    int32_t am_dims[3];      /* alpha volume W,H,D */
+    float aabb[6];           /* min xyz, max xyz */
+    float near_, far_, step_size;
+    float density_shift, distance_scale, weight_thres, alpha_thres, tmax;
+    float gate_lo[3], gate_hi[3]; /* velocity gate box in normalised coordinates */
+    const float* dps[3];     /* density_plane_space[i]  [G_b][G_a][Cd] */
+    const float* dpt[3];     /* density_plane_time[i]   [K][G_c][Cd]   */
+    const float* aps[3];     /* app_plane_space[i]      [G_b][G_a][Ca] */
+    const float* apt[3];     /* app_plane_time[i]       [K][G_c][Ca]   */
+    const float* basis;      /* basis_mat.weight (app_dim, Ca) */
+    const float* rW[3];      /* renderModule.mlp.{0,2,4}.weight */
+    const float* rb[3];
+    const float* vW[6];      /* vel_net.weight_net Linear weights (6 layers) */
+    const float* vb[6];
+    const float* aW[6];      /* vel_net.a_weight_net */
+    const float* ab[6];
+    const float* amask;      /* alpha volume (D,H,W) or NULL */
+} nvfi_field_desc;
+
+/* Gradient buffers, same shapes/layouts as the parameters; kernels ACCUMULATE (+=) into them.
+ * A NULL pointer skips that gradient. */
+typedef struct nvfi_grads {
+    float* dps[3]; float* dpt[3]; float* aps[3]; float* apt[3];
+    float* basis;
+    float* rW[3]; float* rb[3];
+    float* vW[6]; float* vb[6];
+    float* aW[6]; float* ab[6];
+} nvfi_grads;
+
+#define NVFI_TRAIN     1  /* training mode: jitter used, alpha mask ignored, intermediates kept for backward */
+#define NVFI_WHITE_BG  2  /* rgb += 1-acc  (white_bg or the random-white coin, tensorf_keyframe.py:740) */
+#define NVFI_TRANSFER  4  /* transfer_vel: base time 0 (models/nvfi.py:30) */
+
+/* counters written by nvfi_render_fwd (device int64[8]):
+ * 0 valid samples V, 1 warped samples N, 2 appearance-masked samples M, 3 velocity-net evaluations */
+#define NVFI_NCOUNTERS 8
+
+const char* nvfi_last_error(void);
+int nvfi_abi_version(void);
+
+/* ---- render: replaces NVFi.render_ray / TensorVMKeyframeTimeKplane.forward + render_pts
+ *      (models/nvfi.py:27-31, models/tensorf_keyframe.py:613-755) for one chunk of R rays. */
+int nvfi_render_workspace_bytes(const nvfi_field_desc* f, int64_t R, int flags, int64_t* bytes);
+/* exact size for a given time t (extrapolated times need more RK2 steps, hence more stash) */
+int nvfi_render_workspace_bytes_t(const nvfi_field_desc* f, int64_t R, int flags, float t, int64_t* bytes);
+int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R,
+                    const float* rays_o, const float* rays_d, /* (R,3) */
+                    const float* jitter,                     /* (R) u_r in [0,1) or NULL (eval) */
+                    float t, int flags,
+                    float* rgb, float* depth, float* acc,    /* (R,3) (R) (R) */
+                    float* weights,                          /* (R,S) */
+                    void* workspace, int64_t workspace_bytes,
+                    int64_t* counters,                       /* device int64[NVFI_NCOUNTERS] or NULL */
+                    void* stream);
+/* backward of the call that filled `workspace` (autograd of models/tensorf_keyframe.py:613-755,
+ * reference: loss.backward() at train_nvfi.py:242).  Upstream grads may be NULL (= zero). */
+int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R,
+                    const float* rays_o, const float* rays_d, float t, int flags,
+                    const float* weights,                    /* the (R,S) output of the forward */
+                    const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_weights,
+                    const nvfi_grads* grads,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- PDE regulariser: replaces NVFi.get_vel_loss (models/nvfi.py:42-84) with explicit collocation
+ *      points (world space (P,3)) and raw times (P).  out (device float[4]): loss, n_kept, sum div^2,
+ *      sum transport^2.  grads: vW,vb,aW,ab are accumulated scaled by `loss_scale` when non-NULL. */
+int nvfi_pde_workspace_bytes(const nvfi_field_desc* f, int64_t P, int64_t* bytes);
+int nvfi_pde_loss(const nvfi_field_desc* f, int64_t P, const float* points, const float* t,
+                  float loss_scale, float* out, const nvfi_grads* grads,
+                  void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream);
+
+/* ---- building blocks used by train_segm-style callers and by the parity tests */
+/* VelBasis.forward (velocity_field.py:69-75): xt (N,4) -> u (N,6)=(v,a); gated!=0: VelocityAABB[Sur].forward -> (N,3) in u (stride 6) */
+int nvfi_vel_eval(const nvfi_field_desc* f, int64_t N, const float* xt, float* u6, int gated,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+int nvfi_vel_workspace_bytes(const nvfi_field_desc* f, int64_t N, int64_t* bytes);
+/* integrate_pos (tensorf_keyframe.py:575-611): x (N,3) normalised, t (N), base (N) -> xk (N,3) */
+int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const float* x, const float* t, const float* base,
+                       float* xk, void* workspace, int64_t workspace_bytes, void* stream);
+/* compute_densityfeature + feature2density (tensorf_keyframe.py:233-272, 312-321): xyzt (N,4) -> feat (N), sigma (N) */
+int nvfi_density_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, float* feat, float* sigma, void* stream);
+/* compute_appfeature + MLPRender_PE (tensorf_keyframe.py:274-310, tensorf_base.py:88-98): xyzt (N,4), view (N,3) -> rgb (N,3) */
+int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, const float* view, float* rgb,
+                void* workspace, int64_t workspace_bytes, void* stream);
+/* MFMA fragment-layout self test: returns max abs error of a 128x128 fp32 layer against a VALU loop (host float*) */
+int nvfi_selftest(float* max_err_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

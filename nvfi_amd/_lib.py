@@ -1,0 +1,79 @@
+"""ctypes binding of libnvfi_hip.so (include/nvfi_hip.h).  The product path has NO CPU fallback:
+a missing library or a non-GPU tensor raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "csrc", "libnvfi_hip.so")
+fp = C.c_void_p
+
+NVFI_TRAIN, NVFI_WHITE_BG, NVFI_TRANSFER = 1, 2, 4
+NCOUNTERS = 8
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [
+        ("G", C.c_int32 * 3), ("K", C.c_int32), ("Cd", C.c_int32), ("Ca", C.c_int32), ("app_dim", C.c_int32),
+        ("n_samples", C.c_int32), ("use_vel", C.c_int32), ("gate_sur", C.c_int32), ("has_amask", C.c_int32),
+        ("am_dims", C.c_int32 * 3),
+        ("aabb", C.c_float * 6), ("near_", C.c_float), ("far_", C.c_float), ("step_size", C.c_float),
+        ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float),
+        ("alpha_thres", C.c_float), ("tmax", C.c_float),
+        ("gate_lo", C.c_float * 3), ("gate_hi", C.c_float * 3),
+        ("dps", fp * 3), ("dpt", fp * 3), ("aps", fp * 3), ("apt", fp * 3),
+        ("basis", fp), ("rW", fp * 3), ("rb", fp * 3),
+        ("vW", fp * 6), ("vb", fp * 6), ("aW", fp * 6), ("ab", fp * 6),
+        ("amask", fp),
+    ]
+
+
+class Grads(C.Structure):
+    _fields_ = [
+        ("dps", fp * 3), ("dpt", fp * 3), ("aps", fp * 3), ("apt", fp * 3),
+        ("basis", fp), ("rW", fp * 3), ("rb", fp * 3),
+        ("vW", fp * 6), ("vb", fp * 6), ("aW", fp * 6), ("ab", fp * 6),
+    ]
+
+
+EXPORTS = [
+    "nvfi_last_error", "nvfi_abi_version",
+    "nvfi_render_workspace_bytes", "nvfi_render_workspace_bytes_t", "nvfi_render_fwd", "nvfi_render_bwd",
+    "nvfi_pde_workspace_bytes", "nvfi_pde_loss",
+    "nvfi_vel_eval", "nvfi_vel_workspace_bytes", "nvfi_integrate_pos", "nvfi_density_at", "nvfi_app_at",
+    "nvfi_selftest",
+]
+
+_LIB = None
+
+
+class NvfiError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library; fail loudly if it has not been built (no fallback path exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO):
+            raise NvfiError(f"{SO} is missing: build it with `python -m nvfi_amd.build` (needs hipcc). "
+                            "There is no CPU fallback for the NVFi hot path.")
+        L = C.CDLL(SO)
+        L.nvfi_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(L, name)  # raises AttributeError on a missing symbol
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise NvfiError(f"libnvfi_hip error {rc}: {lib().nvfi_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NvfiError("NVFi HIP kernels need tensors on the GPU (no CPU fallback exists)")
+    return C.c_void_p(t.data_ptr())

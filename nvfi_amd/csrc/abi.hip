@@ -1,0 +1,120 @@
+// abi.hip - error plumbing, version, self test and the small building-block entry points of the C ABI.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "common.h"
+#include "vel.h"
+
+static thread_local char g_err[512] = "";
+int nvfi_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* nvfi_last_error(void) { return g_err; }
+extern "C" int nvfi_abi_version(void) { return NVFI_ABI_VERSION; }
+
+// ---------------------------------------------------------------- VelBasis evaluation
+extern "C" int nvfi_vel_workspace_bytes(const nvfi_field_desc* f, int64_t N, int64_t* bytes) {
+    (void)f;
+    *bytes = align_up((int64_t)2 * VEL_FRAG_FLOATS * 4 + 4096 + N * 16 + N * 12, 256);
+    return 0;
+}
+extern "C" int nvfi_vel_eval(const nvfi_field_desc* f, int64_t N, const float* xt, float* u6, int gated,
+                             void* workspace, int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 0) return 0;
+    Bump B{(char*)workspace, 0, 0};
+    float* fv = B.take<float>(VEL_FRAG_FLOATS);
+    float* fa = B.take<float>(VEL_FRAG_FLOATS);
+    if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
+    PackJobs jobs; jobs.n = 0;
+    VelEvalArgs a; memset(&a, 0, sizeof(a));
+    if (pack_vel_frags(f->vW, f->vb, fv, &a.Wv, &jobs)) return 3;
+    if (!gated) { if (pack_vel_frags(f->aW, f->ab, fa, &a.Wa, &jobs)) return 3; }
+    if (launch_pack(jobs, st)) return 1;
+    a.f = *f; a.N = N; a.xt = xt; a.u6 = u6; a.gated = gated;
+    return launch_vel_eval(a, st);
+}
+
+// ---------------------------------------------------------------- integrate_pos (per-point times)
+__global__ void k_pack_xt(int64_t N, const float* x, float4* xw) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < N) xw[i] = make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], 0.f);
+}
+extern "C" int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const float* x, const float* t, const float* base,
+                                  float* xk, void* workspace, int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 0) return 0;
+    Bump B{(char*)workspace, 0, 0};
+    float* fv = B.take<float>(VEL_FRAG_FLOATS);
+    float4* xw = B.take<float4>(N);
+    if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
+    PackJobs jobs; jobs.n = 0;
+    Rk2Args a; memset(&a, 0, sizeof(a));
+    if (pack_vel_frags(f->vW, f->vb, fv, &a.Wv, &jobs)) return 3;
+    if (launch_pack(jobs, st)) return 1;
+    hipLaunchKernelGGL(k_pack_xt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, x, xw);
+    a.f = *f; a.count = nullptr; a.n_direct = N; a.list = nullptr; a.xw = xw; a.xout = xk;
+    a.pt_t = t; a.pt_base = base; a.dt_max = dt_max_of(*f); a.max_steps = 4096;
+    return launch_rk2_fwd(a, N, false, false, st);
+}
+
+// ---------------------------------------------------------------- MFMA layout self test
+__global__ __launch_bounds__(WG_THREADS) void k_selftest(const float* frag, const float* W, const float* X, float* out) {
+    // one workgroup, wave 0 only does the maths: out[o][j] = sum_k W[o][k] X[k][j], 128x128 by 128x32
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    stage_frag(lds, lds + LDS_W_FLOATS, frag, 4 * 64 * 64, nullptr, 0);
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    float x[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) x[s] = X[dmap(s, h) * 32 + j];
+    f32x16 acc[4];
+    acc_init<4>(acc, lds, 0, false);
+    layer_mfma<4, 64>(lds, lane, x, acc);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[dmap(16 * m + r, h) * 32 + j] = acc[m][r];
+}
+extern "C" int nvfi_selftest(float* max_err_host, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int O = 128, K = 128, J = 32;
+    float *hW = new float[O * K], *hX = new float[K * J], *hO = new float[O * J];
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+    for (int i = 0; i < O * K; ++i) hW[i] = rnd();
+    for (int i = 0; i < K * J; ++i) hX[i] = rnd();
+    float *dW, *dX, *dO, *dF;
+    HIPCK(hipMalloc(&dW, O * K * 4)); HIPCK(hipMalloc(&dX, K * J * 4)); HIPCK(hipMalloc(&dO, O * J * 4)); HIPCK(hipMalloc(&dF, 4 * 64 * 64 * 4));
+    HIPCK(hipMemcpyAsync(dW, hW, O * K * 4, hipMemcpyHostToDevice, st));
+    HIPCK(hipMemcpyAsync(dX, hX, K * J * 4, hipMemcpyHostToDevice, st));
+    PackJobs jobs; jobs.n = 1;
+    PackJob& P = jobs.j[0];
+    P.W = dW; P.b = nullptr; P.frag = dF; P.bfrag = nullptr; P.out = O; P.in = K; P.MT = 4; P.NS = 64;
+    P.row_kind = RK_NATURAL; P.slot_kind = SK_HIDDEN; P.transposed = 0;
+    if (launch_pack(jobs, st)) return 1;
+    HIPCK(hipFuncSetAttribute((const void*)k_selftest, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, dF, dW, dX, dO);
+    LAUNCHCK();
+    HIPCK(hipMemcpyAsync(hO, dO, O * J * 4, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    float me = 0.f;
+    for (int o = 0; o < O; ++o)
+        for (int j = 0; j < J; ++j) {
+            float r = 0.f;
+            for (int k = 0; k < K; ++k) r += hW[o * K + k] * hX[k * J + j];
+            float e = fabsf(r - hO[o * J + j]);
+            if (e > me) me = e;
+        }
+    *max_err_host = me;
+    hipFree(dW); hipFree(dX); hipFree(dO); hipFree(dF);
+    delete[] hW; delete[] hX; delete[] hO;
+    return 0;
+}
+
+// ---------------------------------------------------------------- PDE entry points live in pde.hip

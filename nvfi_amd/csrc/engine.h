@@ -1,0 +1,343 @@
+// engine.h - fp32 MFMA "sample-tile" MLP engine for gfx950 (CDNA4).
+//
+// Design (MI355X-first, not a translation of the reference's nn.Linear stack):
+//   * a wave owns a tile of 32 samples; lanes l and l+32 (h = l>>5) hold the same sample.
+//   * a Linear layer is D[out][sample] = W[out][k] * X[k][sample] on v_mfma_f32_32x32x2_f32
+//     (exact fp32, bitwise an fmaf chain).  Activations never leave registers between layers:
+//     the MFMA C/D layout (row = (r&3)+8(r>>2)+4h, col = lane&31) of layer l IS the B-operand
+//     layout of layer l+1 once the contraction index is walked in that order, so the weights are
+//     pre-permuted ("fragment order") instead: frag[(m*NS+s)*64 + lane] = W[32m + (lane&31)][slot(s,h)].
+//   * fragments of one layer (<= 64 KB) are staged in LDS once per workgroup (4 waves = 128
+//     samples) and read with conflict-free ds_read_b32; two workgroups per CU overlap staging,
+//     activation VALU work and MFMA.
+//   * weight gradients are a separate split-K MFMA kernel over stashed tiles (k_wgrad), transposing
+//     sample<->feature through padded LDS images.
+//
+// Reference semantics implemented with this engine: VelBasis weight_net / a_weight_net
+// (models/velocity_field.py:54-98), MLPRender_PE + basis_mat (models/tensorf_base.py:67-98,
+// models/tensorf_keyframe.py:310).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+#define WG_THREADS 256
+#define TILE 32                       // samples per wave
+#define WG_SAMPLES 128                // 4 waves
+#define LDS_W_FLOATS 16384            // 64 KB fragment buffer
+#define LDS_B_FLOATS 128
+#define ENGINE_LDS_BYTES ((LDS_W_FLOATS + LDS_B_FLOATS) * 4)
+#define REGF (64)                     // floats per stash register row (one per lane)
+
+// ---------------------------------------------------------------- layout maps
+// D-layout: register index s (= 16*tile + r) and half h  ->  row index
+__host__ __device__ inline int dmap(int s, int h) {
+    int m = s >> 4, r = s & 15;
+    return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+// inverse: row -> p = 2*s + h
+__host__ __device__ inline int dinv_p(int rho) {
+    int m = rho >> 5, q = rho & 31;
+    int h = (q >> 2) & 1;
+    int r = (q & 3) | ((q >> 3) << 2);
+    return 2 * (16 * m + r) + h;
+}
+
+enum { SK_HIDDEN = 0, SK_VEL_IN = 1, SK_RENDER_IN = 2 };
+// slot p = 2*s + h  ->  logical input feature index of the layer (or -1: unused slot)
+__host__ __device__ inline int slot_logical(int kind, int p) {
+    int s = p >> 1, h = p & 1;
+    if (kind == SK_HIDDEN) return dmap(s, h);
+    if (kind == SK_VEL_IN) {          // PositionEncoder(3) on (x,y,z,t), base_network.py:42-54
+        if (s == 0) return h;         // x | y
+        if (s == 1) return 2 + h;     // z | t
+        if (s < 14) { int k = (s - 2) >> 2, c = (s - 2) & 3; return (h ? 8 : 4) + 8 * k + c; }  // sin | cos
+        return -1;
+    }
+    // SK_RENDER_IN: [feat32 | view3 | pts3 | sin(pts)18 | cos(pts)18 | sin(view)18 | cos(view)18]
+    if (s < 16) return dmap(s, h);
+    if (s < 19) return (h ? 35 : 32) + (s - 16);
+    if (s < 37) return (h ? 56 : 38) + (s - 19);
+    if (s < 55) return (h ? 92 : 74) + (s - 37);
+    return -1;
+}
+enum { RK_NATURAL = 0, RK_VEL_IN = 1, RK_RENDER_IN = 2 };
+__host__ __device__ inline int row_logical(int kind, int rho) {
+    if (kind == RK_NATURAL) return rho;
+    return slot_logical(kind == RK_VEL_IN ? SK_VEL_IN : SK_RENDER_IN, dinv_p(rho));
+}
+
+// ---------------------------------------------------------------- fragment packing
+struct PackJob {
+    const float* W;      // (out,in) row-major
+    const float* b;      // (out) or NULL
+    float* frag;         // MT*NS*64 floats
+    float* bfrag;        // MT*32 floats or NULL
+    int out, in, MT, NS;
+    int row_kind, slot_kind;
+    int transposed;      // 0: rows=out features, slots=in features ; 1 (dgrad): rows=in features, slots=out features
+};
+#define MAX_PACK_JOBS 40
+struct PackJobs { PackJob j[MAX_PACK_JOBS]; int n; };
+
+__global__ void k_pack(PackJobs jobs);
+
+// ---------------------------------------------------------------- activations
+template <int ACT> __device__ __forceinline__ float act_f(float z);
+template <> __device__ __forceinline__ float act_f<0>(float z) { return z > 0.f ? z : 0.f; }
+template <> __device__ __forceinline__ float act_f<1>(float z) { return z / (1.f + expf(-z)); }
+template <int ACT> __device__ __forceinline__ float act_d1(float z);
+template <> __device__ __forceinline__ float act_d1<0>(float z) { return z > 0.f ? 1.f : 0.f; }
+template <> __device__ __forceinline__ float act_d1<1>(float z) {
+    float s = 1.f / (1.f + expf(-z));
+    return s * (1.f + z * (1.f - s));
+}
+template <int ACT> __device__ __forceinline__ float act_d2(float z);
+template <> __device__ __forceinline__ float act_d2<0>(float) { return 0.f; }
+template <> __device__ __forceinline__ float act_d2<1>(float z) {
+    float s = 1.f / (1.f + expf(-z));
+    return s * (1.f - s) * (2.f + z * (1.f - 2.f * s));
+}
+
+// ---------------------------------------------------------------- LDS staging + MFMA layer
+__device__ __forceinline__ void stage_frag(float* lds_w, float* lds_b, const float* __restrict__ frag, int nfloats,
+                                           const float* __restrict__ bfrag, int nb) {
+    const float4* src = reinterpret_cast<const float4*>(frag);
+    float4* dst = reinterpret_cast<float4*>(lds_w);
+    for (int i = threadIdx.x; i < (nfloats >> 2); i += WG_THREADS) dst[i] = src[i];
+    if (threadIdx.x < nb) lds_b[threadIdx.x] = bfrag ? bfrag[threadIdx.x] : 0.f;
+}
+
+template <int MT>
+__device__ __forceinline__ void acc_init(f32x16* acc, const float* lds_b, int h, bool use_bias) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = use_bias ? lds_b[32 * m + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+}
+
+template <int MT, int NS>
+__device__ __forceinline__ void layer_mfma(const float* lds_w, int lane, const float* x, f32x16* acc) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = MFMA32(lds_w[(m * NS + s) * 64 + lane], x[s], acc[m]);
+    }
+}
+
+// store / load a block of NR stash registers (one 256-B row per register)
+template <int NR>
+__device__ __forceinline__ void stash_store(float* base, int lane, const float* v) {
+#pragma unroll
+    for (int s = 0; s < NR; ++s) base[s * REGF + lane] = v[s];
+}
+template <int MT>
+__device__ __forceinline__ void stash_store_acc(float* base, int lane, const f32x16* acc) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) base[(16 * m + r) * REGF + lane] = acc[m][r];
+}
+
+// ---------------------------------------------------------------- velocity-basis nets
+// fragments of one 6-layer net (28-128-128-128-128-128-6), forward and transposed (dgrad)
+struct VelFrags {
+    const float* f[6];   // forward fragments: L0 MT4 NS14 | L1-4 MT4 NS64 | L5 MT1 NS64
+    const float* b[6];   // bias fragments (MT*32)
+    const float* t[6];   // transposed: T0 MT1 NS64 (rows = input slots) | T1-4 MT4 NS64 | T5 MT4 NS4
+};
+#define VEL_F0 (4 * 14 * 64)
+#define VEL_FH (4 * 64 * 64)
+#define VEL_F5 (1 * 64 * 64)
+#define VEL_T0 (1 * 64 * 64)
+#define VEL_T5 (4 * 4 * 64)
+#define VEL_FRAG_FLOATS (VEL_F0 + 4 * VEL_FH + VEL_F5 + 6 * 128 + VEL_T0 + 4 * VEL_FH + VEL_T5)
+
+// stash geometry for one (eval, tile): z: 5 layers x 64 regs, x0: 16 regs
+#define VEL_Z_REGS (5 * 64)
+#define VEL_X0_REGS 16
+
+__device__ __forceinline__ float comp4(const float4& q, int c) { return c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w)); }
+
+// PositionEncoder slots for this lane (x[0..13]); regs 14,15 zero
+__device__ __forceinline__ void vel_encode_slots(const float4& q, int h, float* x) {
+    x[0] = h ? q.y : q.x;
+    x[1] = h ? q.w : q.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = comp4(q, c) * (float)(1 << k);
+            float sn, cs;
+            sincosf(a, &sn, &cs);
+            x[2 + 4 * k + c] = h ? cs : sn;
+        }
+    x[14] = 0.f; x[15] = 0.f;
+}
+
+// One forward evaluation of a VelBasis weight net for the wave's 32 samples.
+// Must be called by all 4 waves of the workgroup (contains barriers).
+// out4: lane h=0 -> w0..w3 ; lane h=1 -> w4,w5,0,0.
+// zst: this (eval,tile)'s z stash (VEL_Z_REGS rows) or NULL; x0st: x0 stash (16 rows) or NULL.
+template <int ACT>
+__device__ __forceinline__ void velnet_forward(const VelFrags& W, float* lds_w, float* lds_b, int lane,
+                                               const float4& q, float* zst, float* x0st, float* out4) {
+    const int h = lane >> 5;
+    float x[64];
+    f32x16 acc[4];
+    vel_encode_slots(q, h, x);
+    if (x0st) stash_store<16>(x0st, lane, x);
+    __syncthreads();
+    stage_frag(lds_w, lds_b, W.f[0], VEL_F0, W.b[0], 128);
+    __syncthreads();
+    acc_init<4>(acc, lds_b, h, true);
+    layer_mfma<4, 14>(lds_w, lane, x, acc);
+#pragma unroll 1
+    for (int l = 1; l <= 4; ++l) {
+        if (zst) stash_store_acc<4>(zst + (size_t)(l - 1) * 64 * REGF, lane, acc);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[16 * m + r] = act_f<ACT>(acc[m][r]);
+        __syncthreads();
+        stage_frag(lds_w, lds_b, W.f[l], VEL_FH, W.b[l], 128);
+        __syncthreads();
+        acc_init<4>(acc, lds_b, h, true);
+        layer_mfma<4, 64>(lds_w, lane, x, acc);
+    }
+    if (zst) stash_store_acc<4>(zst + (size_t)4 * 64 * REGF, lane, acc);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[16 * m + r] = act_f<ACT>(acc[m][r]);
+    __syncthreads();
+    stage_frag(lds_w, lds_b, W.f[5], VEL_F5, W.b[5], 32);
+    __syncthreads();
+    f32x16 o[1];
+    acc_init<1>(o, lds_b, h, true);
+    layer_mfma<1, 64>(lds_w, lane, x, o);
+    out4[0] = o[0][0]; out4[1] = o[0][1]; out4[2] = o[0][2]; out4[3] = o[0][3];
+}
+
+// both halves get the full 6-vector
+__device__ __forceinline__ void gather6(const float* out4, int h, float* w) {
+    float p0 = __shfl_xor(out4[0], 32), p1 = __shfl_xor(out4[1], 32), p2 = __shfl_xor(out4[2], 32), p3 = __shfl_xor(out4[3], 32);
+    if (h == 0) { w[0] = out4[0]; w[1] = out4[1]; w[2] = out4[2]; w[3] = out4[3]; w[4] = p0; w[5] = p1; }
+    else        { w[0] = p0; w[1] = p1; w[2] = p2; w[3] = p3; w[4] = out4[0]; w[5] = out4[1]; }
+}
+// inverse: 6-vector (same in both halves) -> the D-layout tile-0 registers 0..3 of this lane
+__device__ __forceinline__ void scatter6(const float* w, int h, float* r4) {
+    if (h == 0) { r4[0] = w[0]; r4[1] = w[1]; r4[2] = w[2]; r4[3] = w[3]; }
+    else        { r4[0] = w[4]; r4[1] = w[5]; r4[2] = 0.f; r4[3] = 0.f; }
+}
+
+// v = sum_i w_i b_i(x)  (velocity_field.py:77-93)
+__device__ __forceinline__ void vel_from_w(const float* w, float x, float y, float z, float* v) {
+    v[0] = w[0] - w[4] * z + w[5] * y;
+    v[1] = w[1] + w[3] * z - w[5] * x;
+    v[2] = w[2] - w[3] * y + w[4] * x;
+}
+__device__ __forceinline__ void acc_from_w(const float* aw, float x, float y, float z, float* a) {
+    a[0] = aw[0] - aw[4] * x - aw[5] * x;
+    a[1] = aw[1] - aw[3] * y - aw[5] * y;
+    a[2] = aw[2] - aw[3] * z - aw[4] * z;
+}
+
+// Backward (dgrad) of one evaluation.  gw4: adjoint of the 6 outputs in D-layout regs 0..3 of this lane.
+// zst: z stash of the forward; gst: adjoint stash to fill (5*64 rows gz + 16 rows gw) for k_wgrad, or NULL.
+// Returns ge (16 regs, input-slot layout) in ge[].
+template <int ACT>
+__device__ __forceinline__ void velnet_backward(const VelFrags& W, float* lds_w, float* lds_b, int lane,
+                                                const float* gw4, const float* zst, float* gst, float* ge) {
+    float g[64];
+    f32x16 acc[4];
+    g[0] = gw4[0]; g[1] = gw4[1]; g[2] = gw4[2]; g[3] = gw4[3];
+    if (gst) {
+        float* gw_rows = gst + (size_t)5 * 64 * REGF;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
+    }
+    __syncthreads();
+    stage_frag(lds_w, lds_b, W.t[5], VEL_T5, nullptr, 0);
+    __syncthreads();
+    acc_init<4>(acc, lds_b, 0, false);
+    layer_mfma<4, 4>(lds_w, lane, g, acc);
+#pragma unroll 1
+    for (int l = 4; l >= 1; --l) {
+        const float* zl = zst + (size_t)l * 64 * REGF;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = acc[m][r] * act_d1<ACT>(zl[(16 * m + r) * REGF + lane]);
+        if (gst) stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
+        __syncthreads();
+        stage_frag(lds_w, lds_b, W.t[l], VEL_FH, nullptr, 0);
+        __syncthreads();
+        acc_init<4>(acc, lds_b, 0, false);
+        layer_mfma<4, 64>(lds_w, lane, g, acc);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[16 * m + r] = acc[m][r] * act_d1<ACT>(zst[(16 * m + r) * REGF + lane]);
+    if (gst) stash_store<64>(gst, lane, g);
+    __syncthreads();
+    stage_frag(lds_w, lds_b, W.t[0], VEL_T0, nullptr, 0);
+    __syncthreads();
+    f32x16 o[1];
+    acc_init<1>(o, lds_b, 0, false);
+    layer_mfma<1, 64>(lds_w, lane, g, o);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ge[r] = o[0][r];
+}
+
+// adjoint of the PositionEncoder slots: ge (16 regs of this lane) + the forward slots x0 -> (gx,gy,gz,gt) summed over both halves
+__device__ __forceinline__ float4 vel_encode_bwd(const float* ge, const float* x0, int h) {
+    // lane h=0 holds (x | z) raw and the sin slots; lane h=1 holds (y | t) raw and the cos slots.
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float mine = x0[2 + 4 * k + c];               // sin (h=0) or cos (h=1)
+            float other = __shfl_xor(mine, 32);           // cos (h=0) or sin (h=1)
+            float fr = (float)(1 << k);
+            // d sin = fr*cos ; d cos = -fr*sin
+            g[c] += (h ? -fr * other : fr * other) * ge[2 + 4 * k + c];
+        }
+    float r0 = ge[0], r1 = ge[1];
+    // h=0: r0 -> x, r1 -> z ; h=1: r0 -> y, r1 -> t
+    float gx = g[0] + (h ? 0.f : r0), gy = g[1] + (h ? r0 : 0.f), gz = g[2] + (h ? 0.f : r1), gt = g[3] + (h ? r1 : 0.f);
+    gx += __shfl_xor(gx, 32); gy += __shfl_xor(gy, 32); gz += __shfl_xor(gz, 32); gt += __shfl_xor(gt, 32);
+    return make_float4(gx, gy, gz, gt);
+}
+
+// ---------------------------------------------------------------- weight-gradient kernel (split-K over tiles)
+// G[pA][pB] = sum_tiles sum_j A[pA][j] * B[pB][j]   (p-space: p = 2*reg + h)
+enum { BM_RAW = 0, BM_SILU = 1, BM_RELU = 2, BM_SILU_TAN = 3, BM_RELU_TAN = 4 };
+struct WgradJob {
+    const float* A; size_t a_tile_stride; int a_regs;      // rows of 64 floats; a_regs multiple of 16
+    const float* B; const float* B2; size_t b_tile_stride; int b_regs; int bmode;
+    const int* count; int cap_tiles;  // number of valid samples (device), tile capacity
+    int nrep; size_t a_rep_stride, b_rep_stride;   // replicate over e.g. (step,eval) blocks
+    float* slabs;                      // [nslab][ (32*MTA) * (32*KTB) + 32*MTA ]
+    int nslab;
+};
+#define MAX_WGRAD_JOBS 16
+struct WgradJobs { WgradJob j[MAX_WGRAD_JOBS]; int n; };
+__global__ void k_wgrad(WgradJobs jobs);
+
+// slab reduce + un-permute into the logical gradient tensors
+struct ReduceJob {
+    const float* slabs; int nslab; int MTA, KTB;
+    float* gW; float* gb; int out, in;
+    int row_kind, slot_kind;     // maps of the forward layer: rows of G = out rows (p-space of D layout), cols = input slots
+    float scale;
+};
+struct ReduceJobs { ReduceJob j[MAX_WGRAD_JOBS]; int n; };
+__global__ void k_wgrad_reduce(ReduceJobs jobs);
+
+// ---------------------------------------------------------------- helpers
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }

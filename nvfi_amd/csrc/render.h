@@ -1,0 +1,68 @@
+// render.h - argument blocks of the render kernels (render.hip)
+#pragma once
+#include <string.h>
+#include "common.h"
+#include "vel.h"
+
+struct SampleArgs {
+    nvfi_field_desc f;
+    int64_t R;
+    const float* o; const float* d; const float* u;
+    int train;
+    const int* inside;
+    float4* xw; float* xpre; uint8_t* valid; int* cnt;
+};
+
+struct DensityArgs {
+    nvfi_field_desc f;
+    const int* count; int64_t n_direct;
+    const int* list;
+    const float4* xw;
+    float tn; int per_point_t;
+    float* xpre; float* feat_out; float* sigma_out;
+    // backward
+    const float* gxpre;
+    nvfi_grads g;
+    const uint8_t* mflag; const float4* gxw; float4* gxk;
+};
+
+struct WeightArgs {
+    int64_t R; int S;
+    const float* xpre; const float4* xw;
+    float distance_scale, weight_thres, far_;
+    float* weight; uint8_t* mflag; float* acc; float* depth; int* cnt_m;
+    // backward
+    const int* off_m; const float4* rgbs; const float4* rgb_pre;
+    const float* g_rgb; const float* g_depth; const float* g_acc; const float* g_weight;
+    float* gxpre;
+    int white_bg;
+};
+
+struct FinalArgs {
+    int64_t R;
+    const int* off_m; const int* mlist;
+    const float* weight; const float4* rgbs; const float* acc;
+    int white_bg;
+    float4* rgb_pre; float* rgb;
+};
+
+struct AppArgs {
+    nvfi_field_desc f;
+    RenderFrags W;
+    const int* count; int64_t n_direct;
+    const int* list;
+    const float4* xw;
+    float tn; int per_point_t; int S;
+    const float* rays_d; const float* view_per_point;
+    float4* rgbs; int rgb_dense;
+    float* stash_f; float* stash_b;
+    // backward
+    nvfi_grads g;
+    const float* g_rgb; const float4* rgb_pre; const float* weight;
+    float4* gxw;
+};
+
+__global__ void k_counters(const int* c, int nsteps, int64_t* out);
+__global__ void k_unpack_rgb(const float4* in, float* out, int64_t N);
+int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, const int* count, int cap_tiles, int nrep,
+                     int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st);

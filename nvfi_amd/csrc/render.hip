@@ -1,0 +1,965 @@
+// render.hip - ray marching through the keyframe K-plane field: sampling, density gather, volume
+// weights, appearance MLP (fp32 MFMA), composite; and the hand-written backward of all of it.
+//
+// Reference semantics: models/tensorf_base.py:290-314 (sample_ray), models/tensorf_keyframe.py:233-325
+// (feature lookups, softplus), models/tensorf_model_utils.py:176-197 (PE, raw2alpha),
+// models/tensorf_base.py:67-98 (MLPRender_PE), models/tensorf_keyframe.py:641-755 (render_pts).
+//
+// Work decomposition (MI355X-first): the reference's boolean-mask gather/scatter with a host sync
+// per mask becomes on-device compaction (per-ray counts -> one-block scan -> ordered fill), so no
+// kernel launch depends on a host-visible count.  Gathers read channel-last planes with 16-byte
+// loads; per-ray scans/reductions are wave-level; the MLP contractions run on the MFMA engine.
+#include "common.h"
+#include "render.h"
+
+// ================================================================ sampling + compaction
+__global__ void k_any_inside(nvfi_field_desc f, int64_t R, const float* __restrict__ o, int* flag) {
+    // tensorf_base.py:294: ((aabb0 <= o) & (o <= aabb1)).any() over every coordinate of every ray
+    bool hit = false;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < R * 3; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % 3);
+        float v = o[i];
+        if (f.aabb[c] <= v && v <= f.aabb[3 + c]) hit = true;
+    }
+    if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__device__ __forceinline__ float ray_tmin(const nvfi_field_desc& f, bool inside, const float* o, const float* d) {
+    if (inside) return f.near_;
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float vec = d[c] == 0.f ? 1e-6f : d[c];
+        float ra = (f.aabb[3 + c] - o[c]) / vec;
+        float rb = (f.aabb[c] - o[c]) / vec;
+        m = fmaxf(m, fminf(ra, rb));
+    }
+    return fminf(fmaxf(m, f.near_), f.far_);
+}
+
+__device__ __forceinline__ float alpha_lookup(const nvfi_field_desc& f, float x, float y, float z) {
+    // AlphaGridMask.sample_alpha: trilinear, align_corners=True, zeros padding (tensorf_model_utils.py:433-439)
+    const int W = f.am_dims[0], H = f.am_dims[1], D = f.am_dims[2];
+    float ix = (x + 1.f) * ((float)(W - 1) / 2.f), iy = (y + 1.f) * ((float)(H - 1) / 2.f), iz = (z + 1.f) * ((float)(D - 1) / 2.f);
+    float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    float wx = ix - fx, wy = iy - fy, wz = iz - fz;
+    fx = fminf(fmaxf(fx, -4.f), W + 2.f); fy = fminf(fmaxf(fy, -4.f), H + 2.f); fz = fminf(fmaxf(fz, -4.f), D + 2.f);
+    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    float s = 0.f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+                if (xi < 0 || xi >= W || yi < 0 || yi >= H || zi < 0 || zi >= D) continue;
+                float w = (dx ? wx : 1.f - wx) * (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
+                s += f.amask[((size_t)zi * H + yi) * W + xi] * w;
+            }
+    return s;
+}
+
+// one wave per ray
+__global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const nvfi_field_desc& f = a.f;
+    const int S = f.n_samples;
+    float o[3] = {a.o[3 * r], a.o[3 * r + 1], a.o[3 * r + 2]};
+    float d[3] = {a.d[3 * r], a.d[3 * r + 1], a.d[3 * r + 2]};
+    const float tmin = ray_tmin(f, *a.inside != 0, o, d);
+    const float u = (a.train && a.u) ? a.u[r] : 0.f;
+    int cnt = 0;
+    for (int j0 = 0; j0 < S; j0 += 64) {
+        const int j = j0 + lane;
+        bool ok = false;
+        if (j < S) {
+            float rng = (float)j + u;
+            float step = f.step_size * rng;
+            float z = tmin + step;
+            float p[3], xn[3];
+            ok = true;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                p[c] = o[c] + d[c] * z;
+                if (f.aabb[c] > p[c] || p[c] > f.aabb[3 + c]) ok = false;
+                xn[c] = norm_coord(f, c, p[c]);
+            }
+            if (ok && f.has_amask && !a.train) ok = alpha_lookup(f, xn[0], xn[1], xn[2]) > 0.f;
+            const int64_t n = r * S + j;
+            a.xw[n] = make_float4(xn[0], xn[1], xn[2], z);
+            a.xpre[n] = XPRE_INVALID;
+            a.valid[n] = ok ? 1 : 0;
+        }
+        cnt += __popcll(__ballot(ok));
+    }
+    if (lane == 0) a.cnt[r] = cnt;
+}
+
+// exclusive scan of n int32 counts (single workgroup), off[n] = total, *total_out = total
+__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ cnt, int* __restrict__ off, int64_t n, int* total_out) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        int64_t i = base + tid;
+        int v = i < n ? cnt[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        int carry = carry_s;
+        if (i < n) off[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) { off[n] = carry_s; *total_out = carry_s; }
+}
+
+// ordered fill of the compact list: list[off[r] + rank] = dense index
+__global__ __launch_bounds__(256) void k_fill(int64_t R, int S, const uint8_t* __restrict__ flags, const int* __restrict__ off, int* __restrict__ list) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    int base = off[r];
+    for (int j0 = 0; j0 < S; j0 += 64) {
+        const int j = j0 + lane;
+        bool ok = j < S && flags[r * S + j];
+        unsigned long long b = __ballot(ok);
+        if (ok) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (int)(r * S + j);
+        base += __popcll(b);
+    }
+}
+
+// ================================================================ density
+__device__ __forceinline__ float density_feature(const nvfi_field_desc& f, float x, float y, float z, float tn) {
+    Bl b[6];
+    plane_setups(f, x, y, z, tn, b);
+    float sum = 0.f;
+    const int nq = f.Cd >> 2;
+    for (int q4 = 0; q4 < nq; ++q4) {
+        float4 s0 = bl_sample4(f.dps[0], f.Cd, b[0], q4), s1 = bl_sample4(f.dps[1], f.Cd, b[1], q4), s2 = bl_sample4(f.dps[2], f.Cd, b[2], q4);
+        float4 t0 = bl_sample4(f.dpt[0], f.Cd, b[3], q4), t1 = bl_sample4(f.dpt[1], f.Cd, b[4], q4), t2 = bl_sample4(f.dpt[2], f.Cd, b[5], q4);
+        sum += ((s0.x * s1.x) * s2.x) * ((t0.x * t1.x) * t2.x);
+        sum += ((s0.y * s1.y) * s2.y) * ((t0.y * t1.y) * t2.y);
+        sum += ((s0.z * s1.z) * s2.z) * ((t0.z * t1.z) * t2.z);
+        sum += ((s0.w * s1.w) * s2.w) * ((t0.w * t1.w) * t2.w);
+    }
+    return sum;
+}
+
+__global__ __launch_bounds__(256) void k_density_fwd(DensityArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int count = a.count ? *a.count : (int)a.n_direct;
+    if (i >= count) return;
+    const int n = a.list ? a.list[i] : i;
+    const float4 q = a.xw[n];
+    const float tn = a.per_point_t ? q.w : a.tn;
+    const float ft = density_feature(a.f, q.x, q.y, q.z, tn);
+    if (a.feat_out) a.feat_out[n] = ft;
+    if (a.xpre) a.xpre[n] = ft + a.f.density_shift;
+    if (a.sigma_out) a.sigma_out[n] = softplus_f(ft + a.f.density_shift);
+}
+
+// backward: gxpre -> plane grads (atomics) + coordinate grads
+__global__ __launch_bounds__(256) void k_density_bwd(DensityArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int count = *a.count;
+    if (i >= count) return;
+    const nvfi_field_desc& f = a.f;
+    const int n = a.list[i];
+    const float4 q = a.xw[n];
+    const float gf = a.gxpre[n];
+    Bl b[6];
+    plane_setups(f, q.x, q.y, q.z, a.tn, b);
+    float gx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gy[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* pl[6] = {f.dps[0], f.dps[1], f.dps[2], f.dpt[0], f.dpt[1], f.dpt[2]};
+    float* gp[6] = {a.g.dps[0], a.g.dps[1], a.g.dps[2], a.g.dpt[0], a.g.dpt[1], a.g.dpt[2]};
+    const int nq = f.Cd >> 2;
+    for (int q4 = 0; q4 < nq; ++q4) {
+        float4 v[6];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) v[p] = bl_sample4(pl[p], f.Cd, b[p], q4);
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            float4 o = make_float4(gf, gf, gf, gf);
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (k != p) { o.x *= v[k].x; o.y *= v[k].y; o.z *= v[k].z; o.w *= v[k].w; }
+            bl_backward4(pl[p], gp[p], f.Cd, b[p], q4, o, gx[p], gy[p]);
+        }
+    }
+    float g3[3] = {0.f, 0.f, 0.f};
+    {
+        float mx, my;
+        plane_mults(f, 0, mx, my); g3[0] += gx[0] * mx; g3[1] += gy[0] * my;
+        plane_mults(f, 1, mx, my); g3[0] += gx[1] * mx; g3[2] += gy[1] * my;
+        plane_mults(f, 2, mx, my); g3[1] += gx[2] * mx; g3[2] += gy[2] * my;
+        plane_mults(f, 3, mx, my); g3[2] += gx[3] * mx;
+        plane_mults(f, 4, mx, my); g3[1] += gx[4] * mx;
+        plane_mults(f, 5, mx, my); g3[0] += gx[5] * mx;
+    }
+    if (a.gxk) {
+        float4 ga = a.mflag[n] ? a.gxw[n] : zero4();   // appearance-branch part (masked samples only)
+        a.gxk[i] = make_float4(ga.x + g3[0], ga.y + g3[1], ga.z + g3[2], 0.f);
+    }
+}
+
+// ================================================================ volume weights (raw2alpha) + composites
+// one wave per ray; 64-sample segments with a carried transmittance
+__global__ __launch_bounds__(256) void k_weights_fwd(WeightArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int S = a.S;
+    float carry = 1.f, accs = 0.f, dep = 0.f;
+    int cnt = 0;
+    for (int j0 = 0; j0 < S; j0 += 64) {
+        const int j = j0 + lane;
+        const bool in = j < S;
+        const int64_t n = r * S + j;
+        float sig = 0.f, dist = 0.f, z = 0.f;
+        if (in) {
+            sig = softplus_f(a.xpre[n]);
+            z = a.xw[n].w;
+            if (j + 1 < S) dist = (a.xw[n + 1].w - z) * a.distance_scale;
+        }
+        const float al = 1.f - expf(-sig * dist);
+        const float fct = 1.f - al + 1e-10f;
+        float p = fct;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(p, o); if (lane >= o) p *= t; }
+        float ex = __shfl_up(p, 1);
+        if (lane == 0) ex = 1.f;
+        const float T = carry * ex;
+        const float w = al * T;
+        carry = carry * __shfl(p, 63);
+        const bool m = in && w > a.weight_thres;
+        if (in) { a.weight[n] = w; a.mflag[n] = m ? 1 : 0; accs += w; dep += w * z; }
+        cnt += __popcll(__ballot(m));
+    }
+    accs = wave_sum(accs); dep = wave_sum(dep);
+    if (lane == 0) {
+        a.acc[r] = accs;
+        a.depth[r] = dep + (1.f - accs) * a.far_;
+        a.cnt_m[r] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_final_fwd(FinalArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int b0 = a.off_m[r], b1 = a.off_m[r + 1];
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int i = b0 + lane; i < b1; i += 64) {
+        const float w = a.weight[a.mlist[i]];
+        const float4 c = a.rgbs[i];
+        c0 += w * c.x; c1 += w * c.y; c2 += w * c.z;
+    }
+    c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+    if (lane == 0) {
+        if (a.white_bg) { float bg = 1.f - a.acc[r]; c0 += bg; c1 += bg; c2 += bg; }
+        a.rgb_pre[r] = make_float4(c0, c1, c2, 0.f);
+        a.rgb[3 * r] = fminf(fmaxf(c0, 0.f), 1.f);
+        a.rgb[3 * r + 1] = fminf(fmaxf(c1, 0.f), 1.f);
+        a.rgb[3 * r + 2] = fminf(fmaxf(c2, 0.f), 1.f);
+    }
+}
+
+// backward of composites + raw2alpha: produces d/d(xpre) per sample
+__global__ __launch_bounds__(256) void k_weights_bwd(WeightArgs a) {
+    __shared__ float carries[4][17];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    if (r >= a.R) return;
+    const int S = a.S;
+    const int nseg = (S + 63) >> 6;
+    // upstream
+    float gr[3] = {0.f, 0.f, 0.f};
+    if (a.g_rgb) {
+        const float4 pre = a.rgb_pre[r];
+        const float pv[3] = {pre.x, pre.y, pre.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gr[c] = (pv[c] >= 0.f && pv[c] <= 1.f) ? a.g_rgb[3 * r + c] : 0.f;
+    }
+    const float gd = a.g_depth ? a.g_depth[r] : 0.f, ga = a.g_acc ? a.g_acc[r] : 0.f;
+    const float bgsum = a.white_bg ? (gr[0] + gr[1] + gr[2]) : 0.f;
+    // pass 1: carried transmittance at the start of each segment
+    float carry = 1.f;
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int j = sg * 64 + lane;
+        const int64_t n = r * S + j;
+        float sig = 0.f, dist = 0.f;
+        if (j < S) {
+            sig = softplus_f(a.xpre[n]);
+            if (j + 1 < S) dist = (a.xw[n + 1].w - a.xw[n].w) * a.distance_scale;
+        }
+        const float al = 1.f - expf(-sig * dist);
+        float p = 1.f - al + 1e-10f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(p, o); if (lane >= o) p *= t; }
+        if (lane == 0) carries[wv][sg] = carry;
+        carry = carry * __shfl(p, 63);
+    }
+    // pass 2: reverse segments
+    float suffix = 0.f;   // sum_{i>j} gw_i w_i over later segments
+    int mrank_end = a.off_m[r + 1];
+    for (int sg = nseg - 1; sg >= 0; --sg) {
+        const int j = sg * 64 + lane;
+        const bool in = j < S;
+        const int64_t n = r * S + j;
+        float sig = 0.f, dist = 0.f, z = 0.f, xp = XPRE_INVALID;
+        bool m = false;
+        if (in) {
+            xp = a.xpre[n];
+            sig = softplus_f(xp);
+            z = a.xw[n].w;
+            if (j + 1 < S) dist = (a.xw[n + 1].w - z) * a.distance_scale;
+            m = a.mflag[n] != 0;
+        }
+        const float al = 1.f - expf(-sig * dist);
+        const float fct = 1.f - al + 1e-10f;
+        float p = fct;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(p, o); if (lane >= o) p *= t; }
+        float ex = __shfl_up(p, 1);
+        if (lane == 0) ex = 1.f;
+        const float T = carries[wv][sg] * ex;
+        const float w = al * T;
+        // colour of masked samples comes from the compact list (ray-ordered)
+        const unsigned long long mb = __ballot(m);
+        const int seg_cnt = __popcll(mb);
+        float gw = -bgsum + ga + gd * (z - a.far_) + ((a.g_weight && in) ? a.g_weight[n] : 0.f);
+        if (m) {
+            const int mi = mrank_end - seg_cnt + __popcll(mb & ((1ull << lane) - 1ull));
+            const float4 c = a.rgbs[mi];
+            gw += gr[0] * c.x + gr[1] * c.y + gr[2] * c.z;
+        }
+        mrank_end -= seg_cnt;
+        if (!in) gw = 0.f;
+        // suffix sums within the segment: s_j = sum_{i>j} gw_i w_i
+        float v = gw * w, inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { float t = __shfl_down(inc, o); if (lane + o < 64) inc += t; }
+        const float suf = suffix + (inc - v);
+        suffix = suffix + __shfl(inc, 0);
+        if (in) {
+            const float galpha = gw * T - suf / fct;
+            const float gsig = galpha * dist * (1.f - al);
+            a.gxpre[n] = gsig * (xp > 20.f ? 1.f : sigmoid_f(xp));
+        }
+    }
+}
+
+// ================================================================ appearance (MFMA)
+// Per-lane scratch in the (idle) weight LDS region: row k of thread tid lives at scr[k*256 + tid].
+// Loop-computed values (gathers, sincos) go through it so that the big register arrays keep static indices.
+#define SCR_OFF (8 * 256)
+
+__device__ __forceinline__ void app_gather_to_scratch(const nvfi_field_desc& f, const Bl* b, int h, float* scr) {
+    // lane (j,h) holds channels 4*(2a+h)+c, a=0..5  (= the B-operand layout of the basis_mat layer)
+#pragma unroll 1
+    for (int a6 = 0; a6 < 6; ++a6) {
+        const int q4 = 2 * a6 + h;
+        float4 s0 = bl_sample4(f.aps[0], f.Ca, b[0], q4), s1 = bl_sample4(f.aps[1], f.Ca, b[1], q4), s2 = bl_sample4(f.aps[2], f.Ca, b[2], q4);
+        float4 t0 = bl_sample4(f.apt[0], f.Ca, b[3], q4), t1 = bl_sample4(f.apt[1], f.Ca, b[4], q4), t2 = bl_sample4(f.apt[2], f.Ca, b[5], q4);
+        scr[(4 * a6 + 0) * 256 + threadIdx.x] = ((s0.x * s1.x) * s2.x) * ((t0.x * t1.x) * t2.x);
+        scr[(4 * a6 + 1) * 256 + threadIdx.x] = ((s0.y * s1.y) * s2.y) * ((t0.y * t1.y) * t2.y);
+        scr[(4 * a6 + 2) * 256 + threadIdx.x] = ((s0.z * s1.z) * s2.z) * ((t0.z * t1.z) * t2.z);
+        scr[(4 * a6 + 3) * 256 + threadIdx.x] = ((s0.w * s1.w) * s2.w) * ((t0.w * t1.w) * t2.w);
+    }
+}
+
+template <bool STASH>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
+    const nvfi_field_desc& f = a.f;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int count = a.count ? *a.count : (int)a.n_direct;
+    if ((int)(blockIdx.x * WG_SAMPLES) >= count) return;
+    const int tile = blockIdx.x * 4 + wave_id();
+    const int i = tile * TILE + (lane & 31);
+    const bool active = i < count;
+    const int n = active ? (a.list ? a.list[i] : i) : 0;
+    float4 q = active ? a.xw[n] : zero4();
+    const float tn = a.per_point_t ? q.w : a.tn;
+    float vd[3] = {0.f, 0.f, 0.f};
+    if (active) {
+        const float* vp = a.view_per_point ? a.view_per_point + 3 * (size_t)n : a.rays_d + 3 * (size_t)(n / a.S);
+        vd[0] = vp[0]; vd[1] = vp[1]; vd[2] = vp[2];
+    }
+    float x[64];
+    float* scr = lds_w + SCR_OFF;
+    {
+        Bl b[6];
+        plane_setups(f, q.x, q.y, q.z, tn, b);
+        app_gather_to_scratch(f, b, h, scr);
+    }
+#pragma unroll
+    for (int s = 0; s < 24; ++s) x[s] = scr[s * 256 + threadIdx.x];
+    float* st = STASH ? a.stash_f + (size_t)tile * (APP_F_ROWS * REGF) : nullptr;
+    if (STASH) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) st[s * REGF + lane] = s < 24 ? x[s] : 0.f;
+    }
+    // positional encodings (tensorf_model_utils.py:176-183) -> scratch rows 0..35 (sin|cos selected by h)
+#pragma unroll 1
+    for (int e = 0; e < 18; ++e) {
+        const int c = e / 6, k = e - 6 * c;
+        const float fr = (float)(1 << k);
+        const float pc = c == 0 ? q.x : (c == 1 ? q.y : q.z);
+        const float vc = c == 0 ? vd[0] : (c == 1 ? vd[1] : vd[2]);
+        float sn, cs;
+        sincosf(pc * fr, &sn, &cs);
+        scr[e * 256 + threadIdx.x] = h ? cs : sn;
+        sincosf(vc * fr, &sn, &cs);
+        scr[(18 + e) * 256 + threadIdx.x] = h ? cs : sn;
+    }
+    // basis_mat: 48 -> 32 (no bias); its fragment occupies LDS rows below SCR_OFF
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.fb, RF_B, nullptr, 0);
+    __syncthreads();
+    f32x16 o1[1];
+    acc_init<1>(o1, lds_b, h, false);
+    layer_mfma<1, 24>(lds_w, lane, x, o1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = o1[0][r];
+    x[16] = h ? q.x : vd[0]; x[17] = h ? q.y : vd[1]; x[18] = h ? q.z : vd[2];
+#pragma unroll
+    for (int e = 0; e < 18; ++e) { x[19 + e] = scr[e * 256 + threadIdx.x]; x[37 + e] = scr[(18 + e) * 256 + threadIdx.x]; }
+#pragma unroll
+    for (int s = 55; s < 64; ++s) x[s] = 0.f;
+    if (STASH) stash_store<64>(st + 32 * REGF, lane, x);
+    f32x16 acc[4];
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f1, RF_1, a.W.b1, 128);
+    __syncthreads();
+    acc_init<4>(acc, lds_b, h, true);
+    layer_mfma<4, 55>(lds_w, lane, x, acc);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[16 * m + r] = fmaxf(acc[m][r], 0.f);
+    if (STASH) stash_store<64>(st + 96 * REGF, lane, x);
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f2, RF_2, a.W.b2, 128);
+    __syncthreads();
+    acc_init<4>(acc, lds_b, h, true);
+    layer_mfma<4, 64>(lds_w, lane, x, acc);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[16 * m + r] = fmaxf(acc[m][r], 0.f);
+    if (STASH) stash_store<64>(st + 160 * REGF, lane, x);
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f3, RF_3, a.W.b3, 32);
+    __syncthreads();
+    acc_init<1>(o1, lds_b, h, true);
+    layer_mfma<1, 64>(lds_w, lane, x, o1);
+    if (active && h == 0) {
+        float4 c = make_float4(sigmoid_f(o1[0][0]), sigmoid_f(o1[0][1]), sigmoid_f(o1[0][2]), 0.f);
+        a.rgbs[a.rgb_dense ? n : i] = c;
+    }
+}
+
+// backward of the appearance branch for masked samples
+__global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
+    const nvfi_field_desc& f = a.f;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int count = *a.count;
+    if ((int)(blockIdx.x * WG_SAMPLES) >= count) return;
+    const int tile = blockIdx.x * 4 + wave_id();
+    const int i = tile * TILE + (lane & 31);
+    const bool active = i < count;
+    const int n = active ? a.list[i] : 0;
+    const float* stf = a.stash_f + (size_t)tile * (APP_F_ROWS * REGF);
+    float* stb = a.stash_b + (size_t)tile * (APP_B_ROWS * REGF);
+    float g[64];
+    f32x16 acc[4];
+    // seeds: go_c = w * gr_c * c(1-c) in rows 0..2 of a D tile (lane h=0 regs 0..2)
+    {
+        float go[3] = {0.f, 0.f, 0.f};
+        if (active && h == 0 && a.g_rgb) {
+            const int r = n / a.S;
+            const float4 pre = a.rgb_pre[r];
+            const float pv[3] = {pre.x, pre.y, pre.z};
+            const float4 c = a.rgbs[i];
+            const float cv[3] = {c.x, c.y, c.z};
+            const float w = a.weight[n];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float gr = (pv[k] >= 0.f && pv[k] <= 1.f) ? a.g_rgb[3 * (size_t)r + k] : 0.f;
+                go[k] = w * gr * cv[k] * (1.f - cv[k]);
+            }
+        }
+        g[0] = go[0]; g[1] = go[1]; g[2] = go[2]; g[3] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) stb[s * REGF + lane] = s < 3 ? g[s] : 0.f;
+    }
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.t3, RT_3, nullptr, 0);
+    __syncthreads();
+    acc_init<4>(acc, lds_b, 0, false);
+    layer_mfma<4, 4>(lds_w, lane, g, acc);
+    {
+        const float* h2 = stf + 160 * REGF;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = h2[(16 * m + r) * REGF + lane] > 0.f ? acc[m][r] : 0.f;
+    }
+    stash_store<64>(stb + 16 * REGF, lane, g);
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.t2, RT_2, nullptr, 0);
+    __syncthreads();
+    acc_init<4>(acc, lds_b, 0, false);
+    layer_mfma<4, 64>(lds_w, lane, g, acc);
+    {
+        const float* h1 = stf + 96 * REGF;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = h1[(16 * m + r) * REGF + lane] > 0.f ? acc[m][r] : 0.f;
+    }
+    stash_store<64>(stb + 80 * REGF, lane, g);
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.t1, RT_1, nullptr, 0);
+    __syncthreads();
+    acc_init<4>(acc, lds_b, 0, false);
+    layer_mfma<4, 64>(lds_w, lane, g, acc);
+    // acc = gradient wrt the 110 input slots (RENDER_IN layout)
+    float gpts[3];
+    {
+        const float* xin = stf + 32 * REGF;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s = h ? acc[1][c] : 0.f;          // slots 16..18: h=1 holds raw pts
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int sl = 19 + c * 6 + k;
+                const float mine = xin[sl * REGF + lane];
+                const float other = __shfl_xor(mine, 32);
+                const float fr = (float)(1 << k);
+                s += (h ? -fr * other : fr * other) * acc[sl >> 4][sl & 15];
+            }
+            s += __shfl_xor(s, 32);
+            gpts[c] = s;
+        }
+    }
+    // gfeat (tile 0) -> stash, then basis^T -> gg (48 channels in gather layout)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { g[r] = acc[0][r]; stb[(144 + r) * REGF + lane] = g[r]; }
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.tb, RT_B, nullptr, 0);
+    __syncthreads();
+    f32x16 gg[2];
+    acc_init<2>(gg, lds_b, 0, false);
+    layer_mfma<2, 16>(lds_w, lane, g, gg);
+    // plane backward for this lane's 24 channels (channel grads via LDS scratch -> non-unrolled loop)
+    float* scr = lds_w + SCR_OFF;
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < 24; ++s2) scr[s2 * 256 + threadIdx.x] = active ? gg[s2 >> 4][s2 & 15] : 0.f;
+    float4 q = active ? a.xw[n] : zero4();
+    Bl b[6];
+    plane_setups(f, q.x, q.y, q.z, a.tn, b);
+    float gx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gy[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int a6 = 0; a6 < 6; ++a6) {
+        const int q4 = 2 * a6 + h;
+        const float4 gq = make_float4(scr[(4 * a6) * 256 + threadIdx.x], scr[(4 * a6 + 1) * 256 + threadIdx.x],
+                                      scr[(4 * a6 + 2) * 256 + threadIdx.x], scr[(4 * a6 + 3) * 256 + threadIdx.x]);
+        float4 v[6];
+        v[0] = bl_sample4(f.aps[0], f.Ca, b[0], q4); v[1] = bl_sample4(f.aps[1], f.Ca, b[1], q4); v[2] = bl_sample4(f.aps[2], f.Ca, b[2], q4);
+        v[3] = bl_sample4(f.apt[0], f.Ca, b[3], q4); v[4] = bl_sample4(f.apt[1], f.Ca, b[4], q4); v[5] = bl_sample4(f.apt[2], f.Ca, b[5], q4);
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            float4 o = gq;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (k != p) { o.x *= v[k].x; o.y *= v[k].y; o.z *= v[k].z; o.w *= v[k].w; }
+            const float* pl = p == 0 ? f.aps[0] : p == 1 ? f.aps[1] : p == 2 ? f.aps[2] : p == 3 ? f.apt[0] : p == 4 ? f.apt[1] : f.apt[2];
+            float* gp = p == 0 ? a.g.aps[0] : p == 1 ? a.g.aps[1] : p == 2 ? a.g.aps[2] : p == 3 ? a.g.apt[0] : p == 4 ? a.g.apt[1] : a.g.apt[2];
+            bl_backward4(pl, active ? gp : nullptr, f.Ca, b[p], q4, o, gx[p], gy[p]);
+        }
+    }
+    float g3[3] = {0.f, 0.f, 0.f};
+    {
+        float mx, my;
+        plane_mults(f, 0, mx, my); g3[0] += gx[0] * mx; g3[1] += gy[0] * my;
+        plane_mults(f, 1, mx, my); g3[0] += gx[1] * mx; g3[2] += gy[1] * my;
+        plane_mults(f, 2, mx, my); g3[1] += gx[2] * mx; g3[2] += gy[2] * my;
+        plane_mults(f, 3, mx, my); g3[2] += gx[3] * mx;
+        plane_mults(f, 4, mx, my); g3[1] += gx[4] * mx;
+        plane_mults(f, 5, mx, my); g3[0] += gx[5] * mx;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g3[c] += __shfl_xor(g3[c], 32);
+    if (active && h == 0) a.gxw[n] = make_float4(g3[0] + gpts[0], g3[1] + gpts[1], g3[2] + gpts[2], 0.f);
+}
+
+// ================================================================ host: fragment jobs, launches, ABI
+int pack_render_frags(const nvfi_field_desc* f, float* buf, RenderFrags* out, PackJobs* jobs) {
+    float* p = buf;
+    auto take = [&](int n) { float* r = p; p += n; return r; };
+    float* fb = take(RF_B); float* f1 = take(RF_1); float* f2 = take(RF_2); float* f3 = take(RF_3);
+    float* b1 = take(128); float* b2 = take(128); float* b3 = take(32);
+    float* t3 = take(RT_3); float* t2 = take(RT_2); float* t1 = take(RT_1); float* tb = take(RT_B);
+    auto add = [&](const float* W, const float* b, float* frag, float* bfrag, int o, int in, int MT, int NS, int rk, int sk, int tr) {
+        if (jobs->n >= MAX_PACK_JOBS) return 1;
+        PackJob& J = jobs->j[jobs->n++];
+        J.W = W; J.b = b; J.frag = frag; J.bfrag = bfrag; J.out = o; J.in = in; J.MT = MT; J.NS = NS;
+        J.row_kind = rk; J.slot_kind = sk; J.transposed = tr;
+        return 0;
+    };
+    int rc = 0;
+    rc |= add(f->basis, nullptr, fb, nullptr, f->app_dim, f->Ca, 1, 24, RK_NATURAL, SK_HIDDEN, 0);
+    rc |= add(f->rW[0], f->rb[0], f1, b1, 128, 110, 4, 55, RK_NATURAL, SK_RENDER_IN, 0);
+    rc |= add(f->rW[1], f->rb[1], f2, b2, 128, 128, 4, 64, RK_NATURAL, SK_HIDDEN, 0);
+    rc |= add(f->rW[2], f->rb[2], f3, b3, 3, 128, 1, 64, RK_NATURAL, SK_HIDDEN, 0);
+    rc |= add(f->rW[2], nullptr, t3, nullptr, 3, 128, 4, 4, RK_NATURAL, SK_HIDDEN, 1);
+    rc |= add(f->rW[1], nullptr, t2, nullptr, 128, 128, 4, 64, RK_NATURAL, SK_HIDDEN, 1);
+    rc |= add(f->rW[0], nullptr, t1, nullptr, 128, 110, 4, 64, RK_RENDER_IN, SK_HIDDEN, 1);
+    rc |= add(f->basis, nullptr, tb, nullptr, f->app_dim, f->Ca, 2, 16, RK_NATURAL, SK_HIDDEN, 1);
+    if (rc) return nvfi_fail(3, "too many pack jobs");
+    out->fb = fb; out->f1 = f1; out->b1 = b1; out->f2 = f2; out->b2 = b2; out->f3 = f3; out->b3 = b3;
+    out->t3 = t3; out->t2 = t2; out->t1 = t1; out->tb = tb;
+    return 0;
+}
+
+static int check_desc(const nvfi_field_desc* f) {
+    if (f->Cd != 24 || f->Ca != 48 || f->app_dim != 32)
+        return nvfi_fail(2, "unsupported component counts Cd=%d Ca=%d app_dim=%d (kernels are built for 24/48/32)", f->Cd, f->Ca, f->app_dim);
+    if (f->n_samples < 1 || f->n_samples > 1024) return nvfi_fail(2, "n_samples=%d outside [1,1024]", f->n_samples);
+    return 0;
+}
+
+// number of RK2 steps and their (dt, t) sequence for a per-call scalar t (tensorf_keyframe.py:575-609)
+static int rk_schedule(const nvfi_field_desc* f, float t, int flags, float* base_out, float* dts, float* tcs) {
+    float base = (flags & NVFI_TRANSFER) ? 0.f : snap_base(*f, t);
+    *base_out = base;
+    if (!f->use_vel || is_close(t, base)) return 0;
+    float dtm = dt_max_of(*f), off = t - base, tc = t;
+    int n = 0;
+    while (fabsf(off) > 0.f) {
+        if (n >= MAX_RK_STEPS) return -1;
+        float m = fabsf(off) < dtm ? fabsf(off) : dtm;
+        float dt = off > 0.f ? m : -m;
+        dts[n] = dt; tcs[n] = tc;
+        off = off - dt; tc = tc - dt;
+        ++n;
+    }
+    return n;
+}
+
+struct RenderPlan {
+    int64_t N, cap_tiles;
+    int nsteps;
+    int* counters;      // [0] V, [1] M, [2] inside flag
+    int *cnt_v, *off_v, *cnt_m, *off_m, *vlist, *mlist;
+    uint8_t *valid, *mflag;
+    float4 *xw, *rgbs, *rgb_pre, *gxw, *gxk;
+    float *xpre, *gxpre;
+    float *vel_frag, *render_frag;
+    float *app_f, *app_b, *zst, *x0st, *rec, *gst;
+    float *slabs;
+    int64_t total;
+};
+#define NSLAB 96
+#define SLAB_FLOATS (128 * 128 + 128)
+
+static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nsteps, void* ws, RenderPlan* P) {
+    Bump B{(char*)ws, 0, 0};
+    const int64_t N = R * f->n_samples;
+    const bool train = flags & NVFI_TRAIN;
+    P->N = N; P->nsteps = nsteps;
+    P->cap_tiles = (N + WG_SAMPLES - 1) / WG_SAMPLES * 4;   // whole workgroups: every wave of an active workgroup owns a stash tile
+    P->counters = B.take<int>(16);
+    P->cnt_v = B.take<int>(R); P->off_v = B.take<int>(R + 1);
+    P->cnt_m = B.take<int>(R); P->off_m = B.take<int>(R + 1);
+    P->vlist = B.take<int>(N); P->mlist = B.take<int>(N);
+    P->valid = B.take<uint8_t>(N); P->mflag = B.take<uint8_t>(N);
+    P->xw = B.take<float4>(N + 1); P->rgbs = B.take<float4>(N); P->rgb_pre = B.take<float4>(R);
+    P->xpre = B.take<float>(N);
+    P->vel_frag = B.take<float>(VEL_FRAG_FLOATS);
+    P->render_frag = B.take<float>(RENDER_FRAG_FLOATS);
+    P->app_f = P->app_b = P->zst = P->x0st = P->rec = P->gst = P->slabs = nullptr;
+    P->gxw = P->gxk = nullptr; P->gxpre = nullptr;
+    if (train) {
+        P->gxw = B.take<float4>(N); P->gxk = B.take<float4>(N); P->gxpre = B.take<float>(N);
+        P->app_f = B.take<float>(P->cap_tiles * (int64_t)(APP_F_ROWS * REGF));
+        P->app_b = B.take<float>(P->cap_tiles * (int64_t)(APP_B_ROWS * REGF));
+        P->slabs = B.take<float>((int64_t)NSLAB * SLAB_FLOATS * 6);
+        if (nsteps > 0) {
+            const int64_t nev = 2 * (int64_t)nsteps;
+            P->zst = B.take<float>(nev * P->cap_tiles * (int64_t)(VEL_Z_REGS * REGF));
+            P->x0st = B.take<float>(nev * P->cap_tiles * (int64_t)(VEL_X0_REGS * REGF));
+            P->gst = B.take<float>(nev * P->cap_tiles * (int64_t)(VEL_G_REGS * REGF));
+            P->rec = B.take<float>((int64_t)nsteps * RK_NF * N);
+        }
+    }
+    P->total = align_up(B.off, 256);
+}
+
+extern "C" int nvfi_render_workspace_bytes(const nvfi_field_desc* f, int64_t R, int flags, int64_t* bytes) {
+    if (check_desc(f)) return 2;
+    // t-independent upper bound: a training call may need up to 2 RK2 steps (|t-base| <= dt_max up to
+    // rounding); extrapolated times need more and are re-planned by the caller via nvfi_render_workspace_bytes_t.
+    RenderPlan P;
+    plan_render(f, R, flags, (f->use_vel && (flags & NVFI_TRAIN)) ? 2 : 0, nullptr, &P);
+    *bytes = P.total;
+    return 0;
+}
+extern "C" int nvfi_render_workspace_bytes_t(const nvfi_field_desc* f, int64_t R, int flags, float t, int64_t* bytes) {
+    if (check_desc(f)) return 2;
+    float base, dts[MAX_RK_STEPS], tcs[MAX_RK_STEPS];
+    int ns = rk_schedule(f, t, flags, &base, dts, tcs);
+    if (ns < 0) return nvfi_fail(2, "t=%g needs more than %d RK2 steps", t, MAX_RK_STEPS);
+    RenderPlan P;
+    plan_render(f, R, flags, ns, nullptr, &P);
+    *bytes = P.total;
+    return 0;
+}
+
+static int ensure_render_attrs() {
+    static bool done = false;
+    if (done) return 0;
+    HIPCK(hipFuncSetAttribute((const void*)k_app_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_app_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_app_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    done = true;
+    return 0;
+}
+
+extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d,
+                               const float* jitter, float t, int flags, float* rgb, float* depth, float* acc,
+                               float* weights, void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (check_desc(f)) return 2;
+    if (R <= 0) return 0;
+    if (R * (int64_t)f->n_samples >= (1ll << 31) - 64) return nvfi_fail(2, "R*S too large for one call; chunk the rays");
+    if (ensure_render_attrs() || ensure_lds_attrs()) return 1;
+    const bool train = flags & NVFI_TRAIN;
+    float base, dts[MAX_RK_STEPS], tcs[MAX_RK_STEPS];
+    const int nsteps = rk_schedule(f, t, flags, &base, dts, tcs);
+    if (nsteps < 0) return nvfi_fail(2, "t=%g needs more than %d RK2 steps", t, MAX_RK_STEPS);
+    RenderPlan P;
+    plan_render(f, R, flags, nsteps, workspace, &P);
+    if (P.total > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld bytes, got %lld", (long long)P.total, (long long)workspace_bytes);
+    const int S = f->n_samples;
+    const int64_t N = P.N;
+    const float tn = f->use_vel ? norm_time(*f, base) : norm_time(*f, t);
+    HIPCK(hipMemsetAsync(P.counters, 0, 16 * sizeof(int), st));
+    // fragments (weights change every optimiser step: repack per call, ~0.3 MB)
+    PackJobs jobs; jobs.n = 0;
+    VelFrags VW; RenderFrags RW;
+    if (f->use_vel && nsteps > 0) { if (pack_vel_frags(f->vW, f->vb, P.vel_frag, &VW, &jobs)) return 3; }
+    if (pack_render_frags(f, P.render_frag, &RW, &jobs)) return 3;
+    if (launch_pack(jobs, st)) return 1;
+    const unsigned ray_blocks = (unsigned)((R + 3) / 4);
+    // sampling
+    hipLaunchKernelGGL(k_any_inside, dim3(64), dim3(256), 0, st, *f, R, rays_o, P.counters + 2);
+    SampleArgs sa; sa.f = *f; sa.R = R; sa.o = rays_o; sa.d = rays_d; sa.u = jitter; sa.train = train; sa.inside = P.counters + 2;
+    sa.xw = P.xw; sa.xpre = P.xpre; sa.valid = P.valid; sa.cnt = P.cnt_v;
+    hipLaunchKernelGGL(k_sample, dim3(ray_blocks), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P.cnt_v, P.off_v, R, P.counters + 0);
+    hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.valid, P.off_v, P.vlist);
+    LAUNCHCK();
+    // velocity warp back to the keyframe
+    if (nsteps > 0) {
+        Rk2Args ra; memset(&ra, 0, sizeof(ra));
+        ra.f = *f; ra.Wv = VW; ra.count = P.counters + 0; ra.list = P.vlist; ra.xw = P.xw; ra.xout = nullptr;
+        ra.nsteps = nsteps;
+        for (int s = 0; s < nsteps; ++s) { ra.dt[s] = dts[s]; ra.tcur[s] = tcs[s]; }
+        ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles;
+        if (launch_rk2_fwd(ra, N, true, train, st)) return 1;
+    }
+    // density
+    DensityArgs da; memset(&da, 0, sizeof(da));
+    da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn;
+    hipLaunchKernelGGL(k_density_fwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da);
+    // weights
+    WeightArgs wa; memset(&wa, 0, sizeof(wa));
+    wa.R = R; wa.S = S; wa.xpre = P.xpre; wa.xw = P.xw; wa.distance_scale = f->distance_scale; wa.weight_thres = f->weight_thres;
+    wa.far_ = f->far_; wa.weight = weights; wa.mflag = P.mflag; wa.acc = acc; wa.depth = depth; wa.cnt_m = P.cnt_m;
+    hipLaunchKernelGGL(k_weights_fwd, dim3(ray_blocks), dim3(256), 0, st, wa);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P.cnt_m, P.off_m, R, P.counters + 1);
+    hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.mflag, P.off_m, P.mlist);
+    LAUNCHCK();
+    // appearance
+    AppArgs aa; memset(&aa, 0, sizeof(aa));
+    aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S;
+    aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f;
+    const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
+    if (train) hipLaunchKernelGGL(k_app_fwd<true>, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa);
+    else hipLaunchKernelGGL(k_app_fwd<false>, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa);
+    // composite
+    FinalArgs fa; fa.R = R; fa.off_m = P.off_m; fa.mlist = P.mlist; fa.weight = weights; fa.rgbs = P.rgbs; fa.acc = acc;
+    fa.white_bg = (flags & NVFI_WHITE_BG) ? 1 : 0; fa.rgb_pre = P.rgb_pre; fa.rgb = rgb;
+    hipLaunchKernelGGL(k_final_fwd, dim3(ray_blocks), dim3(256), 0, st, fa);
+    LAUNCHCK();
+    if (counters) {
+        hipLaunchKernelGGL(k_counters, dim3(1), dim3(64), 0, st, P.counters, nsteps, counters);
+        LAUNCHCK();
+    }
+    return 0;
+}
+
+extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d, float t,
+                               int flags, const float* weights, const float* g_rgb, const float* g_depth,
+                               const float* g_acc, const float* g_weights, const nvfi_grads* grads, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (check_desc(f)) return 2;
+    if (R <= 0) return 0;
+    if (!(flags & NVFI_TRAIN)) return nvfi_fail(2, "nvfi_render_bwd needs the workspace of a NVFI_TRAIN forward");
+    if (ensure_render_attrs() || ensure_lds_attrs()) return 1;
+    float base, dts[MAX_RK_STEPS], tcs[MAX_RK_STEPS];
+    const int nsteps = rk_schedule(f, t, flags, &base, dts, tcs);
+    RenderPlan P;
+    plan_render(f, R, flags, nsteps, workspace, &P);
+    if (P.total > workspace_bytes) return nvfi_fail(4, "workspace too small");
+    const int S = f->n_samples;
+    const int64_t N = P.N;
+    const float tn = f->use_vel ? norm_time(*f, base) : norm_time(*f, t);
+    const unsigned ray_blocks = (unsigned)((R + 3) / 4);
+    // fragments were packed by the forward into the same workspace
+    VelFrags VW; RenderFrags RW; PackJobs dummy; dummy.n = 0;
+    if (f->use_vel && nsteps > 0) pack_vel_frags(f->vW, f->vb, P.vel_frag, &VW, &dummy);
+    dummy.n = 0;
+    pack_render_frags(f, P.render_frag, &RW, &dummy);
+    // appearance branch
+    AppArgs aa; memset(&aa, 0, sizeof(aa));
+    aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S;
+    aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f; aa.stash_b = P.app_b; aa.g = *grads;
+    aa.g_rgb = g_rgb; aa.rgb_pre = P.rgb_pre; aa.weight = weights; aa.gxw = P.gxw;
+    const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
+    hipLaunchKernelGGL(k_app_bwd, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa);
+    LAUNCHCK();
+    // render-MLP weight gradients
+    {
+        WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
+        const size_t fs = APP_F_ROWS * REGF, bs = APP_B_ROWS * REGF;
+        auto add = [&](const float* A, int a_regs, const float* B, int b_regs, float* slabs, float* gW, float* gb, int out, int in, int sk) {
+            WgradJob& J = wj.j[wj.n++];
+            J.A = A; J.a_tile_stride = bs; J.a_regs = a_regs; J.B = B; J.B2 = nullptr; J.b_tile_stride = fs; J.b_regs = b_regs;
+            J.bmode = BM_RAW; J.count = P.counters + 1; J.cap_tiles = (int)P.cap_tiles; J.nrep = 1; J.a_rep_stride = 0; J.b_rep_stride = 0;
+            J.slabs = slabs; J.nslab = NSLAB;
+            ReduceJob& Q = rj.j[rj.n++];
+            Q.slabs = slabs; Q.nslab = NSLAB; Q.MTA = a_regs / 16; Q.KTB = b_regs / 16; Q.gW = gW; Q.gb = gb; Q.out = out; Q.in = in;
+            Q.row_kind = RK_NATURAL; Q.slot_kind = sk; Q.scale = 1.f;
+        };
+        float* sl = P.slabs;
+        if (grads->rW[2] || grads->rb[2]) add(P.app_b + 0, 16, P.app_f + 160 * REGF, 64, sl + 0 * (size_t)NSLAB * SLAB_FLOATS, grads->rW[2], grads->rb[2], 3, 128, SK_HIDDEN);
+        if (grads->rW[1] || grads->rb[1]) add(P.app_b + 16 * REGF, 64, P.app_f + 96 * REGF, 64, sl + 1 * (size_t)NSLAB * SLAB_FLOATS, grads->rW[1], grads->rb[1], 128, 128, SK_HIDDEN);
+        if (grads->rW[0] || grads->rb[0]) add(P.app_b + 80 * REGF, 64, P.app_f + 32 * REGF, 64, sl + 2 * (size_t)NSLAB * SLAB_FLOATS, grads->rW[0], grads->rb[0], 128, 110, SK_RENDER_IN);
+        if (grads->basis) add(P.app_b + 144 * REGF, 16, P.app_f + 0, 32, sl + 3 * (size_t)NSLAB * SLAB_FLOATS, grads->basis, nullptr, f->app_dim, f->Ca, SK_HIDDEN);
+        if (launch_wgrad(wj, rj, st)) return 1;
+    }
+    // composites + raw2alpha
+    WeightArgs wa; memset(&wa, 0, sizeof(wa));
+    wa.R = R; wa.S = S; wa.xpre = P.xpre; wa.xw = P.xw; wa.distance_scale = f->distance_scale; wa.weight_thres = f->weight_thres;
+    wa.far_ = f->far_; wa.mflag = P.mflag; wa.off_m = P.off_m; wa.rgbs = P.rgbs; wa.rgb_pre = P.rgb_pre;
+    wa.g_rgb = g_rgb; wa.g_depth = g_depth; wa.g_acc = g_acc; wa.g_weight = g_weights; wa.gxpre = P.gxpre;
+    wa.white_bg = (flags & NVFI_WHITE_BG) ? 1 : 0;
+    hipLaunchKernelGGL(k_weights_bwd, dim3(ray_blocks), dim3(256), 0, st, wa);
+    // density planes + coordinate grads
+    DensityArgs da; memset(&da, 0, sizeof(da));
+    da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn;
+    da.gxpre = P.gxpre; da.g = *grads; da.mflag = P.mflag; da.gxw = P.gxw; da.gxk = nsteps > 0 ? P.gxk : nullptr;
+    hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da);
+    LAUNCHCK();
+    // RK2 adjoint + velocity-net weight gradients
+    if (nsteps > 0) {
+        Rk2Args ra; memset(&ra, 0, sizeof(ra));
+        ra.f = *f; ra.Wv = VW; ra.count = P.counters + 0; ra.list = P.vlist; ra.xw = P.xw;
+        ra.nsteps = nsteps;
+        for (int s = 0; s < nsteps; ++s) { ra.dt[s] = dts[s]; ra.tcur[s] = tcs[s]; }
+        ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles; ra.gxk = P.gxk;
+        if (launch_rk2_bwd(ra, N, st)) return 1;
+        if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 0, (int)P.cap_tiles, 2 * nsteps, BM_SILU, P.slabs, NSLAB,
+                             grads->vW, grads->vb, 1.f, st)) return 1;
+    }
+    return 0;
+}
+
+// velocity-net weight gradients from the (z, x0, g) stashes of nrep evaluations
+int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, const int* count, int cap_tiles, int nrep,
+                     int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st) {
+    WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
+    const size_t zs = VEL_Z_REGS * REGF, gs = VEL_G_REGS * REGF, xs = VEL_X0_REGS * REGF;
+    for (int l = 0; l < 6; ++l) {
+        if (!gW[l] && !gb[l]) continue;
+        WgradJob& J = wj.j[wj.n++];
+        J.A = gst + (size_t)l * 64 * REGF; J.a_tile_stride = gs; J.a_regs = l < 5 ? 64 : 16; J.a_rep_stride = (size_t)cap_tiles * gs;
+        if (l == 0) { J.B = x0st; J.b_tile_stride = xs; J.b_regs = 16; J.bmode = BM_RAW; J.b_rep_stride = (size_t)cap_tiles * xs; }
+        else { J.B = zst + (size_t)(l - 1) * 64 * REGF; J.b_tile_stride = zs; J.b_regs = 64; J.bmode = act_mode; J.b_rep_stride = (size_t)cap_tiles * zs; }
+        J.B2 = nullptr; J.count = count; J.cap_tiles = cap_tiles; J.nrep = nrep;
+        J.slabs = slabs + (size_t)l * nslab * SLAB_FLOATS; J.nslab = nslab;
+        ReduceJob& Q = rj.j[rj.n++];
+        Q.slabs = J.slabs; Q.nslab = nslab; Q.MTA = J.a_regs / 16; Q.KTB = J.b_regs / 16; Q.gW = gW[l]; Q.gb = gb[l];
+        Q.out = l < 5 ? 128 : 6; Q.in = l == 0 ? 28 : 128; Q.row_kind = RK_NATURAL; Q.slot_kind = l == 0 ? SK_VEL_IN : SK_HIDDEN; Q.scale = scale;
+    }
+    return launch_wgrad(wj, rj, st);
+}
+
+__global__ void k_counters(const int* c, int nsteps, int64_t* out) {
+    if (threadIdx.x == 0) {
+        out[0] = c[0];
+        out[1] = nsteps > 0 ? c[0] : 0;
+        out[2] = c[1];
+        out[3] = (int64_t)c[0] * 2 * nsteps;
+        out[4] = out[5] = out[6] = out[7] = 0;
+    }
+}
+
+// ================================================================ building blocks
+extern "C" int nvfi_density_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, float* feat, float* sigma, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (check_desc(f)) return 2;
+    if (N <= 0) return 0;
+    DensityArgs da; memset(&da, 0, sizeof(da));
+    da.f = *f; da.count = nullptr; da.n_direct = N; da.list = nullptr; da.xw = reinterpret_cast<const float4*>(xyzt);
+    da.per_point_t = 1; da.feat_out = feat; da.sigma_out = sigma; da.xpre = nullptr;
+    hipLaunchKernelGGL(k_density_fwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da);
+    LAUNCHCK();
+    return 0;
+}
+
+extern "C" int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, const float* view, float* rgb,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (check_desc(f)) return 2;
+    if (N <= 0) return 0;
+    if (ensure_render_attrs()) return 1;
+    Bump B{(char*)workspace, 0, 0};
+    float* frag = B.take<float>(RENDER_FRAG_FLOATS);
+    float4* out4 = B.take<float4>(N);
+    if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
+    PackJobs jobs; jobs.n = 0; RenderFrags RW;
+    if (pack_render_frags(f, frag, &RW, &jobs)) return 3;
+    if (launch_pack(jobs, st)) return 1;
+    AppArgs aa; memset(&aa, 0, sizeof(aa));
+    aa.f = *f; aa.W = RW; aa.count = nullptr; aa.n_direct = N; aa.list = nullptr; aa.xw = reinterpret_cast<const float4*>(xyzt);
+    aa.per_point_t = 1; aa.S = 1; aa.view_per_point = view; aa.rgbs = out4; aa.rgb_dense = 1;
+    hipLaunchKernelGGL(k_app_fwd<false>, dim3((unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES)), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa);
+    hipLaunchKernelGGL(k_unpack_rgb, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, out4, rgb, N);
+    LAUNCHCK();
+    return 0;
+}
+__global__ void k_unpack_rgb(const float4* in, float* out, int64_t N) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < N) { float4 v = in[i]; out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z; }
+}

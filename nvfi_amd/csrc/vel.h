@@ -1,0 +1,41 @@
+// vel.h - argument blocks of the velocity kernels (vel.hip)
+#pragma once
+#include "common.h"
+
+#define RK_NF 19                       // per (step, sample) record fields: x3 pmid3 w1[6] w2[6] flags
+#define VEL_G_REGS (5 * 64 + 16)       // adjoint stash rows per (eval, tile): gz[5][64] + gw[16]
+#define MAX_RK_STEPS 64
+
+struct VelEvalArgs {
+    nvfi_field_desc f;
+    VelFrags Wv, Wa;
+    int64_t N;
+    const float* xt;   // (N,4)
+    float* u6;         // (N,6)
+    int gated;
+};
+
+struct Rk2Args {
+    nvfi_field_desc f;
+    VelFrags Wv;
+    const int* count;      // device count of compact samples (NULL -> n_direct)
+    int64_t n_direct;
+    const int* list;       // compact -> dense index (NULL: identity)
+    float4* xw;            // dense (x,y,z,zval), updated in place unless xout
+    float* xout;           // optional (count,3) output instead of in-place
+    // uniform mode (render): per-step dt and start time
+    int nsteps;
+    float dt[MAX_RK_STEPS];
+    float tcur[MAX_RK_STEPS];
+    // per-point mode
+    const float* pt_t; const float* pt_base; float dt_max; int max_steps;
+    // stashes (training)
+    float* zst; float* x0st; float* rec; float* gst;
+    int64_t cap; int64_t cap_tiles;
+    // backward
+    const float4* gxk;     // (count) upstream gradient wrt the warped position
+};
+
+int launch_vel_eval(const VelEvalArgs& a, hipStream_t st);
+int launch_rk2_fwd(const Rk2Args& a, int64_t cap_samples, bool uniform, bool stash, hipStream_t st);
+int launch_rk2_bwd(const Rk2Args& a, int64_t cap_samples, hipStream_t st);

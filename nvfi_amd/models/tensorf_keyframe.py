@@ -1,0 +1,484 @@
+"""TensorVMKeyframeTimeKplane - host-side mirror of the reference field module
+(models/tensorf_keyframe.py:37-756 + models/tensorf_base.py:133-269) for the render hot path.
+
+Parameters keep the reference's names and logical shapes (state_dict compatible, including the
+duplicated `vel.vel_net.*` keys, tensorf_keyframe.py:94,106); the factor planes are stored
+physically channel-last so one bilinear tap is one contiguous vector for the HIP kernels.
+Everything between "rays in" and "rgb/depth/acc/weights (+ gradients) out" is one call into
+libnvfi_hip.so through ctypes; there is no PyTorch/CPU fallback.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from .tensorf_model_utils import AlphaGridMask
+from .velocity_field import VelBasis, VelocityAABB, VelocityAABBSur
+
+
+class MLPRender_PE(nn.Module):
+    """Parameter container of the appearance decoder (tensorf_base.py:67-98); evaluated by k_app_fwd."""
+
+    def __init__(self, inChanel, viewpe=6, pospe=6, featureC=128):
+        super().__init__()
+        self.in_mlpC = (3 + 2 * viewpe * 3) + (3 + 2 * pospe * 3) + inChanel
+        self.viewpe, self.pospe = viewpe, pospe
+        self.mlp = nn.Sequential(nn.Linear(self.in_mlpC, featureC), nn.ReLU(inplace=True),
+                                 nn.Linear(featureC, featureC), nn.ReLU(inplace=True), nn.Linear(featureC, 3))
+        nn.init.constant_(self.mlp[-1].bias, 0)
+        self._owner = None
+
+    def forward(self, pts, viewdirs, features, kwargs=None):
+        raise NotImplementedError("MLPRender_PE is evaluated inside the fused appearance kernel; use field.app_at(xyzt, viewdirs)")
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _RenderFn(torch.autograd.Function):
+    """autograd boundary around nvfi_render_fwd / nvfi_render_bwd (include/nvfi_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, field, t, rays_o, rays_d, jitter, flags, *params):
+        L = _lib.lib()
+        R = rays_o.shape[0]
+        dev = rays_o.device
+        desc = field._desc()
+        S = desc.n_samples
+        nbytes = C.c_int64(0)
+        _lib.check(L.nvfi_render_workspace_bytes_t(C.byref(desc), C.c_int64(R), C.c_int(flags), C.c_float(t), C.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        rgb = torch.empty(R, 3, device=dev)
+        depth = torch.empty(R, device=dev)
+        acc = torch.empty(R, device=dev)
+        weights = torch.empty(R, S, device=dev)
+        counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=dev)
+        _lib.check(L.nvfi_render_fwd(C.byref(desc), C.c_int64(R), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(jitter),
+                                     C.c_float(t), C.c_int(flags), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc),
+                                     _lib.ptr(weights), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
+        field.last_counters = counters
+        if flags & _lib.NVFI_TRAIN:
+            ctx.field, ctx.t, ctx.flags, ctx.ws = field, t, flags, ws
+            ctx.save_for_backward(rays_o, rays_d, weights, *params)
+        ctx.mark_non_differentiable(counters)
+        return rgb, depth, acc, weights, counters
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_acc, g_weights, _gc):
+        L = _lib.lib()
+        rays_o, rays_d, weights, *params = ctx.saved_tensors
+        field = ctx.field
+        desc = field._desc(params)
+        need = ctx.needs_input_grad[6:]
+        grads = [torch.zeros_like(p) if n else None for p, n in zip(params, need)]
+        G = field._grads_struct(grads)
+        gs = [None if g is None else g.contiguous() for g in (g_rgb, g_depth, g_acc, g_weights)]
+        R = rays_o.shape[0]
+        _lib.check(L.nvfi_render_bwd(C.byref(desc), C.c_int64(R), _lib.ptr(rays_o), _lib.ptr(rays_d), C.c_float(ctx.t),
+                                     C.c_int(ctx.flags), _lib.ptr(weights), _lib.ptr(gs[0]), _lib.ptr(gs[1]), _lib.ptr(gs[2]),
+                                     _lib.ptr(gs[3]), C.byref(G), _lib.ptr(ctx.ws), C.c_int64(ctx.ws.numel()), _stream_ptr()))
+        ctx.ws = None
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+class _PdeFn(torch.autograd.Function):
+    """nvfi_pde_loss computes the loss AND its parameter gradients in one pass; backward scales them."""
+
+    @staticmethod
+    def forward(ctx, field, points, t, *params):
+        L = _lib.lib()
+        dev = points.device
+        P = points.shape[0]
+        desc = field._desc()
+        nbytes = C.c_int64(0)
+        _lib.check(L.nvfi_pde_workspace_bytes(C.byref(desc), C.c_int64(P), C.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        out = torch.zeros(4, device=dev)
+        grads = [torch.zeros_like(p) for p in params]
+        G = field._grads_struct_vel(grads)
+        counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=dev)
+        _lib.check(L.nvfi_pde_loss(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(1.0), _lib.ptr(out),
+                                   C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
+        field.last_pde_out = out
+        field.last_pde_counters = counters
+        ctx.save_for_backward(*grads)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None) + tuple(g * gr for gr in ctx.saved_tensors)
+
+
+class TensorVMKeyframeTimeKplane(nn.Module):
+    def __init__(self, aabb, gridSize, device, near_far, cfg):
+        super().__init__()
+        self.matModeSpace = [[0, 1], [0, 2], [1, 2]]
+        self.matModeTime = [[2, 3], [1, 3], [0, 3]]
+        self.cfg = cfg
+        self.device = device
+        self.num_keyframes = cfg.num_keyframes
+        self.tmax = cfg.tmax
+        self.time_scale_factor = self.tmax / (self.num_keyframes - 1) if self.num_keyframes > 1 else 1
+        self.densityMode = cfg.densityMode
+        if self.densityMode != "Density":
+            raise NotImplementedError("only densityMode=Density is on the hot path (every shipped config)")
+        self.data_dim_density = 1
+        self.register_buffer("aabb", aabb.to(device).float())
+        self.step_ratio = cfg.step_ratio
+        self.max_n_samples = cfg.max_n_samples
+        self.near_far = near_far
+        self.density_n_comp = cfg.density_n_comp
+        self.app_n_comp = cfg.appearance_n_comp
+        self.app_dim = cfg.app_dim
+        self.density_shift = cfg.density_shift
+        self.distance_scale = cfg.distance_scale
+        self.alphaMask = None
+        self.alphaMask_thres = cfg.alphaMask_thres
+        self.rayMarch_weight_thres = cfg.rayMarch_weight_thres
+        self.fea2denseAct = cfg.fea2denseAct
+        if self.fea2denseAct != "softplus":
+            raise NotImplementedError("only fea2denseAct=softplus is on the hot path (every shipped config)")
+        self.update_stepSize(gridSize)
+        self.init_svd_volume(device)
+        self.shadingMode = cfg.shadingMode
+        self.pos_pe, self.view_pe, self.fea_pe, self.featureC = cfg.pos_pe, cfg.view_pe, cfg.fea_pe, cfg.featureC
+        if self.shadingMode != "MLP_PE" or self.pos_pe != 6 or self.view_pe != 6 or self.featureC != 128:
+            raise NotImplementedError("only shadingMode=MLP_PE with pos_pe=view_pe=6, featureC=128 is on the hot path")
+        self.renderModule = MLPRender_PE(self.app_dim, self.view_pe, self.pos_pe, self.featureC).to(device)
+        self.use_vel = bool(cfg.use_vel)
+        if self.use_vel:
+            self.vel_net = VelBasis().to(device)
+            self.vel_net._owner = weakref.ref(self)
+            eps = cfg.eps if "eps" in cfg else 0.03
+            if all(k in cfg for k in ("sur_x", "sur_y", "sur_z")):
+                sur = torch.stack([torch.tensor(cfg[k]) for k in ("sur_x", "sur_y", "sur_z")], dim=-1).to(device)
+                self.vel = VelocityAABBSur(self.vel_net, self.aabb.clone(), sur)
+            else:
+                self.vel = VelocityAABB(self.vel_net, eps)
+        self.mask_field = None
+        self.contract_ray = bool("contract_ray" in cfg and cfg.contract_ray)
+        if self.contract_ray:
+            raise NotImplementedError("contract_ray is out of scope")
+        self.last_counters = None
+        self.register_load_state_dict_post_hook(lambda m, k: m.update_stepSize(m.gridSize.tolist()))
+
+    # ------------------------------------------------------------------ construction
+    def update_stepSize(self, gridSize):
+        """tensorf_base.py:214-227"""
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        self.gridSize = torch.LongTensor([int(g) for g in gridSize]).to(self.aabb.device)
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio
+        self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
+        self.nSamples = min(self.max_n_samples, int((self.aabbDiag / self.stepSize).item()) + 1)
+        # host copies of the scalars the C ABI needs (no device sync per render call)
+        self._aabb_host = [float(v) for v in self.aabb.detach().reshape(-1).cpu().tolist()]
+        self._step_host = float(self.stepSize)
+
+    def _init_planes(self, n_component, gridSize, numFrames, scale, device):
+        """tensorf_keyframe.py:136-186 (softplus branch): uniform(0.1,0.5)*scale space planes, ones time planes."""
+        space, time = [], []
+        for i in range(3):
+            a, b = self.matModeSpace[i]
+            c = self.matModeTime[i][0]
+            p = torch.empty(1, n_component[i], int(gridSize[b]), int(gridSize[a]))
+            nn.init.uniform_(p, a=0.1, b=0.5)
+            space.append(nn.Parameter(_cl(scale * p)))
+            time.append(nn.Parameter(_cl(torch.ones(1, n_component[i], numFrames, int(gridSize[c])))))
+        return nn.ParameterList(space).to(device), nn.ParameterList(time).to(device)
+
+    def init_svd_volume(self, device):
+        gs = self.gridSize.tolist()
+        self.density_plane_space, self.density_plane_time = self._init_planes(self.density_n_comp, gs, self.num_keyframes, 0.8, device)
+        self.app_plane_space, self.app_plane_time = self._init_planes(self.app_n_comp, gs, self.num_keyframes, 0.1, device)
+        self.basis_mat = nn.Linear(self.app_n_comp[0], self.app_dim, bias=False).to(device)
+        self.basis_mat_density = nn.Linear(self.density_n_comp[0], self.data_dim_density, bias=False).to(device)
+        self._fix_layout()
+
+    def _fix_layout(self):
+        for pl in (self.density_plane_space, self.density_plane_time, self.app_plane_space, self.app_plane_time):
+            for p in pl:
+                if not p.data.is_contiguous(memory_format=torch.channels_last):
+                    p.data = _cl(p.data)
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._fix_layout()
+        self.device = self.aabb.device
+        for name in ("gridSize", "aabbSize", "invaabbSize", "units", "stepSize", "aabbDiag"):
+            if hasattr(self, name) and isinstance(getattr(self, name), torch.Tensor):
+                setattr(self, name, getattr(self, name).to(self.aabb.device))
+        if self.use_vel and isinstance(self.vel, VelocityAABBSur):
+            self.vel.bounds = self.vel.bounds.to(self.aabb.device)
+        return r
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _render_params(self):
+        ps = list(self.density_plane_space) + list(self.density_plane_time) + list(self.app_plane_space) + list(self.app_plane_time)
+        ps.append(self.basis_mat.weight)
+        for i in (0, 2, 4):
+            ps += [self.renderModule.mlp[i].weight, self.renderModule.mlp[i].bias]
+        if self.use_vel:
+            for lin in VelBasis.linears(self.vel_net.weight_net):
+                ps += [lin.weight, lin.bias]
+        return ps
+
+    def _pde_params(self):
+        ps = []
+        for net in (self.vel_net.weight_net, self.vel_net.a_weight_net):
+            for lin in VelBasis.linears(net):
+                ps += [lin.weight, lin.bias]
+        return ps
+
+    def _gate(self):
+        if not self.use_vel:
+            return 0, [-1.0] * 3, [1.0] * 3
+        if isinstance(self.vel, VelocityAABBSur):
+            if getattr(self, "_sur_host", None) is None:
+                b = self.vel.bounds.detach().float().cpu().numpy()
+                self._sur_host = (b[0].tolist(), b[1].tolist())
+            return 1, self._sur_host[0], self._sur_host[1]
+        eps = float(self.vel.eps)
+        return 0, [float(np.float32(-1 + eps))] * 3, [float(np.float32(1 - eps))] * 3
+
+    def _desc(self, params=None):
+        """nvfi_field_desc for the current parameters (or for the tensors saved by autograd)."""
+        ps = self._render_params() if params is None else list(params)
+        d = _lib.FieldDesc()
+        gs = [int(g) for g in self.gridSize.tolist()]
+        d.G[:] = gs
+        d.K = int(self.num_keyframes)
+        d.Cd, d.Ca, d.app_dim = int(self.density_n_comp[0]), int(self.app_n_comp[0]), int(self.app_dim)
+        d.n_samples = int(self.nSamples)
+        d.use_vel = int(self.use_vel)
+        gsur, lo, hi = self._gate()
+        d.gate_sur = gsur
+        d.gate_lo[:] = lo
+        d.gate_hi[:] = hi
+        d.aabb[:] = self._aabb_host
+        d.near_, d.far_ = float(self.near_far[0]), float(self.near_far[1])
+        d.step_size = self._step_host
+        d.density_shift, d.distance_scale = float(self.density_shift), float(self.distance_scale)
+        d.weight_thres, d.alpha_thres, d.tmax = float(self.rayMarch_weight_thres), float(self.alphaMask_thres), float(self.tmax)
+        for p in ps[:12]:
+            if not p.is_contiguous(memory_format=torch.channels_last):
+                raise _lib.NvfiError("factor planes must be channels_last (call field._fix_layout())")
+        for i in range(3):
+            d.dps[i] = _lib.ptr(ps[i]); d.dpt[i] = _lib.ptr(ps[3 + i]); d.aps[i] = _lib.ptr(ps[6 + i]); d.apt[i] = _lib.ptr(ps[9 + i])
+        d.basis = _lib.ptr(ps[12])
+        for i in range(3):
+            d.rW[i] = _lib.ptr(ps[13 + 2 * i]); d.rb[i] = _lib.ptr(ps[14 + 2 * i])
+        if self.use_vel:
+            if len(ps) >= 31:
+                for i in range(6):
+                    d.vW[i] = _lib.ptr(ps[19 + 2 * i]); d.vb[i] = _lib.ptr(ps[20 + 2 * i])
+            for i, lin in enumerate(VelBasis.linears(self.vel_net.a_weight_net)):
+                d.aW[i] = _lib.ptr(lin.weight); d.ab[i] = _lib.ptr(lin.bias)
+        if self.alphaMask is not None:
+            d.has_amask = 1
+            v = self.alphaMask.alpha_volume
+            d.am_dims[:] = [v.shape[-1], v.shape[-2], v.shape[-3]]
+            d.amask = _lib.ptr(v)
+        return d
+
+    def _grads_struct(self, grads):
+        G = _lib.Grads()
+        g = list(grads) + [None] * (31 - len(grads))
+        for i in range(3):
+            G.dps[i] = _lib.ptr(g[i]); G.dpt[i] = _lib.ptr(g[3 + i]); G.aps[i] = _lib.ptr(g[6 + i]); G.apt[i] = _lib.ptr(g[9 + i])
+        G.basis = _lib.ptr(g[12])
+        for i in range(3):
+            G.rW[i] = _lib.ptr(g[13 + 2 * i]); G.rb[i] = _lib.ptr(g[14 + 2 * i])
+        for i in range(6):
+            G.vW[i] = _lib.ptr(g[19 + 2 * i]); G.vb[i] = _lib.ptr(g[20 + 2 * i])
+        return G
+
+    def _grads_struct_vel(self, grads):
+        G = _lib.Grads()
+        for i in range(6):
+            G.vW[i] = _lib.ptr(grads[2 * i]); G.vb[i] = _lib.ptr(grads[2 * i + 1])
+            G.aW[i] = _lib.ptr(grads[12 + 2 * i]); G.ab[i] = _lib.ptr(grads[13 + 2 * i])
+        return G
+
+    # ------------------------------------------------------------------ hot path
+    def forward(self, t, ray_o, ray_d, white_bg=True, ndc_ray=False, N_samples=-1, transfer_vel=False):
+        """render one chunk of rays (tensorf_keyframe.py:613-755) -> rgb, depth, acc, weights, mask_map."""
+        if ndc_ray:
+            raise NotImplementedError("ndc rays are out of scope (ndc: False in every shipped config)")
+        if N_samples > 0 and N_samples != self.nSamples:
+            raise NotImplementedError("per-call N_samples override is not supported")
+        ray_o = ray_o.reshape(-1, 3).contiguous().float()
+        ray_d = ray_d.reshape(-1, 3).contiguous().float()
+        R = ray_o.shape[0]
+        training = self.training
+        flags = 0
+        jitter = None
+        if training:
+            flags |= _lib.NVFI_TRAIN
+            # the reference draws the per-ray jitter on the CPU generator (tensorf_base.py:302-306)
+            jitter = torch.rand(R, 1).to(ray_o.device, non_blocking=True).reshape(-1)
+        # white background or the training-time random-white coin, drawn on CPU (tensorf_keyframe.py:740)
+        if white_bg or (training and bool(torch.rand((1,)) < 0.5)):
+            flags |= _lib.NVFI_WHITE_BG
+        if transfer_vel:
+            flags |= _lib.NVFI_TRANSFER
+        t = float(np.float32(float(t)))
+        params = self._render_params()
+        if training and torch.is_grad_enabled():
+            rgb, depth, acc, weights, _ = _RenderFn.apply(self, t, ray_o, ray_d, jitter, flags, *params)
+        else:
+            with torch.no_grad():
+                rgb, depth, acc, weights, _ = _RenderFn.apply(self, t, ray_o, ray_d, jitter, flags, *params)
+        mask_dim = 3 if self.mask_field is None else self.mask_field.mask_dim
+        mask_map = torch.zeros(R, mask_dim, device=ray_o.device)
+        return rgb, depth, acc, weights, mask_map
+
+    # ------------------------------------------------------------------ building blocks (inference, no autograd)
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0]) * self.invaabbSize - 1
+
+    def normalize_time_coord(self, time):
+        if self.num_keyframes == 1 or self.tmax == 0:
+            return time * 0
+        return time * 2 / self.tmax - 1
+
+    @torch.no_grad()
+    def _vel_eval(self, xt, gated):
+        L = _lib.lib()
+        xt = xt.reshape(-1, 4).contiguous().float()
+        N = xt.shape[0]
+        desc = self._desc()
+        nb = C.c_int64(0)
+        _lib.check(L.nvfi_vel_workspace_bytes(C.byref(desc), C.c_int64(N), C.byref(nb)))
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=xt.device)
+        u = torch.zeros(N, 6, device=xt.device)
+        _lib.check(L.nvfi_vel_eval(C.byref(desc), C.c_int64(N), _lib.ptr(xt), _lib.ptr(u), C.c_int(int(gated)), _lib.ptr(ws),
+                                   C.c_int64(ws.numel()), _stream_ptr()))
+        return u[:, :3].contiguous() if gated else u
+
+    @torch.no_grad()
+    def integrate_pos(self, pos_init, t, base_times):
+        """RK2 back-advection with per-point times (tensorf_keyframe.py:575-611). Unlike the reference this
+        does not mutate its arguments."""
+        L = _lib.lib()
+        x = pos_init.reshape(-1, 3).contiguous().float()
+        tt = t.reshape(-1).contiguous().float()
+        bb = base_times.reshape(-1).contiguous().float()
+        N = x.shape[0]
+        desc = self._desc()
+        nb = C.c_int64(0)
+        _lib.check(L.nvfi_vel_workspace_bytes(C.byref(desc), C.c_int64(N), C.byref(nb)))
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device)
+        out = torch.empty_like(x)
+        _lib.check(L.nvfi_integrate_pos(C.byref(desc), C.c_int64(N), _lib.ptr(x), _lib.ptr(tt), _lib.ptr(bb), _lib.ptr(out),
+                                        _lib.ptr(ws), C.c_int64(ws.numel()), _stream_ptr()))
+        return out
+
+    @torch.no_grad()
+    def compute_densityfeature(self, xyzt):
+        """(N,4) normalised (x,y,z,t') -> (N,1) (tensorf_keyframe.py:233-272)."""
+        L = _lib.lib()
+        q = xyzt.reshape(-1, 4).contiguous().float()
+        N = q.shape[0]
+        feat = torch.empty(N, device=q.device)
+        sigma = torch.empty(N, device=q.device)
+        desc = self._desc()
+        _lib.check(L.nvfi_density_at(C.byref(desc), C.c_int64(N), _lib.ptr(q), _lib.ptr(feat), _lib.ptr(sigma), _stream_ptr()))
+        return feat.unsqueeze(-1)
+
+    def feature2density(self, density_features, x=None):
+        return F.softplus(density_features[..., 0] + self.density_shift)
+
+    @torch.no_grad()
+    def app_at(self, xyzt, viewdirs):
+        """compute_appfeature + renderModule for explicit points (tensorf_keyframe.py:274-310, tensorf_base.py:88-98)."""
+        L = _lib.lib()
+        q = xyzt.reshape(-1, 4).contiguous().float()
+        v = viewdirs.reshape(-1, 3).contiguous().float()
+        N = q.shape[0]
+        rgb = torch.empty(N, 3, device=q.device)
+        ws = torch.empty(4 * 70000 + 16 * N + 4096, dtype=torch.uint8, device=q.device)
+        desc = self._desc()
+        _lib.check(L.nvfi_app_at(C.byref(desc), C.c_int64(N), _lib.ptr(q), _lib.ptr(v), _lib.ptr(rgb), _lib.ptr(ws),
+                                 C.c_int64(ws.numel()), _stream_ptr()))
+        return rgb
+
+    def pde_loss(self, points, t):
+        """PDE regulariser on explicit collocation points (world-space (P,3), raw t (P,1)); models/nvfi.py:42-84."""
+        points = points.reshape(-1, 3).contiguous().float()
+        t = t.reshape(-1).contiguous().float()
+        return _PdeFn.apply(self, points, t, *self._pde_params())
+
+    # ------------------------------------------------------------------ per-iteration regularisers (next-row f-1; torch ops)
+    def density_L1(self):
+        total = 0
+        for i in range(3):
+            total = total + torch.mean(torch.abs(self.density_plane_space[i])) + torch.mean(torch.abs(1 - self.density_plane_time[i]))
+        return total
+
+    def TV_loss_density(self, reg):
+        total = 0
+        for i in range(3):
+            total = total + reg(self.density_plane_space[i]) * 1e-2 + ((reg(self.density_plane_time[i], t=True) * 1e-2) if self.num_keyframes > 1 else 0)
+        return total
+
+    def TV_loss_app(self, reg):
+        total = 0
+        for i in range(3):
+            total = total + reg(self.app_plane_space[i]) * 1e-2
+        return total
+
+    # ------------------------------------------------------------------ optimiser / checkpoint surface
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        """tensorf_keyframe.py:539-550"""
+        gv = [{"params": self.density_plane_space, "lr": lr_init_spatialxyz},
+              {"params": self.density_plane_time, "lr": lr_init_spatialxyz},
+              {"params": self.app_plane_space, "lr": lr_init_spatialxyz},
+              {"params": self.app_plane_time, "lr": lr_init_spatialxyz},
+              {"params": self.basis_mat.parameters(), "lr": lr_init_network},
+              {"params": self.basis_mat_density.parameters(), "lr": lr_init_network},
+              {"params": self.renderModule.parameters(), "lr": lr_init_network}]
+        if self.use_vel:
+            gv += [{"params": self.vel.parameters(), "lr": lr_init_network}]
+        return gv
+
+    def get_kwargs(self):
+        """tensorf_base.py:247-268"""
+        kw = {"aabb": self.aabb, "gridSize": self.gridSize.tolist(), "density_n_comp": self.density_n_comp,
+              "appearance_n_comp": self.app_n_comp, "app_dim": self.app_dim, "density_shift": self.density_shift,
+              "alphaMask_thres": self.alphaMask_thres, "fea2denseAct": self.fea2denseAct, "near_far": self.near_far,
+              "step_ratio": self.step_ratio, "shadingMode": self.shadingMode, "pos_pe": self.pos_pe, "view_pe": self.view_pe,
+              "fea_pe": self.fea_pe, "featureC": self.featureC, "num_keyframes": self.num_keyframes}
+        if self.alphaMask is not None:
+            kw["alphaMask_grid"] = self.alphaMask.gridSize
+        return kw
+
+    # ------------------------------------------------------------------ grid maintenance (next-row f-3; torch ops)
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target, new_keyframes):
+        """tensorf_keyframe.py:327-376: bilinear align_corners=True resampling of every plane."""
+        self.num_keyframes = new_keyframes
+        self.time_scale_factor = self.tmax / (self.num_keyframes - 1) if self.num_keyframes > 1 else 1
+
+        def up(space, time):
+            ns, nt = [], []
+            for i in range(3):
+                a, b = self.matModeSpace[i]
+                c = self.matModeTime[i][0]
+                ns.append(nn.Parameter(_cl(F.interpolate(space[i].data, size=(int(res_target[b]), int(res_target[a])), mode="bilinear", align_corners=True))))
+                nt.append(nn.Parameter(_cl(F.interpolate(time[i].data, size=(self.num_keyframes, int(res_target[c])), mode="bilinear", align_corners=True))))
+            return nn.ParameterList(ns), nn.ParameterList(nt)
+
+        self.app_plane_space, self.app_plane_time = up(self.app_plane_space, self.app_plane_time)
+        self.density_plane_space, self.density_plane_time = up(self.density_plane_space, self.density_plane_time)
+        self.update_stepSize(res_target)
