@@ -102,6 +102,13 @@ int nvfi_pde_loss(const nvfi_field_desc* f, int64_t P, const float* points, cons
                   float loss_scale, float* out, const nvfi_grads* grads,
                   void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream);
 
+/* same, with optional diagnostics: kept (device uint8[P]), jac (device float[n_jac][6][4], rows 3..5 zero: the loss
+ * does not use the acceleration Jacobian) for the first n_jac kept points */
+int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float* points, const float* t,
+                     float loss_scale, float* out, const nvfi_grads* grads,
+                     void* workspace, int64_t workspace_bytes, int64_t* counters,
+                     uint8_t* kept_out, float* jac_out, int64_t n_jac, void* stream);
+
 /* ---- building blocks used by train_segm-style callers and by the parity tests */
 /* VelBasis.forward (velocity_field.py:69-75): xt (N,4) -> u (N,6)=(v,a); gated!=0: VelocityAABB[Sur].forward -> (N,3) in u (stride 6) */
 int nvfi_vel_eval(const nvfi_field_desc* f, int64_t N, const float* xt, float* u6, int gated,

@@ -321,7 +321,7 @@ struct WgradJob {
     const float* A; size_t a_tile_stride; int a_regs;      // rows of 64 floats; a_regs multiple of 16
     const float* B; const float* B2; size_t b_tile_stride; int b_regs; int bmode;
     const int* count; int cap_tiles;  // number of valid samples (device), tile capacity
-    int nrep; size_t a_rep_stride, b_rep_stride;   // replicate over e.g. (step,eval) blocks
+    int nrep; size_t a_rep_stride, b_rep_stride, b2_rep_stride;   // replicate over e.g. (step,eval) blocks
     float* slabs;                      // [nslab][ (32*MTA) * (32*KTB) + 32*MTA ]
     int nslab;
 };

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradJobs jobs) {
         int rep = item / ntiles, tile = item - rep * ntiles;
         const float* At = J.A + (size_t)rep * J.a_rep_stride + (size_t)tile * J.a_tile_stride;
         const float* Bt = J.B + (size_t)rep * J.b_rep_stride + (size_t)tile * J.b_tile_stride;
-        const float* B2t = J.B2 ? J.B2 + (size_t)rep * J.b_rep_stride + (size_t)tile * J.b_tile_stride : nullptr;
+        const float* B2t = J.B2 ? J.B2 + (size_t)rep * J.b2_rep_stride + (size_t)tile * J.b_tile_stride : nullptr;
         __syncthreads();
         for (int e = tid; e < J.a_regs * 64; e += WG_THREADS) {
             int reg = e >> 6, ln = e & 63;

@@ -1,0 +1,37 @@
+// pde.h - argument blocks and stash geometry of the PDE kernels (pde.hip)
+#pragma once
+#include "common.h"
+
+#define PDE_MAX_CLASS 64           // RK2 step-count buckets
+#define PDE_CHUNK 32768            // kept points processed per pass (bounds the stash)
+#define PDE_NSLAB 64
+
+// per-tile stash rows (each row = 64 floats)
+#define PDE_Z     0                          // weight_net pre-activations        5*64
+#define PDE_ZD    (PDE_Z + 320)              // tangent pre-activations       4 x 5*64
+#define PDE_X0    (PDE_ZD + 4 * 320)         // encoder slots                      16
+#define PDE_X0D   (PDE_X0 + 16)              // encoder tangents               4 x 16
+#define PDE_GA    (PDE_X0D + 64)             // adjoints: value, 4 tangents   5 x 336
+#define PDE_CORR  (PDE_GA + 5 * 336)         // second-derivative correction      320
+#define PDE_ZA    (PDE_CORR + 320)           // a_weight_net pre-activations      320
+#define PDE_GAA   (PDE_ZA + 320)             // a_weight_net adjoints             336
+#define PDE_TILE_ROWS (PDE_GAA + 336)
+
+struct PdePrepArgs {
+    nvfi_field_desc f;
+    int64_t P;
+    const float* points; const float* t;
+    float4* qorig; float4* xw; float* pt_t; float* pt_base;
+    int* cls; int* rank; int* cls_count;
+};
+
+struct PdeJetArgs {
+    VelFrags Wv, Wa;
+    const float4* qorig; const int* klist;
+    int64_t first; int count; int64_t cap;
+    float* stash; float* seeds; double* sums;
+    float inv_n, scale;
+    float* jac; int64_t n_jac;
+};
+
+int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, const nvfi_grads* G, hipStream_t st);

@@ -139,23 +139,15 @@ __global__ __launch_bounds__(256) void k_fill(int64_t R, int S, const uint8_t* _
     }
 }
 
-// ================================================================ density
-__device__ __forceinline__ float density_feature(const nvfi_field_desc& f, float x, float y, float z, float tn) {
-    Bl b[6];
-    plane_setups(f, x, y, z, tn, b);
-    float sum = 0.f;
-    const int nq = f.Cd >> 2;
-    for (int q4 = 0; q4 < nq; ++q4) {
-        float4 s0 = bl_sample4(f.dps[0], f.Cd, b[0], q4), s1 = bl_sample4(f.dps[1], f.Cd, b[1], q4), s2 = bl_sample4(f.dps[2], f.Cd, b[2], q4);
-        float4 t0 = bl_sample4(f.dpt[0], f.Cd, b[3], q4), t1 = bl_sample4(f.dpt[1], f.Cd, b[4], q4), t2 = bl_sample4(f.dpt[2], f.Cd, b[5], q4);
-        sum += ((s0.x * s1.x) * s2.x) * ((t0.x * t1.x) * t2.x);
-        sum += ((s0.y * s1.y) * s2.y) * ((t0.y * t1.y) * t2.y);
-        sum += ((s0.z * s1.z) * s2.z) * ((t0.z * t1.z) * t2.z);
-        sum += ((s0.w * s1.w) * s2.w) * ((t0.w * t1.w) * t2.w);
-    }
-    return sum;
+// scan + ordered fill for n_groups groups of 64 flags (used by the PDE prefilter)
+int launch_scan_fill(const int* cnt, int* off, int64_t ngroups, int* total, const uint8_t* flags, int* list, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, cnt, off, ngroups, total);
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, st, ngroups, 64, flags, off, list);
+    LAUNCHCK();
+    return 0;
 }
 
+// ================================================================ density
 __global__ __launch_bounds__(256) void k_density_fwd(DensityArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int count = a.count ? *a.count : (int)a.n_direct;
@@ -854,6 +846,7 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
         const size_t fs = APP_F_ROWS * REGF, bs = APP_B_ROWS * REGF;
         auto add = [&](const float* A, int a_regs, const float* B, int b_regs, float* slabs, float* gW, float* gb, int out, int in, int sk) {
             WgradJob& J = wj.j[wj.n++];
+            memset(&J, 0, sizeof(J));
             J.A = A; J.a_tile_stride = bs; J.a_regs = a_regs; J.B = B; J.B2 = nullptr; J.b_tile_stride = fs; J.b_regs = b_regs;
             J.bmode = BM_RAW; J.count = P.counters + 1; J.cap_tiles = (int)P.cap_tiles; J.nrep = 1; J.a_rep_stride = 0; J.b_rep_stride = 0;
             J.slabs = slabs; J.nslab = NSLAB;
@@ -903,6 +896,7 @@ int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, cons
     for (int l = 0; l < 6; ++l) {
         if (!gW[l] && !gb[l]) continue;
         WgradJob& J = wj.j[wj.n++];
+        memset(&J, 0, sizeof(J));
         J.A = gst + (size_t)l * 64 * REGF; J.a_tile_stride = gs; J.a_regs = l < 5 ? 64 : 16; J.a_rep_stride = (size_t)cap_tiles * gs;
         if (l == 0) { J.B = x0st; J.b_tile_stride = xs; J.b_regs = 16; J.bmode = BM_RAW; J.b_rep_stride = (size_t)cap_tiles * xs; }
         else { J.B = zst + (size_t)(l - 1) * 64 * REGF; J.b_tile_stride = zs; J.b_regs = 64; J.bmode = act_mode; J.b_rep_stride = (size_t)cap_tiles * zs; }

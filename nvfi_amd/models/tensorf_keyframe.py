@@ -106,8 +106,12 @@ class _PdeFn(torch.autograd.Function):
         grads = [torch.zeros_like(p) for p in params]
         G = field._grads_struct_vel(grads)
         counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=dev)
-        _lib.check(L.nvfi_pde_loss(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(1.0), _lib.ptr(out),
-                                   C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
+        kept = torch.zeros(P, dtype=torch.uint8, device=dev) if field.pde_debug else None
+        jac = torch.zeros(field.pde_debug, 6, 4, device=dev) if field.pde_debug else None
+        _lib.check(L.nvfi_pde_loss_ex(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(1.0), _lib.ptr(out),
+                                      C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters),
+                                      _lib.ptr(kept), _lib.ptr(jac), C.c_int64(int(field.pde_debug)), _stream_ptr()))
+        field.last_pde_kept, field.last_pde_jac = kept, jac
         field.last_pde_out = out
         field.last_pde_counters = counters
         ctx.save_for_backward(*grads)
@@ -169,6 +173,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         if self.contract_ray:
             raise NotImplementedError("contract_ray is out of scope")
         self.last_counters = None
+        self.pde_debug = 0   # >0: also return the kept mask and the first n Jacobians of get_vel_loss
         self.register_load_state_dict_post_hook(lambda m, k: m.update_stepSize(m.gridSize.tolist()))
 
     # ------------------------------------------------------------------ construction
@@ -407,7 +412,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         v = viewdirs.reshape(-1, 3).contiguous().float()
         N = q.shape[0]
         rgb = torch.empty(N, 3, device=q.device)
-        ws = torch.empty(4 * 70000 + 16 * N + 4096, dtype=torch.uint8, device=q.device)
+        ws = torch.empty(4 * 80000 + 16 * N + 8192, dtype=torch.uint8, device=q.device)
         desc = self._desc()
         _lib.check(L.nvfi_app_at(C.byref(desc), C.c_int64(N), _lib.ptr(q), _lib.ptr(v), _lib.ptr(rgb), _lib.ptr(ws),
                                  C.c_int64(ws.numel()), _stream_ptr()))

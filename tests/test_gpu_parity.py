@@ -191,3 +191,31 @@ def test_render_vs_oracle_bigger(fields, models, kind):
                "vel_net.weight_net.1.weight", "vel_net.weight_net.4.0.weight", "vel_net.weight_net.7.0.bias"):
         e = relerr(g[pn], gref[pn])
         assert e < 5e-4, (pn, e)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_pde_loss(gold, models, kind):
+    model, meta = models[kind]
+    f = model.nvfi
+    model.zero_grad(set_to_none=True)
+    f.pde_debug = 64
+    try:
+        loss = model.get_vel_loss(points=_cuda(gold[f"{kind}:pde:points"]), t=_cuda(gold[f"{kind}:pde:t"]))
+    finally:
+        f.pde_debug = 0
+    kept = f.last_pde_kept.cpu().numpy().astype(bool)
+    ref_kept = gold[f"{kind}:pde:kept"]
+    assert np.mean(kept != ref_kept) < 2e-3      # alpha within rounding of the 1e-4 threshold may flip
+    if np.array_equal(kept, ref_kept):
+        np.testing.assert_allclose(f.last_pde_jac.cpu().numpy()[:, :3], gold[f"{kind}:pde:jac64"][:, :3], rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(float(loss), gold[f"{kind}:pde:loss"][0], rtol=5e-4)
+    (loss * 1.0).backward()
+    g = named_grads(model)
+    n = 0
+    for k in gold.files:
+        pre = f"{kind}:pde:grad:"
+        if k.startswith(pre):
+            e = relerr(g["vel_net." + k[len(pre):]], gold[k])
+            assert e < 1e-3, (k, e)
+            n += 1
+    assert n >= 8
