@@ -490,7 +490,7 @@ int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, const nvfi_gr
         WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
         for (int l = 0; l < 6; ++l) {
             float* gW = pass < 2 ? G->vW[l] : G->aW[l];
-            float* gb = pass < 2 ? G->vb[l] : G->ab[l];
+            float* gb = pass == 0 ? G->vb[l] : (pass == 1 ? nullptr : G->ab[l]);   // tangent columns carry no bias term
             if (!gW && !gb) continue;
             WgradJob& J = wj.j[wj.n++];
             memset(&J, 0, sizeof(J));
