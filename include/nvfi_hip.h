@@ -122,6 +122,11 @@ int nvfi_density_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, floa
 /* compute_appfeature + MLPRender_PE (tensorf_keyframe.py:274-310, tensorf_base.py:88-98): xyzt (N,4), view (N,3) -> rgb (N,3) */
 int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, const float* view, float* rgb,
                 void* workspace, int64_t workspace_bytes, void* stream);
+/* per-kernel-class HIP-event timing for bench.py: enable, run, collect (host arrays of nvfi_prof_nclasses() entries).
+ * classes: 0 rk2_fwd 1 rk2_bwd 2 app_fwd 3 app_bwd 4 wgrad 5 pde_fwd 6 pde_bwd 7 density_fwd 8 density_bwd 9 pde_prefilter */
+int nvfi_prof_enable(int on);
+int nvfi_prof_collect(double* total_ms, int64_t* count);
+int nvfi_prof_nclasses(void);
 /* MFMA fragment-layout self test: returns max abs error of a 128x128 fp32 layer against a VALU loop (host float*) */
 int nvfi_selftest(float* max_err_host, void* stream);
 

@@ -118,3 +118,45 @@ extern "C" int nvfi_selftest(float* max_err_host, void* stream) {
 }
 
 // ---------------------------------------------------------------- PDE entry points live in pde.hip
+
+// ---------------------------------------------------------------- per-kernel-class event timing
+#include <vector>
+static int g_prof = 0;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_ev[PK_COUNT];
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t g_open[PK_COUNT];
+static hipEvent_t ev_get() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+void prof_begin(int cls, hipStream_t st) {
+    if (!g_prof) return;
+    g_open[cls] = ev_get();
+    (void)hipEventRecord(g_open[cls], st);
+}
+void prof_end(int cls, hipStream_t st) {
+    if (!g_prof) return;
+    hipEvent_t e = ev_get();
+    (void)hipEventRecord(e, st);
+    g_ev[cls].push_back({g_open[cls], e});
+}
+extern "C" int nvfi_prof_enable(int on) {
+    g_prof = on;
+    for (int c = 0; c < PK_COUNT; ++c) { for (auto& p : g_ev[c]) { g_pool.push_back(p.first); g_pool.push_back(p.second); } g_ev[c].clear(); }
+    return 0;
+}
+/* total_ms[PK_COUNT], count[PK_COUNT] (host arrays); synchronises the recorded events */
+extern "C" int nvfi_prof_collect(double* total_ms, int64_t* count) {
+    for (int c = 0; c < PK_COUNT; ++c) {
+        double t = 0.0;
+        for (auto& p : g_ev[c]) {
+            HIPCK(hipEventSynchronize(p.second));
+            float ms = 0.f;
+            HIPCK(hipEventElapsedTime(&ms, p.first, p.second));
+            t += ms;
+        }
+        total_ms[c] = t; count[c] = (int64_t)g_ev[c].size();
+    }
+    return 0;
+}
+extern "C" int nvfi_prof_nclasses(void) { return PK_COUNT; }

@@ -16,6 +16,13 @@ int nvfi_fail(int code, const char* fmt, ...);
     } while (0)
 #define LAUNCHCK() HIPCK(hipGetLastError())
 
+// optional per-kernel-class HIP-event timing (bench.py): events are recorded on the launch stream
+enum { PK_RK2_FWD = 0, PK_RK2_BWD, PK_APP_FWD, PK_APP_BWD, PK_WGRAD, PK_PDE_FWD, PK_PDE_BWD, PK_DENSITY_FWD, PK_DENSITY_BWD,
+       PK_PDE_PREFILTER, PK_OTHER, PK_COUNT };
+void prof_begin(int cls, hipStream_t st);
+void prof_end(int cls, hipStream_t st);
+struct ProfScope { int c; hipStream_t s; ProfScope(int cls, hipStream_t st) : c(cls), s(st) { prof_begin(c, s); } ~ProfScope() { prof_end(c, s); } };
+
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // simple bump allocator over the caller's workspace

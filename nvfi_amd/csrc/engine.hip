@@ -153,6 +153,7 @@ int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st) {
     }
     int nslab = 0;
     for (int i = 0; i < wj.n; ++i) nslab = wj.j[i].nslab > nslab ? wj.j[i].nslab : nslab;
+    ProfScope ps(PK_WGRAD, st);
     hipLaunchKernelGGL(k_wgrad, dim3(nslab, wj.n), dim3(WG_THREADS), lds_bytes, st, wj);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(32, rj.n), dim3(256), 0, st, rj);
     LAUNCHCK();

@@ -452,9 +452,9 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
             ja.Wv = VW; ja.Wa = AW; ja.qorig = L.qorig; ja.klist = L.klist; ja.first = first; ja.count = (int)cnt; ja.cap = cap;
             ja.stash = L.stash; ja.seeds = L.seeds; ja.sums = L.sums; ja.inv_n = inv_n; ja.scale = loss_scale; ja.jac = jac_out; ja.n_jac = n_jac;
             const unsigned wgs = (unsigned)(cap / WG_SAMPLES);
-            hipLaunchKernelGGL(k_pde_fwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+            { ProfScope ps(PK_PDE_FWD, st); hipLaunchKernelGGL(k_pde_fwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja); }
             if (grads) {
-                hipLaunchKernelGGL(k_pde_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                { ProfScope ps(PK_PDE_BWD, st); hipLaunchKernelGGL(k_pde_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja); }
                 LAUNCHCK();
                 if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, grads, st)) return 1;
             }

@@ -781,7 +781,7 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
     // density
     DensityArgs da; memset(&da, 0, sizeof(da));
     da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn;
-    hipLaunchKernelGGL(k_density_fwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da);
+    { ProfScope ps(PK_DENSITY_FWD, st); hipLaunchKernelGGL(k_density_fwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
     // weights
     WeightArgs wa; memset(&wa, 0, sizeof(wa));
     wa.R = R; wa.S = S; wa.xpre = P.xpre; wa.xw = P.xw; wa.distance_scale = f->distance_scale; wa.weight_thres = f->weight_thres;
@@ -795,8 +795,11 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
     aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S;
     aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f;
     const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
-    if (train) hipLaunchKernelGGL(k_app_fwd<true>, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa);
-    else hipLaunchKernelGGL(k_app_fwd<false>, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa);
+    {
+        ProfScope ps(PK_APP_FWD, st);
+        if (train) hipLaunchKernelGGL(k_app_fwd<true>, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa);
+        else hipLaunchKernelGGL(k_app_fwd<false>, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa);
+    }
     // composite
     FinalArgs fa; fa.R = R; fa.off_m = P.off_m; fa.mlist = P.mlist; fa.weight = weights; fa.rgbs = P.rgbs; fa.acc = acc;
     fa.white_bg = (flags & NVFI_WHITE_BG) ? 1 : 0; fa.rgb_pre = P.rgb_pre; fa.rgb = rgb;
@@ -838,7 +841,7 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f; aa.stash_b = P.app_b; aa.g = *grads;
     aa.g_rgb = g_rgb; aa.rgb_pre = P.rgb_pre; aa.weight = weights; aa.gxw = P.gxw;
     const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
-    hipLaunchKernelGGL(k_app_bwd, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa);
+    { ProfScope ps(PK_APP_BWD, st); hipLaunchKernelGGL(k_app_bwd, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa); }
     LAUNCHCK();
     // render-MLP weight gradients
     {
@@ -872,7 +875,7 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     DensityArgs da; memset(&da, 0, sizeof(da));
     da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn;
     da.gxpre = P.gxpre; da.g = *grads; da.mflag = P.mflag; da.gxw = P.gxw; da.gxk = nsteps > 0 ? P.gxk : nullptr;
-    hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da);
+    { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
     LAUNCHCK();
     // RK2 adjoint + velocity-net weight gradients
     if (nsteps > 0) {

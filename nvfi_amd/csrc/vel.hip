@@ -215,6 +215,7 @@ int launch_rk2_fwd(const Rk2Args& a, int64_t cap_samples, bool uniform, bool sta
     int64_t nwg = (cap_samples + WG_SAMPLES - 1) / WG_SAMPLES;
     if (nwg <= 0) return 0;
     dim3 g((unsigned)nwg), b(WG_THREADS);
+    ProfScope ps(uniform ? PK_RK2_FWD : PK_PDE_PREFILTER, st);
     if (uniform && stash) hipLaunchKernelGGL((k_rk2_fwd<true, true>), g, b, ENGINE_LDS_BYTES, st, a);
     else if (uniform) hipLaunchKernelGGL((k_rk2_fwd<true, false>), g, b, ENGINE_LDS_BYTES, st, a);
     else hipLaunchKernelGGL((k_rk2_fwd<false, false>), g, b, ENGINE_LDS_BYTES, st, a);
@@ -225,6 +226,7 @@ int launch_rk2_bwd(const Rk2Args& a, int64_t cap_samples, hipStream_t st) {
     if (ensure_lds_attrs()) return 1;
     int64_t nwg = (cap_samples + WG_SAMPLES - 1) / WG_SAMPLES;
     if (nwg <= 0) return 0;
+    ProfScope ps(PK_RK2_BWD, st);
     hipLaunchKernelGGL(k_rk2_bwd, dim3((unsigned)nwg), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
     LAUNCHCK();
     return 0;

@@ -1,0 +1,63 @@
+"""Ray-sharded data parallelism: one process per GPU, ONE all-reduce per step.
+
+Every rank holds a full replica of the field, renders its own rays / collocation points, and the only
+exchange is a sum of the flat gradient buffer (RCCL over xGMI through torch.distributed backend "nccl";
+"gloo" on CPU for the tests).  The loss means are formed so that the averaged gradient equals the
+single-process gradient of the global batch: the render MSE is a mean over equal-sized shards, and the
+PDE term - whose per-rank kept count differs - is re-weighted by W * n_kept_r / sum_r n_kept_r.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBucket:
+    """One flat fp32 buffer that backs every parameter's .grad (so the step has a single collective)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        seen, uniq = set(), []
+        for p in self.params:
+            if id(p) not in seen:
+                seen.add(id(p)); uniq.append(p)
+        self.params = uniq
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            chunk = self.flat[off:off + p.numel()]
+            if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
+                N, C, H, W = p.shape
+                g = chunk.view(N, H, W, C).permute(0, 3, 1, 2)   # same strides as the channels_last parameter
+            else:
+                g = chunk.view(p.shape)
+            p.grad = g
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+
+def pde_rank_weight(n_kept_local):
+    """W * n_r / sum_r n_r  (1.0 for a single process; 0 when nothing is kept anywhere)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1.0
+    t = torch.tensor([float(n_kept_local)], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    tot = t.clone()
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    tot = float(tot.item())
+    return 0.0 if tot == 0 else dist.get_world_size() * float(n_kept_local) / tot
+
+
+def shard_range(n, rank, world):
+    """Contiguous shard [lo, hi) of n items for this rank (remainder spread over the first ranks)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
