@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 VEL_FLOP = 139776          # 2*(28*128 + 4*128^2 + 128*6)   one VelBasis net evaluation
 APP_FLOP = 64768           # 2*(48*32 + 110*128 + 128^2 + 128*3)
 PEAK_FP32_MFMA = 157.3     # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
-CLASSES = ["rk2_fwd", "rk2_bwd", "app_fwd", "app_bwd", "wgrad", "pde_fwd", "pde_bwd", "density_fwd", "density_bwd", "pde_prefilter", "other"]
+CLASSES = ["rk2_fwd", "rk2_bwd", "app_fwd", "app_bwd", "wgrad", "pde_fwd", "pde_bwd", "density_fwd", "density_bwd", "pde_prefilter", "density_scatter", "app_scatter", "other"]
 
 
 def bat_cfg(S=128, use_vel=True):

@@ -18,7 +18,7 @@ int nvfi_fail(int code, const char* fmt, ...);
 
 // optional per-kernel-class HIP-event timing (bench.py): events are recorded on the launch stream
 enum { PK_RK2_FWD = 0, PK_RK2_BWD, PK_APP_FWD, PK_APP_BWD, PK_WGRAD, PK_PDE_FWD, PK_PDE_BWD, PK_DENSITY_FWD, PK_DENSITY_BWD,
-       PK_PDE_PREFILTER, PK_OTHER, PK_COUNT };
+       PK_PDE_PREFILTER, PK_DENSITY_SCATTER, PK_APP_SCATTER, PK_OTHER, PK_COUNT };
 void prof_begin(int cls, hipStream_t st);
 void prof_end(int cls, hipStream_t st);
 struct ProfScope { int c; hipStream_t s; ProfScope(int cls, hipStream_t st) : c(cls), s(st) { prof_begin(c, s); } ~ProfScope() { prof_end(c, s); } };

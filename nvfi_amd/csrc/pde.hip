@@ -18,28 +18,38 @@
 
 // ---------------------------------------------------------------- prefilter
 __global__ __launch_bounds__(256) void k_pde_prep(PdePrepArgs a) {
+    __shared__ int hist[PDE_MAX_CLASS];
+    __shared__ int gbase[PDE_MAX_CLASS];
+    if (threadIdx.x < PDE_MAX_CLASS) hist[threadIdx.x] = 0;
+    __syncthreads();
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= a.P) return;
+    const bool on = i < a.P;
     const nvfi_field_desc& f = a.f;
-    const float t = a.t[i];
-    const float base = snap_base(f, t);
-    float xn[3];
+    int ns = 0, lr = 0;
+    if (on) {
+        const float t = a.t[i];
+        const float base = snap_base(f, t);
+        float xn[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) xn[c] = norm_coord(f, c, a.points[3 * i + c]);
-    a.qorig[i] = make_float4(xn[0], xn[1], xn[2], t);
-    a.xw[i] = make_float4(xn[0], xn[1], xn[2], norm_time(f, base));
-    a.pt_t[i] = t; a.pt_base[i] = base;
-    // number of RK2 steps this point will take (same fp32 recurrence as the integrator)
-    const float dtm = dt_max_of(f);
-    float off = t - base;
-    int ns = 0;
-    while (fabsf(off) > 0.f && ns < PDE_MAX_CLASS - 1) {
-        float m = fminf(fabsf(off), dtm);
-        off = off - (off > 0.f ? m : -m);
-        ++ns;
+        for (int c = 0; c < 3; ++c) xn[c] = norm_coord(f, c, a.points[3 * i + c]);
+        a.qorig[i] = make_float4(xn[0], xn[1], xn[2], t);
+        a.xw[i] = make_float4(xn[0], xn[1], xn[2], norm_time(f, base));
+        a.pt_t[i] = t; a.pt_base[i] = base;
+        // number of RK2 steps this point will take (same fp32 recurrence as the integrator)
+        const float dtm = dt_max_of(f);
+        float off = t - base;
+        while (fabsf(off) > 0.f && ns < PDE_MAX_CLASS - 1) {
+            float m = fminf(fabsf(off), dtm);
+            off = off - (off > 0.f ? m : -m);
+            ++ns;
+        }
+        a.cls[i] = ns;
+        lr = atomicAdd(&hist[ns], 1);          // rank inside the workgroup (LDS atomic)
     }
-    a.cls[i] = ns;
-    a.rank[i] = atomicAdd(&a.cls_count[ns], 1);
+    __syncthreads();
+    if (threadIdx.x < PDE_MAX_CLASS && hist[threadIdx.x] > 0) gbase[threadIdx.x] = atomicAdd(&a.cls_count[threadIdx.x], hist[threadIdx.x]);
+    __syncthreads();
+    if (on) a.rank[i] = gbase[ns] + lr;
 }
 // bucket points by step count: perm[class_off[c] + rank] = i
 __global__ __launch_bounds__(256) void k_pde_bucket(int64_t P, const int* cls, const int* rank, const int* cls_count, int* perm,

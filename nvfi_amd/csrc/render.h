@@ -60,6 +60,16 @@ struct AppArgs {
     nvfi_grads g;
     const float* g_rgb; const float4* rgb_pre; const float* weight;
     float4* gxw;
+    float* gg;           // (M,48) per-sample channel gradients for k_plane_scatter (NULL: scatter in-kernel)
+};
+
+struct ScatterArgs {
+    nvfi_field_desc f;
+    const int* count; const int* list;
+    const float4* xw; float tn;
+    const float* gxpre;   // density: one upstream gradient per sample
+    const float* gg;      // appearance: (M,48)
+    nvfi_grads g;
 };
 
 __global__ void k_counters(const int* c, int nsteps, int64_t* out);
