@@ -325,13 +325,14 @@ struct WgradJob {
     float* slabs;                      // [nslab][ (32*MTA) * (32*KTB) + 32*MTA ]
     int nslab;
 };
-#define MAX_WGRAD_JOBS 16
+#define MAX_WGRAD_JOBS 24
 struct WgradJobs { WgradJob j[MAX_WGRAD_JOBS]; int n; };
 __global__ void k_wgrad(WgradJobs jobs);
 
 // slab reduce + un-permute into the logical gradient tensors
 struct ReduceJob {
     const float* slabs; int nslab; int MTA, KTB;
+    const float* slabs2; int nslab2;   // optional second slab set reduced into the same target
     float* gW; float* gb; int out, in;
     int row_kind, slot_kind;     // maps of the forward layer: rows of G = out rows (p-space of D layout), cols = input slots
     float scale;

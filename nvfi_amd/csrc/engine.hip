@@ -27,114 +27,154 @@ __global__ void k_pack(PackJobs jobs) {
     }
 }
 
-// G[pA][pB] = sum over tiles of A[pA][j] B[pB][j]; one slab per workgroup, reduced by k_wgrad_reduce.
-__global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradJobs jobs) {
-    const WgradJob& J = jobs.j[blockIdx.y];
-    if ((int)blockIdx.x >= J.nslab) return;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int a_rows = 2 * J.a_regs, b_rows = 2 * J.b_regs;
-    float* la = lds;
-    float* lb = lds + a_rows * 33;
-    const int KTB = b_rows >> 5, NTT = (a_rows >> 5) * KTB;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// G[pA][pB] = sum over tiles of A[pA][j] B[pB][j]  (p-space rows of the stash images).
+// No LDS, no barriers: the MFMA contraction index is the SAMPLE, and a stash row already holds the 32
+// samples of one p contiguously, so lane (i,h) reads row i, samples 16h..16h+15 (4 x 16-byte loads) and
+// MFMA step st pairs sample 16h+st of both operands.  Each wave is an independent worker that owns MT
+// row tiles x KT column tiles of G for a strided subset of the sample tiles and writes its own slab part;
+// k_wgrad_reduce sums the slabs and un-permutes into the logical gradient tensors.
+template <int MT, int KT>
+__device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int lane) {
     const int i = lane & 31, h = lane >> 5;
+    const int MTA = J.a_regs >> 4;
+    const int nhalves = MTA / MT;
+    const int mhalf = worker % nhalves, wslot = worker / nhalves;
+    if (wslot >= J.nslab) return;
+    const int a_rows = 2 * J.a_regs, b_rows = 2 * J.b_regs;
     int count = *J.count;
     int ntiles = (count + TILE - 1) / TILE;
     if (ntiles > J.cap_tiles) ntiles = J.cap_tiles;
     const int nitems = J.nrep * ntiles;
-    f32x16 acc[4];
+    f32x16 acc[MT][KT];
+    float bsum[MT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int mt = 0; mt < MT; ++mt) {
+        bsum[mt] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    float bsum = 0.f;
-    int aoff[4], boff[4];
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int tt = w + 4 * q;
-        int m = tt / KTB, kt = tt % KTB;
-        aoff[q] = (32 * m + i) * 33 + h;
-        boff[q] = (32 * kt + i) * 33 + h;
+            for (int r = 0; r < 16; ++r) acc[mt][kt][r] = 0.f;
     }
-    for (int item = blockIdx.x; item < nitems; item += J.nslab) {
-        int rep = item / ntiles, tile = item - rep * ntiles;
+    // float offset of (row p, sample 16h) inside a tile image: p = 2*reg + hh -> reg*64 + hh*32
+    int aoff[MT], boff[KT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { const int p = 32 * (mhalf * MT + mt) + i; aoff[mt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) { const int p = 32 * kt + i; boff[kt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
+    for (int item = wslot; item < nitems; item += J.nslab) {
+        const int rep = item / ntiles, tile = item - rep * ntiles;
         const float* At = J.A + (size_t)rep * J.a_rep_stride + (size_t)tile * J.a_tile_stride;
         const float* Bt = J.B + (size_t)rep * J.b_rep_stride + (size_t)tile * J.b_tile_stride;
         const float* B2t = J.B2 ? J.B2 + (size_t)rep * J.b2_rep_stride + (size_t)tile * J.b_tile_stride : nullptr;
-        __syncthreads();
-        for (int e = tid; e < J.a_regs * 64; e += WG_THREADS) {
-            int reg = e >> 6, ln = e & 63;
-            la[(2 * reg + (ln >> 5)) * 33 + (ln & 31)] = At[e];
-        }
-        for (int e = tid; e < J.b_regs * 64; e += WG_THREADS) {
-            int reg = e >> 6, ln = e & 63;
-            float v = Bt[e];
-            switch (J.bmode) {
-                case BM_SILU: v = act_f<1>(v); break;
-                case BM_RELU: v = act_f<0>(v); break;
-                case BM_SILU_TAN: v = act_d1<1>(v) * B2t[e]; break;
-                case BM_RELU_TAN: v = act_d1<0>(v) * B2t[e]; break;
-                default: break;
-            }
-            lb[(2 * reg + (ln >> 5)) * 33 + (ln & 31)] = v;
-        }
-        __syncthreads();
-        if (tid < a_rows) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < 32; ++j) s += la[tid * 33 + j];
-            bsum += s;
-        }
+        float a[MT][16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (w + 4 * q < NTT) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int st = 0; st < 16; ++st) acc[q] = MFMA32(la[aoff[q] + 2 * st], lb[boff[q] + 2 * st], acc[q]);
+            for (int v = 0; v < 4; ++v) {
+                const float4 t4 = *reinterpret_cast<const float4*>(At + aoff[mt] + 4 * v);
+                a[mt][4 * v] = t4.x; a[mt][4 * v + 1] = t4.y; a[mt][4 * v + 2] = t4.z; a[mt][4 * v + 3] = t4.w;
             }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) bsum[mt] += a[mt][v];
+        }
+        // B operand in groups of two column tiles (keeps the live set under 256 VGPRs at 2 waves/SIMD)
+        constexpr int KG = KT >= 2 ? 2 : 1;
+#pragma unroll
+        for (int k0 = 0; k0 < KT; k0 += KG) {
+            float b[KG][16];
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) {
+                const int kt = k0 + kk;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(Bt + boff[kt] + 4 * v);
+                    float z[4] = {t4.x, t4.y, t4.z, t4.w};
+                    if (J.bmode == BM_SILU) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) z[c] = act_f<1>(z[c]);
+                    } else if (J.bmode == BM_RELU) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) z[c] = act_f<0>(z[c]);
+                    } else if (J.bmode == BM_SILU_TAN || J.bmode == BM_RELU_TAN) {
+                        const float4 u4 = *reinterpret_cast<const float4*>(B2t + boff[kt] + 4 * v);
+                        const float z2[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) z[c] = (J.bmode == BM_SILU_TAN ? act_d1<1>(z[c]) : act_d1<0>(z[c])) * z2[c];
+                    }
+                    b[kk][4 * v] = z[0]; b[kk][4 * v + 1] = z[1]; b[kk][4 * v + 2] = z[2]; b[kk][4 * v + 3] = z[3];
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 16; ++st)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int kk = 0; kk < KG; ++kk) acc[mt][k0 + kk] = MFMA32(a[mt][st], b[kk][st], acc[mt][k0 + kk]);
         }
     }
-    float* S = J.slabs + (size_t)blockIdx.x * ((size_t)a_rows * b_rows + a_rows);
+    float* S = J.slabs + (size_t)wslot * ((size_t)a_rows * b_rows + a_rows);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int tt = w + 4 * q;
-        if (tt < NTT) {
-            int m = tt / KTB, kt = tt % KTB;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mhalf * MT + mt;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
-                S[(size_t)row * b_rows + 32 * kt + i] = acc[q][r];
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                S[(size_t)row * b_rows + 32 * kt + i] = acc[mt][kt][r];
             }
-        }
+        float bs = bsum[mt] + __shfl_xor(bsum[mt], 32);
+        if (h == 0) S[(size_t)a_rows * b_rows + 32 * m + i] = bs;
     }
-    if (tid < a_rows) S[(size_t)a_rows * b_rows + tid] = bsum;
 }
 
-__global__ void k_wgrad_reduce(ReduceJobs jobs) {
+__global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgradJobs jobs) {
+    const WgradJob& J = jobs.j[blockIdx.y];
+    const int worker = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (J.a_regs == 64 && J.b_regs == 64) wgrad_worker<2, 4>(J, worker, lane);
+    else if (J.a_regs == 16 && J.b_regs == 64) wgrad_worker<1, 4>(J, worker, lane);
+    else if (J.a_regs == 64 && J.b_regs == 16) wgrad_worker<2, 1>(J, worker, lane);
+    else if (J.a_regs == 16 && J.b_regs == 32) wgrad_worker<1, 2>(J, worker, lane);
+}
+
+// 64 G entries per workgroup; 4 threads per entry each sum a quarter of the slabs
+__global__ __launch_bounds__(256) void k_wgrad_reduce(ReduceJobs jobs) {
+    __shared__ float part[4][64];
     const ReduceJob& J = jobs.j[blockIdx.y];
     const int a_rows = 32 * J.MTA, b_rows = 32 * J.KTB;
     const size_t slab = (size_t)a_rows * b_rows + a_rows;
     const int total = a_rows * b_rows + a_rows;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        int pA, pB = -1;
-        if (idx < a_rows * b_rows) { pA = idx / b_rows; pB = idx - pA * b_rows; }
-        else pA = idx - a_rows * b_rows;
-        // G rows/cols are p-space indices (p = 2*reg + h) of the A / B stash images
-        int o = row_logical(J.row_kind, dmap(pA >> 1, pA & 1));
-        if (o < 0 || o >= J.out) continue;
-        float* dst;
-        if (pB >= 0) {
-            int in = slot_logical(J.slot_kind, pB);
-            if (in < 0 || in >= J.in || !J.gW) continue;
-            dst = J.gW + (size_t)o * J.in + in;
-        } else {
-            if (!J.gb) continue;
-            dst = J.gb + o;
-        }
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int start = J.gW ? 0 : a_rows * b_rows;   // bias-only job: skip the weight entries
+    for (int base = start + blockIdx.x * 64; base < total; base += gridDim.x * 64) {
+        const int idx = base + e;
         float s = 0.f;
-        for (int k = 0; k < J.nslab; ++k) s += J.slabs[(size_t)k * slab + idx];
-        *dst += J.scale * s;
+        if (idx < total) {
+            for (int k = g; k < J.nslab; k += 4) s += J.slabs[(size_t)k * slab + idx];
+            if (J.slabs2) for (int k = g; k < J.nslab2; k += 4) s += J.slabs2[(size_t)k * slab + idx];
+        }
+        __syncthreads();
+        part[g][e] = s;
+        __syncthreads();
+        if (g == 0 && idx < total) {
+            s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+            int pA, pB = -1;
+            if (idx < a_rows * b_rows) { pA = idx / b_rows; pB = idx - pA * b_rows; }
+            else pA = idx - a_rows * b_rows;
+            // G rows/cols are p-space indices (p = 2*reg + h) of the A / B stash images
+            const int o = row_logical(J.row_kind, dmap(pA >> 1, pA & 1));
+            if (o >= 0 && o < J.out) {
+                if (pB >= 0) {
+                    const int in = slot_logical(J.slot_kind, pB);
+                    if (in >= 0 && in < J.in && J.gW) J.gW[(size_t)o * J.in + in] += J.scale * s;
+                } else if (J.gb) J.gb[o] += J.scale * s;
+            }
+        }
     }
 }
+
+static_assert(sizeof(WgradJobs) <= 4000 && sizeof(ReduceJobs) <= 4000 && sizeof(PackJobs) <= 4000, "kernel argument blocks must stay under 4 KB");
 
 // ---------------------------------------------------------------- host launchers (kept in this TU: no relocatable device code needed)
 int launch_pack(const PackJobs& jobs, hipStream_t st) {
@@ -145,17 +185,17 @@ int launch_pack(const PackJobs& jobs, hipStream_t st) {
 }
 int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st) {
     if (wj.n == 0) return 0;
-    static bool attr = false;
-    const int lds_bytes = 2 * 128 * 33 * 4;
-    if (!attr) {
-        HIPCK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr = true;
+    int nworkers = 0;
+    for (int i = 0; i < wj.n; ++i) {
+        const WgradJob& J = wj.j[i];
+        const bool ok = (J.a_regs == 64 && J.b_regs == 64) || (J.a_regs == 16 && J.b_regs == 64) || (J.a_regs == 64 && J.b_regs == 16) || (J.a_regs == 16 && J.b_regs == 32);
+        if (!ok) return nvfi_fail(5, "k_wgrad: unsupported tile shape a_regs=%d b_regs=%d", J.a_regs, J.b_regs);
+        const int w = J.nslab * (J.a_regs == 64 ? 2 : 1);
+        nworkers = w > nworkers ? w : nworkers;
     }
-    int nslab = 0;
-    for (int i = 0; i < wj.n; ++i) nslab = wj.j[i].nslab > nslab ? wj.j[i].nslab : nslab;
     ProfScope ps(PK_WGRAD, st);
-    hipLaunchKernelGGL(k_wgrad, dim3(nslab, wj.n), dim3(WG_THREADS), lds_bytes, st, wj);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(32, rj.n), dim3(256), 0, st, rj);
+    hipLaunchKernelGGL(k_wgrad, dim3((nworkers + 3) / 4, wj.n), dim3(WG_THREADS), 0, st, wj);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(260, rj.n), dim3(256), 0, st, rj);
     LAUNCHCK();
     return 0;
 }

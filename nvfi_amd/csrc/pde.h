@@ -3,8 +3,8 @@
 #include "common.h"
 
 #define PDE_MAX_CLASS 64           // RK2 step-count buckets
-#define PDE_CHUNK 32768            // kept points processed per pass (bounds the stash)
-#define PDE_NSLAB 64
+#define PDE_CHUNK 65536            // kept points processed per pass (bounds the stash)
+#define PDE_NSLAB 128
 
 // per-tile stash rows (each row = 64 floats)
 #define PDE_Z     0                          // weight_net pre-activations        5*64
@@ -12,8 +12,8 @@
 #define PDE_X0    (PDE_ZD + 4 * 320)         // encoder slots                      16
 #define PDE_X0D   (PDE_X0 + 16)              // encoder tangents               4 x 16
 #define PDE_GA    (PDE_X0D + 64)             // adjoints: value, 4 tangents   5 x 336
-#define PDE_CORR  (PDE_GA + 5 * 336)         // second-derivative correction      320
-#define PDE_ZA    (PDE_CORR + 320)           // a_weight_net pre-activations      320
+#define PDE_CORR  (PDE_GA + 5 * 336)         // second-derivative corrections 4 x 320 (one per tangent column)
+#define PDE_ZA    (PDE_CORR + 4 * 320)           // a_weight_net pre-activations      320
 #define PDE_GAA   (PDE_ZA + 320)             // a_weight_net adjoints             336
 #define PDE_TILE_ROWS (PDE_GAA + 336)
 
@@ -29,9 +29,9 @@ struct PdeJetArgs {
     VelFrags Wv, Wa;
     const float4* qorig; const int* klist;
     int64_t first; int count; int64_t cap;
-    float* stash; float* seeds; double* sums;
+    float* stash; float* seeds; float* wout; double* sums;
     float inv_n, scale;
     float* jac; int64_t n_jac;
 };
 
-int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, const nvfi_grads* G, hipStream_t st);
+int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st);

@@ -210,7 +210,10 @@ __device__ __forceinline__ void velnet_value_backward(const VelFrags& W, float* 
             for (int r = 0; r < 16; ++r) {
                 const int s = 16 * m + r;
                 float v = act_d1<ACT>(zl[s * REGF + lane]) * acc[m][r];
-                if (CORR) v += corr[(size_t)l * 64 * REGF + s * REGF + lane];
+                if (CORR) {
+                    const float* c0 = corr + (size_t)l * 64 * REGF + s * REGF + lane;
+                    v += (c0[0] + c0[(size_t)320 * REGF]) + (c0[(size_t)640 * REGF] + c0[(size_t)960 * REGF]);
+                }
                 g[s] = v;
             }
         stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
@@ -224,141 +227,174 @@ __device__ __forceinline__ void velnet_value_backward(const VelFrags& W, float* 
     }
 }
 
-// forward: value + 4 tangents (weight_net), value (a_weight_net), loss partial sums and adjoint seeds
-__global__ __launch_bounds__(WG_THREADS, 2) void k_pde_fwd(PdeJetArgs a) {
+// ---- column-parallel jet kernels: the value column, the 4 tangent columns and the a_weight_net column of a
+// tile run in DIFFERENT workgroups (blockIdx.y = column) so that a few ten-thousand kept points still fill 256 CUs.
+
+// K1: value forward of weight_net (y=0) and a_weight_net (y=1)
+__global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_fwd(PdeJetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
-    __shared__ float red[8];
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int tile = blockIdx.x * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     const bool active = i < a.count;
     float4 q = active ? a.qorig[a.klist[a.first + i]] : zero4();
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
-    float o4[4], w[6], wd[4][6], aw[6], x0[16];
-    velnet_forward<1>(a.Wv, lds_w, lds_b, lane, q, T + PDE_Z * REGF, T + PDE_X0 * REGF, o4);
+    float o4[4], w[6];
+    if (blockIdx.y == 0) velnet_forward<1>(a.Wv, lds_w, lds_b, lane, q, T + PDE_Z * REGF, T + PDE_X0 * REGF, o4);
+    else velnet_forward<0>(a.Wa, lds_w, lds_b, lane, q, T + PDE_ZA * REGF, nullptr, o4);
     gather6(o4, h, w);
-    vel_encode_slots(q, h, x0);
-#pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
-        float xd[16];
-        encode_tangent(x0, h, j, xd);
-        stash_store<16>(T + (PDE_X0D + 16 * j) * REGF, lane, xd);
-        velnet_tangent_forward<1>(a.Wv, lds_w, lds_b, lane, xd, T + PDE_Z * REGF, T + (PDE_ZD + 320 * j) * REGF, o4);
-        float tmp[6];
-        gather6(o4, h, tmp);
+    if (h == 0 && i < a.cap) {
+        float* o = a.wout + (size_t)(blockIdx.y == 0 ? 0 : 30) * a.cap + i;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[(size_t)k * a.cap] = w[k];
+    }
+}
+// K2: tangent column j = blockIdx.y of weight_net
+__global__ __launch_bounds__(WG_THREADS, 2) void k_pde_tangent_fwd(PdeJetArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int j = blockIdx.y;
+    const int tile = blockIdx.x * 4 + wave_id();
+    const int i = tile * TILE + (lane & 31);
+    float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
+    float x0[16], xd[16], o4[4], wd[6];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) x0[s] = T[(PDE_X0 + s) * REGF + lane];
+    encode_tangent(x0, h, j, xd);
+    stash_store<16>(T + (PDE_X0D + 16 * j) * REGF, lane, xd);
+    velnet_tangent_forward<1>(a.Wv, lds_w, lds_b, lane, xd, T + PDE_Z * REGF, T + (PDE_ZD + 320 * j) * REGF, o4);
+    gather6(o4, h, wd);
+    if (h == 0 && i < a.cap) {
+        float* o = a.wout + (size_t)(6 + 6 * j) * a.cap + i;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[(size_t)k * a.cap] = wd[k];
+    }
+}
+// K3: per-point residuals (nvfi.py:74-83), loss partial sums and adjoint seeds
+__global__ __launch_bounds__(256) void k_pde_seeds(PdeJetArgs a) {
+    __shared__ float red[8];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < a.count;
+    const size_t cs = a.cap;
+    float sd = 0.f, st = 0.f;
+    if (i < a.cap) {
+        float w[6], wd[4][6], aw[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            if (j == 0) wd[0][k] = tmp[k];
-            else if (j == 1) wd[1][k] = tmp[k];
-            else if (j == 2) wd[2][k] = tmp[k];
-            else wd[3][k] = tmp[k];
+            w[k] = a.wout[(size_t)k * cs + i]; aw[k] = a.wout[(size_t)(30 + k) * cs + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wd[j][k] = a.wout[(size_t)(6 + 6 * j + k) * cs + i];
         }
-    }
-    velnet_forward<0>(a.Wa, lds_w, lds_b, lane, q, T + PDE_ZA * REGF, nullptr, o4);
-    gather6(o4, h, aw);
-    // ---- per-point residuals (nvfi.py:74-83)
-    const float x = q.x, y = q.y, z = q.z;
-    float v[3], ac[3], Jv[3][4];
-    vel_from_w(w, x, y, z, v);
-    acc_from_w(aw, x, y, z, ac);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        Jv[0][j] = wd[j][0] - wd[j][4] * z + wd[j][5] * y;
-        Jv[1][j] = wd[j][1] + wd[j][3] * z - wd[j][5] * x;
-        Jv[2][j] = wd[j][2] - wd[j][3] * y + wd[j][4] * x;
-    }
-    Jv[0][2] += -w[4]; Jv[0][1] += w[5];
-    Jv[1][2] += w[3];  Jv[1][0] += -w[5];
-    Jv[2][1] += -w[3]; Jv[2][0] += w[4];
-    const float div = Jv[0][0] + Jv[1][1] + Jv[2][2];
-    float tr[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) tr[c] = Jv[c][0] * v[0] + Jv[c][1] * v[1] + Jv[c][2] * v[2] + Jv[c][3] - ac[c];
-    const bool mine = active && h == 0;
-    float sd = mine ? div * div : 0.f, st = mine ? (tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2]) : 0.f;
-    sd = wave_sum(sd); st = wave_sum(st);
-    if (lane == 0) { red[wave_id()] = sd; red[4 + wave_id()] = st; }
-    // ---- adjoint seeds
-    if (mine) {
-        const float gdiv = a.scale * 10.f * div * a.inv_n;
-        float gtr[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gtr[c] = a.scale * 0.2f * tr[c] * a.inv_n / 3.f;
-        float gJ[3][4], gv[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { gJ[c][k] = gtr[c] * v[k]; gv[k] += gtr[c] * Jv[c][k]; }
-            gJ[c][3] = gtr[c];
-            gJ[c][c] += gdiv;
-        }
-        float* sp = a.seeds + i;
-        const size_t cs = a.cap;
-        sp[0 * cs] = gv[0]; sp[1 * cs] = gv[1]; sp[2 * cs] = gv[2];
-        sp[3 * cs] = z * gv[1] - y * gv[2] + gJ[1][2] - gJ[2][1];
-        sp[4 * cs] = -z * gv[0] + x * gv[2] - gJ[0][2] + gJ[2][0];
-        sp[5 * cs] = y * gv[0] - x * gv[1] + gJ[0][1] - gJ[1][0];
+        float4 q = active ? a.qorig[a.klist[a.first + i]] : zero4();
+        const float x = q.x, y = q.y, z = q.z;
+        float v[3], ac[3], Jv[3][4];
+        vel_from_w(w, x, y, z, v);
+        acc_from_w(aw, x, y, z, ac);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            sp[(6 + 6 * j + 0) * cs] = gJ[0][j]; sp[(6 + 6 * j + 1) * cs] = gJ[1][j]; sp[(6 + 6 * j + 2) * cs] = gJ[2][j];
-            sp[(6 + 6 * j + 3) * cs] = z * gJ[1][j] - y * gJ[2][j];
-            sp[(6 + 6 * j + 4) * cs] = -z * gJ[0][j] + x * gJ[2][j];
-            sp[(6 + 6 * j + 5) * cs] = y * gJ[0][j] - x * gJ[1][j];
+            Jv[0][j] = wd[j][0] - wd[j][4] * z + wd[j][5] * y;
+            Jv[1][j] = wd[j][1] + wd[j][3] * z - wd[j][5] * x;
+            Jv[2][j] = wd[j][2] - wd[j][3] * y + wd[j][4] * x;
         }
-        const float ga[3] = {-gtr[0], -gtr[1], -gtr[2]};
-        sp[30 * cs] = ga[0]; sp[31 * cs] = ga[1]; sp[32 * cs] = ga[2];
-        sp[33 * cs] = -y * ga[1] - z * ga[2];
-        sp[34 * cs] = -x * ga[0] - z * ga[2];
-        sp[35 * cs] = -x * ga[0] - y * ga[1];
-        if (a.jac && (a.first + i) < a.n_jac) {
-            float* jp = a.jac + (size_t)(a.first + i) * 24;
+        Jv[0][2] += -w[4]; Jv[0][1] += w[5];
+        Jv[1][2] += w[3];  Jv[1][0] += -w[5];
+        Jv[2][1] += -w[3]; Jv[2][0] += w[4];
+        const float div = Jv[0][0] + Jv[1][1] + Jv[2][2];
+        float tr[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c) tr[c] = Jv[c][0] * v[0] + Jv[c][1] * v[1] + Jv[c][2] * v[2] + Jv[c][3] - ac[c];
+        float* sp = a.seeds + i;
+        if (active) {
+            sd = div * div; st = tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2];
+            const float gdiv = a.scale * 10.f * div * a.inv_n;
+            float gtr[3];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) jp[c * 4 + j] = Jv[c][j];
+            for (int c = 0; c < 3; ++c) gtr[c] = a.scale * 0.2f * tr[c] * a.inv_n / 3.f;
+            float gJ[3][4], gv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 12; k < 24; ++k) jp[k] = 0.f;
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { gJ[c][k] = gtr[c] * v[k]; gv[k] += gtr[c] * Jv[c][k]; }
+                gJ[c][3] = gtr[c];
+                gJ[c][c] += gdiv;
+            }
+            sp[0 * cs] = gv[0]; sp[1 * cs] = gv[1]; sp[2 * cs] = gv[2];
+            sp[3 * cs] = z * gv[1] - y * gv[2] + gJ[1][2] - gJ[2][1];
+            sp[4 * cs] = -z * gv[0] + x * gv[2] - gJ[0][2] + gJ[2][0];
+            sp[5 * cs] = y * gv[0] - x * gv[1] + gJ[0][1] - gJ[1][0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sp[(6 + 6 * j + 0) * cs] = gJ[0][j]; sp[(6 + 6 * j + 1) * cs] = gJ[1][j]; sp[(6 + 6 * j + 2) * cs] = gJ[2][j];
+                sp[(6 + 6 * j + 3) * cs] = z * gJ[1][j] - y * gJ[2][j];
+                sp[(6 + 6 * j + 4) * cs] = -z * gJ[0][j] + x * gJ[2][j];
+                sp[(6 + 6 * j + 5) * cs] = y * gJ[0][j] - x * gJ[1][j];
+            }
+            const float ga[3] = {-gtr[0], -gtr[1], -gtr[2]};
+            sp[30 * cs] = ga[0]; sp[31 * cs] = ga[1]; sp[32 * cs] = ga[2];
+            sp[33 * cs] = -y * ga[1] - z * ga[2];
+            sp[34 * cs] = -x * ga[0] - z * ga[2];
+            sp[35 * cs] = -x * ga[0] - y * ga[1];
+            if (a.jac && (a.first + i) < a.n_jac) {
+                float* jp = a.jac + (size_t)(a.first + i) * 24;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) jp[c * 4 + j] = Jv[c][j];
+#pragma unroll
+                for (int k = 12; k < 24; ++k) jp[k] = 0.f;
+            }
+        } else {
+            // ragged tail of the last workgroup: zero seeds so that every adjoint stash row is zero
+            for (int k = 0; k < 36; ++k) sp[(size_t)k * cs] = 0.f;
         }
-    } else if (h == 0 && i < a.cap) {
-        // ragged tail of an active workgroup: zero seeds so that every adjoint stash row is zero
-        for (int k = 0; k < 36; ++k) a.seeds[(size_t)k * a.cap + i] = 0.f;
     }
+    sd = wave_sum(sd); st = wave_sum(st);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sd; red[4 + (threadIdx.x >> 6)] = st; }
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(a.sums + 0, (double)(red[0] + red[1] + red[2] + red[3]));
         atomicAdd(a.sums + 1, (double)(red[4] + red[5] + red[6] + red[7]));
     }
 }
-
-// backward: 4 tangent-adjoint passes, the value-adjoint pass, and the a_weight_net adjoint
-__global__ __launch_bounds__(WG_THREADS, 2) void k_pde_bwd(PdeJetArgs a) {
+// K4: tangent-adjoint column j = blockIdx.y (0..3) or the a_weight_net adjoint (y = 4)
+__global__ __launch_bounds__(WG_THREADS, 2) void k_pde_tangent_bwd(PdeJetArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int j = blockIdx.y;
+    const int tile = blockIdx.x * 4 + wave_id();
+    const int i = tile * TILE + (lane & 31);
+    float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
+    const size_t cs = a.cap;
+    const bool ok = i < a.cap;
+    float r4[4], s6[6];
+    const int sbase = j < 4 ? 6 + 6 * j : 30;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s6[k] = ok ? a.seeds[(size_t)(sbase + k) * cs + i] : 0.f;
+    scatter6(s6, h, r4);
+    if (j < 4)
+        velnet_tangent_backward<1>(a.Wv, lds_w, lds_b, lane, r4, T + PDE_Z * REGF, T + (PDE_ZD + 320 * j) * REGF,
+                                   T + (PDE_CORR + 320 * j) * REGF, true, T + (PDE_GA + 336 * (1 + j)) * REGF);
+    else
+        velnet_value_backward<0, false>(a.Wa, lds_w, lds_b, lane, r4, T + PDE_ZA * REGF, nullptr, T + PDE_GAA * REGF);
+}
+// K5: value adjoint of weight_net with the summed second-derivative corrections
+__global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_bwd(PdeJetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int tile = blockIdx.x * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
-    const float* sp = a.seeds + (i < a.cap ? i : 0);
     const size_t cs = a.cap;
     const bool ok = i < a.cap;
     float r4[4], s6[6];
-#pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s6[k] = ok ? sp[(6 + 6 * j + k) * cs] : 0.f;
-        scatter6(s6, h, r4);
-        velnet_tangent_backward<1>(a.Wv, lds_w, lds_b, lane, r4, T + PDE_Z * REGF, T + (PDE_ZD + 320 * j) * REGF,
-                                   T + PDE_CORR * REGF, j == 0, T + (PDE_GA + 336 * (1 + j)) * REGF);
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s6[k] = ok ? sp[k * cs] : 0.f;
+    for (int k = 0; k < 6; ++k) s6[k] = ok ? a.seeds[(size_t)k * cs + i] : 0.f;
     scatter6(s6, h, r4);
     velnet_value_backward<1, true>(a.Wv, lds_w, lds_b, lane, r4, T + PDE_Z * REGF, T + PDE_CORR * REGF, T + PDE_GA * REGF);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s6[k] = ok ? sp[(30 + k) * cs] : 0.f;
-    scatter6(s6, h, r4);
-    velnet_value_backward<0, false>(a.Wa, lds_w, lds_b, lane, r4, T + PDE_ZA * REGF, nullptr, T + PDE_GAA * REGF);
 }
 
 __global__ void k_pde_finish(const double* sums, int64_t nk, float* out) {
@@ -373,10 +409,10 @@ __global__ void k_pde_finish(const double* sums, int64_t nk, float* out) {
 struct PdePlan {
     float4 *qorig, *xw;
     float *pt_t, *pt_base, *pt_t_perm, *pt_base_perm;
-    int *cls, *rank, *cls_count, *perm, *cnt, *off, *klist, *kcount;
+    int *cls, *rank, *cls_count, *perm, *cnt, *off, *klist, *kcount, *dcount;
     uint8_t* flags;
     double* sums;
-    float *vel_frag, *a_frag, *stash, *seeds, *slabs;
+    float *vel_frag, *a_frag, *stash, *seeds, *wout, *slabs;
     int64_t chunk, total;
 };
 static void plan_pde(int64_t P, void* ws, PdePlan* L) {
@@ -388,11 +424,13 @@ static void plan_pde(int64_t P, void* ws, PdePlan* L) {
     L->cnt = B.take<int>(nw); L->off = B.take<int>(nw + 1); L->klist = B.take<int>(P); L->kcount = L->cls_count + PDE_MAX_CLASS;
     L->flags = B.take<uint8_t>(nw * 64);
     L->sums = B.take<double>(4);
+    L->dcount = B.take<int>(16);
     L->vel_frag = B.take<float>(VEL_FRAG_FLOATS); L->a_frag = B.take<float>(VEL_FRAG_FLOATS);
     L->chunk = P < PDE_CHUNK ? (P + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES : PDE_CHUNK;
     L->stash = B.take<float>(L->chunk / TILE * (int64_t)PDE_TILE_ROWS * REGF);
     L->seeds = B.take<float>(36 * L->chunk);
-    L->slabs = B.take<float>((int64_t)PDE_NSLAB * (128 * 128 + 128) * 6);
+    L->wout = B.take<float>(36 * L->chunk);
+    L->slabs = B.take<float>((int64_t)PDE_NSLAB * (128 * 128 + 128) * 18);
     L->total = align_up(B.off, 256);
 }
 extern "C" int nvfi_pde_workspace_bytes(const nvfi_field_desc* f, int64_t P, int64_t* bytes) {
@@ -405,8 +443,10 @@ extern "C" int nvfi_pde_workspace_bytes(const nvfi_field_desc* f, int64_t P, int
 static int ensure_pde_attrs() {
     static bool done = false;
     if (done) return 0;
-    HIPCK(hipFuncSetAttribute((const void*)k_pde_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_pde_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_pde_value_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_pde_tangent_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_pde_tangent_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_pde_value_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     done = true;
     return 0;
 }
@@ -462,11 +502,21 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
             ja.Wv = VW; ja.Wa = AW; ja.qorig = L.qorig; ja.klist = L.klist; ja.first = first; ja.count = (int)cnt; ja.cap = cap;
             ja.stash = L.stash; ja.seeds = L.seeds; ja.sums = L.sums; ja.inv_n = inv_n; ja.scale = loss_scale; ja.jac = jac_out; ja.n_jac = n_jac;
             const unsigned wgs = (unsigned)(cap / WG_SAMPLES);
-            { ProfScope ps(PK_PDE_FWD, st); hipLaunchKernelGGL(k_pde_fwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja); }
+            ja.wout = L.wout;
+            {
+                ProfScope ps(PK_PDE_FWD, st);
+                hipLaunchKernelGGL(k_pde_value_fwd, dim3(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                hipLaunchKernelGGL(k_pde_tangent_fwd, dim3(wgs, 4), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                hipLaunchKernelGGL(k_pde_seeds, dim3((unsigned)(cap / 256 + 1)), dim3(256), 0, st, ja);
+            }
             if (grads) {
-                { ProfScope ps(PK_PDE_BWD, st); hipLaunchKernelGGL(k_pde_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja); }
+                {
+                    ProfScope ps(PK_PDE_BWD, st);
+                    hipLaunchKernelGGL(k_pde_tangent_bwd, dim3(wgs, 5), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                    hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                }
                 LAUNCHCK();
-                if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, grads, st)) return 1;
+                if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, st)) return 1;
             }
             LAUNCHCK();
         }
@@ -487,47 +537,58 @@ extern "C" int nvfi_pde_loss(const nvfi_field_desc* f, int64_t P, const float* p
 }
 
 // weight gradients of both nets from one chunk's stash
-int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, const nvfi_grads* G, hipStream_t st) {
+int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st) {
     const size_t ts = (size_t)PDE_TILE_ROWS * REGF;
     const size_t slab = (size_t)PDE_NSLAB * (128 * 128 + 128);
-    // device-side count is not needed: tiles are exact for the chunk -> use a static count buffer trick: count = ntiles*32
-    // (k_wgrad reads *count; we keep a small device int in the slab area's tail)
-    int* dcount = reinterpret_cast<int*>(slabs + 6 * slab - 64);
+    // k_wgrad reads the sample count from device memory
     const int hc = ntiles * TILE;
     HIPCK(hipMemcpyAsync(dcount, &hc, sizeof(int), hipMemcpyHostToDevice, st));
     HIPCK(hipStreamSynchronize(st));
-    for (int pass = 0; pass < 3; ++pass) {
-        WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
+    WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
+    for (int net = 0; net < 2; ++net)
         for (int l = 0; l < 6; ++l) {
-            float* gW = pass < 2 ? G->vW[l] : G->aW[l];
-            float* gb = pass == 0 ? G->vb[l] : (pass == 1 ? nullptr : G->ab[l]);   // tangent columns carry no bias term
+            float* gW = net == 0 ? G->vW[l] : G->aW[l];
+            float* gb = net == 0 ? G->vb[l] : G->ab[l];
             if (!gW && !gb) continue;
-            WgradJob& J = wj.j[wj.n++];
-            memset(&J, 0, sizeof(J));
-            J.a_tile_stride = ts; J.b_tile_stride = ts; J.a_regs = l < 5 ? 64 : 16; J.count = dcount; J.cap_tiles = ntiles;
-            J.slabs = slabs + (size_t)l * slab; J.nslab = PDE_NSLAB;
-            if (pass == 0) {          // value column of weight_net
-                J.A = stash + (size_t)(PDE_GA + l * 64) * REGF; J.nrep = 1;
-                if (l == 0) { J.B = stash + (size_t)PDE_X0 * REGF; J.b_regs = 16; J.bmode = BM_RAW; }
-                else { J.B = stash + (size_t)(PDE_Z + (l - 1) * 64) * REGF; J.b_regs = 64; J.bmode = BM_SILU; }
-            } else if (pass == 1) {   // 4 tangent columns
-                J.A = stash + (size_t)(PDE_GA + 336 + l * 64) * REGF; J.nrep = 4; J.a_rep_stride = (size_t)336 * REGF;
-                if (l == 0) { J.B = stash + (size_t)PDE_X0D * REGF; J.b_regs = 16; J.bmode = BM_RAW; J.b_rep_stride = (size_t)16 * REGF; }
-                else {
-                    J.B = stash + (size_t)(PDE_Z + (l - 1) * 64) * REGF; J.b_rep_stride = 0;
-                    J.B2 = stash + (size_t)(PDE_ZD + (l - 1) * 64) * REGF; J.b2_rep_stride = (size_t)320 * REGF;
-                    J.b_regs = 64; J.bmode = BM_SILU_TAN;
+            const int npass = net == 0 ? 2 : 1;    // weight_net: value column + 4 tangent columns
+            float* sl[2] = {nullptr, nullptr};
+            for (int pass = 0; pass < npass; ++pass) {
+                WgradJob& J = wj.j[wj.n];
+                memset(&J, 0, sizeof(J));
+                J.a_tile_stride = ts; J.b_tile_stride = ts; J.a_regs = l < 5 ? 64 : 16; J.count = dcount; J.cap_tiles = ntiles;
+                J.slabs = slabs + (size_t)wj.n * slab; J.nslab = PDE_NSLAB;
+                sl[pass] = J.slabs;
+                ++wj.n;
+                if (net == 1) {               // a_weight_net
+                    J.A = stash + (size_t)(PDE_GAA + l * 64) * REGF; J.nrep = 1;
+                    if (l == 0) { J.B = stash + (size_t)PDE_X0 * REGF; J.b_regs = 16; J.bmode = BM_RAW; }
+                    else { J.B = stash + (size_t)(PDE_ZA + (l - 1) * 64) * REGF; J.b_regs = 64; J.bmode = BM_RELU; }
+                } else if (pass == 0) {       // value column of weight_net
+                    J.A = stash + (size_t)(PDE_GA + l * 64) * REGF; J.nrep = 1;
+                    if (l == 0) { J.B = stash + (size_t)PDE_X0 * REGF; J.b_regs = 16; J.bmode = BM_RAW; }
+                    else { J.B = stash + (size_t)(PDE_Z + (l - 1) * 64) * REGF; J.b_regs = 64; J.bmode = BM_SILU; }
+                } else {                      // 4 tangent columns (no bias term)
+                    J.A = stash + (size_t)(PDE_GA + 336 + l * 64) * REGF; J.nrep = 4; J.a_rep_stride = (size_t)336 * REGF;
+                    if (l == 0) { J.B = stash + (size_t)PDE_X0D * REGF; J.b_regs = 16; J.bmode = BM_RAW; J.b_rep_stride = (size_t)16 * REGF; }
+                    else {
+                        J.B = stash + (size_t)(PDE_Z + (l - 1) * 64) * REGF; J.b_rep_stride = 0;
+                        J.B2 = stash + (size_t)(PDE_ZD + (l - 1) * 64) * REGF; J.b2_rep_stride = (size_t)320 * REGF;
+                        J.b_regs = 64; J.bmode = BM_SILU_TAN;
+                    }
                 }
-            } else {                  // a_weight_net
-                J.A = stash + (size_t)(PDE_GAA + l * 64) * REGF; J.nrep = 1;
-                if (l == 0) { J.B = stash + (size_t)PDE_X0 * REGF; J.b_regs = 16; J.bmode = BM_RAW; }
-                else { J.B = stash + (size_t)(PDE_ZA + (l - 1) * 64) * REGF; J.b_regs = 64; J.bmode = BM_RELU; }
             }
+            const int a_regs = l < 5 ? 64 : 16, b_regs = l == 0 ? 16 : 64;
+            // weights: value (+ tangent) slabs; bias: value slabs only (tangent columns carry no bias term)
             ReduceJob& Q = rj.j[rj.n++];
-            Q.slabs = J.slabs; Q.nslab = PDE_NSLAB; Q.MTA = J.a_regs / 16; Q.KTB = J.b_regs / 16; Q.gW = gW; Q.gb = gb;
+            memset(&Q, 0, sizeof(Q));
+            Q.slabs = sl[0]; Q.nslab = PDE_NSLAB; Q.slabs2 = sl[1]; Q.nslab2 = sl[1] ? PDE_NSLAB : 0;
+            Q.MTA = a_regs / 16; Q.KTB = b_regs / 16; Q.gW = gW; Q.gb = nullptr;
             Q.out = l < 5 ? 128 : 6; Q.in = l == 0 ? 28 : 128; Q.row_kind = RK_NATURAL; Q.slot_kind = l == 0 ? SK_VEL_IN : SK_HIDDEN; Q.scale = 1.f;
+            if (gb) {
+                ReduceJob& Qb = rj.j[rj.n++];
+                Qb = Q; Qb.slabs2 = nullptr; Qb.nslab2 = 0; Qb.gW = nullptr; Qb.gb = gb;
+            }
         }
-        if (launch_wgrad(wj, rj, st)) return 1;
-    }
+    if (launch_wgrad(wj, rj, st)) return 1;
     return 0;
 }

@@ -762,7 +762,7 @@ struct RenderPlan {
     float *slabs;
     int64_t total;
 };
-#define NSLAB 96
+#define NSLAB 256
 #define SLAB_FLOATS (128 * 128 + 128)
 
 static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nsteps, void* ws, RenderPlan* P) {
@@ -955,6 +955,7 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
             J.bmode = BM_RAW; J.count = P.counters + 1; J.cap_tiles = (int)P.cap_tiles; J.nrep = 1; J.a_rep_stride = 0; J.b_rep_stride = 0;
             J.slabs = slabs; J.nslab = NSLAB;
             ReduceJob& Q = rj.j[rj.n++];
+            memset(&Q, 0, sizeof(Q));
             Q.slabs = slabs; Q.nslab = NSLAB; Q.MTA = a_regs / 16; Q.KTB = b_regs / 16; Q.gW = gW; Q.gb = gb; Q.out = out; Q.in = in;
             Q.row_kind = RK_NATURAL; Q.slot_kind = sk; Q.scale = 1.f;
         };
@@ -1013,6 +1014,7 @@ int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, cons
         J.B2 = nullptr; J.count = count; J.cap_tiles = cap_tiles; J.nrep = nrep;
         J.slabs = slabs + (size_t)l * nslab * SLAB_FLOATS; J.nslab = nslab;
         ReduceJob& Q = rj.j[rj.n++];
+        memset(&Q, 0, sizeof(Q));
         Q.slabs = J.slabs; Q.nslab = nslab; Q.MTA = J.a_regs / 16; Q.KTB = J.b_regs / 16; Q.gW = gW[l]; Q.gb = gb[l];
         Q.out = l < 5 ? 128 : 6; Q.in = l == 0 ? 28 : 128; Q.row_kind = RK_NATURAL; Q.slot_kind = l == 0 ? SK_VEL_IN : SK_HIDDEN; Q.scale = scale;
     }
