@@ -104,6 +104,7 @@ class Step:
         self.L1w, self.tvd, self.tva, self.vw = 8e-4, 1.0, 1.0, 1.0
         self.counters = []
         self.pde_counters = []
+        self.fused_regs = True
 
     def rays(self):
         from nvfi_amd.models import Ray
@@ -133,7 +134,8 @@ class Step:
         loss = loss + torch.nn.functional.mse_loss(out[0], target)
         self.counters.append(f.last_counters)
         self.L1w *= self.lr_factor; self.tvd *= self.lr_factor; self.tva *= self.lr_factor
-        loss = loss + self.L1w * f.density_L1() + self.tvd * f.TV_loss_density(self.tv) + self.tva * f.TV_loss_app(self.tv)
+        if not self.fused_regs:
+            loss = loss + self.L1w * f.density_L1() + self.tvd * f.TV_loss_density(self.tv) + self.tva * f.TV_loss_app(self.tv)
         if self.workload == "cfg3":
             self.vw *= self.lr_factor
             lv = m.get_vel_loss(self.n_pts)
@@ -142,6 +144,8 @@ class Step:
             if not isinstance(lv, float):
                 loss = loss + (self.vw * w) * lv
         loss.backward()
+        if self.fused_regs:   # same regularisers + their gradients, fused into one pass per plane (nvfi_plane_regs)
+            self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
         self.bucket.all_reduce_mean()
         self.opt.step()
         for g in self.opt.param_groups:

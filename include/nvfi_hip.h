@@ -109,6 +109,13 @@ int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float* points, c
                      void* workspace, int64_t workspace_bytes, int64_t* counters,
                      uint8_t* kept_out, float* jac_out, int64_t n_jac, void* stream);
 
+/* ---- per-iteration plane regularisers (next-row f-1): density_L1, TV_loss_density, TV_loss_app
+ *      (models/tensorf_keyframe.py:188-231, utils/tensorf_utils.py:139-158) in one pass.  out3 (device float[3]) receives the
+ *      UN-weighted values (L1, TV density, TV app) exactly as the reference functions return them; when grads is non-NULL the
+ *      gradient of  w_l1*L1 + w_tv_density*TVd + w_tv_app*TVa  is accumulated into grads->dps/dpt/aps. */
+int nvfi_plane_regs(const nvfi_field_desc* f, float w_l1, float w_tv_density, float w_tv_app, float* out3,
+                    const nvfi_grads* grads, void* stream);
+
 /* ---- building blocks used by train_segm-style callers and by the parity tests */
 /* VelBasis.forward (velocity_field.py:69-75): xt (N,4) -> u (N,6)=(v,a); gated!=0: VelocityAABB[Sur].forward -> (N,3) in u (stride 6) */
 int nvfi_vel_eval(const nvfi_field_desc* f, int64_t N, const float* xt, float* u6, int gated,

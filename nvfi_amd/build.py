@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["engine.hip", "vel.hip", "render.hip", "pde.hip", "abi.hip"]
+SOURCES = ["engine.hip", "vel.hip", "render.hip", "pde.hip", "regs.hip", "abi.hip"]
 HEADERS = ["engine.h", "common.h", "vel.h", "render.h", "pde.h", os.path.join("..", "..", "include", "nvfi_hip.h")]
 SO = os.path.join(CSRC, "libnvfi_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]

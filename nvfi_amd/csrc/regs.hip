@@ -1,0 +1,77 @@
+// regs.hip - per-iteration plane regularisers: density_L1 + TV_loss_density + TV_loss_app
+// in ONE memory-bound pass per plane that also accumulates the weighted gradients.
+//
+// Reference semantics: TensorVMKeyframeTimeKplane.density_L1 / TV_loss_density / TV_loss_app
+// (models/tensorf_keyframe.py:188-231) with utils.tensorf_utils.TVLoss (utils/tensorf_utils.py:139-158; t=True
+// multiplies the time-axis term by 3).  Planes are channel-last [H][W][C]: the x neighbour is +-C floats away,
+// the y neighbour +-W*C, so every load is coalesced across the channel/x index.
+#include "common.h"
+
+struct RegJob {
+    const float* p; float* g;
+    int H, W, C;
+    int l1_mode;        // 0 none, 1 mean|v|, 2 mean|1-v|
+    float l1_val;       // 1/n            (loss contribution scale)
+    float l1_grad;      // w_l1/n         (gradient scale)
+    float h_val, w_val; // TV value scales: 2*1e-2*hmul/count_h , 2*1e-2/count_w
+    float tv_w;         // TV weight (gradient scale multiplies the value scales)
+    int tv_slot;        // 1: TV density, 2: TV app, 0: no TV
+};
+struct RegJobs { RegJob j[12]; int n; float* out; };
+
+__global__ __launch_bounds__(256) void k_plane_regs(RegJobs jobs) {
+    __shared__ float red[2][4];
+    const RegJob& J = jobs.j[blockIdx.y];
+    const int64_t total = (int64_t)J.H * J.W * J.C;
+    const int64_t rowf = (int64_t)J.W * J.C;
+    float l1 = 0.f, tv = 0.f;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t y = idx / rowf;
+        const int x = (int)((idx - y * rowf) / J.C);
+        const float v = J.p[idx];
+        float g = 0.f;
+        if (J.l1_mode == 1) { l1 += fabsf(v); g += J.l1_grad * (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)); }
+        else if (J.l1_mode == 2) { const float u = 1.f - v; l1 += fabsf(u); g -= J.l1_grad * (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)); }
+        if (J.tv_slot) {
+            float gh = 0.f, gw = 0.f;
+            if (y + 1 < J.H) { const float d = J.p[idx + rowf] - v; tv += J.h_val * d * d; gh -= d; }
+            if (y > 0) gh += v - J.p[idx - rowf];
+            if (x + 1 < J.W) { const float d = J.p[idx + J.C] - v; tv += J.w_val * d * d; gw -= d; }
+            if (x > 0) gw += v - J.p[idx - J.C];
+            g += J.tv_w * 2.f * (J.h_val * gh + J.w_val * gw);
+        }
+        if (J.g) J.g[idx] += g;
+    }
+    l1 = wave_sum(l1); tv = wave_sum(tv);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = l1; red[1][threadIdx.x >> 6] = tv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (J.l1_mode) atomicAdd(jobs.out + 0, J.l1_val * (red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        if (J.tv_slot) atomicAdd(jobs.out + J.tv_slot, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+extern "C" int nvfi_plane_regs(const nvfi_field_desc* f, float w_l1, float w_tv_density, float w_tv_app, float* out3,
+                               const nvfi_grads* grads, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    RegJobs jobs; jobs.n = 0; jobs.out = out3;
+    HIPCK(hipMemsetAsync(out3, 0, 3 * sizeof(float), st));
+    const int A[3] = {0, 0, 1}, Bx[3] = {1, 2, 2}, Cc[3] = {2, 1, 0};
+    auto add = [&](const float* p, float* g, int H, int W, int C, int l1_mode, int tv_slot, float hmul, float tvw) {
+        RegJob& J = jobs.j[jobs.n++];
+        J.p = p; J.g = g; J.H = H; J.W = W; J.C = C; J.l1_mode = l1_mode; J.tv_slot = tv_slot; J.tv_w = tvw;
+        const double n = (double)H * W * C;
+        J.l1_val = (float)(1.0 / n); J.l1_grad = (float)(w_l1 / n);
+        const double ch = (double)C * (H - 1) * W, cw = (double)C * H * (W - 1);
+        J.h_val = H > 1 ? (float)(2.0 * 1e-2 * hmul / ch) : 0.f;
+        J.w_val = W > 1 ? (float)(2.0 * 1e-2 / cw) : 0.f;
+    };
+    for (int i = 0; i < 3; ++i) {
+        add(f->dps[i], grads ? grads->dps[i] : nullptr, f->G[Bx[i]], f->G[A[i]], f->Cd, 1, 1, 1.f, w_tv_density);
+        add(f->dpt[i], grads ? grads->dpt[i] : nullptr, f->K, f->G[Cc[i]], f->Cd, 2, f->K > 1 ? 1 : 0, 3.f, w_tv_density);
+        add(f->aps[i], grads ? grads->aps[i] : nullptr, f->G[Bx[i]], f->G[A[i]], f->Ca, 0, 2, 1.f, w_tv_app);
+    }
+    hipLaunchKernelGGL(k_plane_regs, dim3(1024, jobs.n), dim3(256), 0, st, jobs);
+    LAUNCHCK();
+    return 0;
+}

@@ -443,6 +443,28 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             total = total + reg(self.app_plane_space[i]) * 1e-2
         return total
 
+    @torch.no_grad()
+    def regularizers_backward_(self, w_l1, w_tv_density, w_tv_app):
+        """Fused form of `loss += w_l1*density_L1() + w_tv_density*TV_loss_density(reg) + w_tv_app*TV_loss_app(reg)`
+        followed by backward: one pass per plane that ACCUMULATES the weighted gradients into p.grad and returns the
+        three un-weighted loss values (device tensor [L1, TVd, TVa]).  Call it next to loss.backward()."""
+        L = _lib.lib()
+        ps = self._render_params()
+        grads = []
+        for p in ps[:9]:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
+        for g, p in zip(grads, ps[:9]):
+            if g.stride() != p.stride():
+                raise _lib.NvfiError("plane .grad must share the channels_last layout of its parameter")
+        G = self._grads_struct(grads + [None] * 22)
+        out = torch.empty(3, device=ps[0].device)
+        desc = self._desc()
+        _lib.check(L.nvfi_plane_regs(C.byref(desc), C.c_float(w_l1), C.c_float(w_tv_density), C.c_float(w_tv_app), _lib.ptr(out),
+                                     C.byref(G), _stream_ptr()))
+        return out
+
     # ------------------------------------------------------------------ optimiser / checkpoint surface
     def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
         """tensorf_keyframe.py:539-550"""

@@ -219,3 +219,29 @@ def test_pde_loss(gold, models, kind):
             assert e < 1e-3, (k, e)
             n += 1
     assert n >= 8
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_plane_regularisers(gold, models, kind):
+    """fused nvfi_plane_regs vs the golden values and vs torch autograd of the mirrored reference formulas"""
+    from nvfi_amd.utils import TVLoss
+    model, meta = models[kind]
+    f = model.nvfi
+    model.zero_grad(set_to_none=True)
+    tv = TVLoss()
+    w = (8e-4, 0.7, 1.3)
+    loss = w[0] * f.density_L1() + w[1] * f.TV_loss_density(tv) + w[2] * f.TV_loss_app(tv)
+    loss.backward()
+    ref = {k: v.copy() for k, v in named_grads(model).items() if v is not None}
+    model.zero_grad(set_to_none=True)
+    out = f.regularizers_backward_(*w).cpu().numpy()
+    np.testing.assert_allclose(out[0], gold[f"{kind}:regs:L1"][0], rtol=1e-5)
+    np.testing.assert_allclose(out[1], gold[f"{kind}:regs:TVd"][0], rtol=1e-4)
+    np.testing.assert_allclose(out[2], gold[f"{kind}:regs:TVa"][0], rtol=1e-4)
+    g = named_grads(model)
+    n = 0
+    for k, r in ref.items():
+        if "plane" in k:
+            assert relerr(g[k], r) < 1e-5, k
+            n += 1
+    assert n == 9
