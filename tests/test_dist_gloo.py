@@ -1,0 +1,85 @@
+"""N>1 path on CPU (gloo, world_size 2): ray shards + ONE flat-gradient all-reduce reproduce the single-process
+gradient of the global batch.  The per-rank compute stands in for the GPU kernels with the CPU oracle (tests may use it)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLD, ROOT
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from nvfi_amd.dist import GradBucket, pde_rank_weight, shard_range
+    orc.set_threads(2)
+    gold = np.load(os.path.join(GOLD, "hotpath.npz"))
+    fs = orc.FieldSpec.from_npz(os.path.join(GOLD, "field_A.npz"))
+    o, d = gold["A:rays_o"], gold["A:rays_d"]
+    u, tgt = gold["A:train_nonkey:u"], gold["A:train_nonkey:target"]
+    R = o.shape[0]
+    lo, hi = shard_range(R, rank, world)
+    # parameters as torch tensors, two of them channels_last like the product's planes
+    names = ["density_plane_space.0", "app_plane_time.1", "vel_net.weight_net.3.0.weight", "renderModule.mlp.0.bias"]
+    params = []
+    for n in names:
+        t = torch.from_numpy(fs.p[n].copy())
+        if t.dim() == 4:
+            t = t.contiguous(memory_format=torch.channels_last)
+        params.append(torch.nn.Parameter(t))
+    bucket = GradBucket(params)
+    assert all(p.grad.stride() == p.stride() for p in params)
+    bucket.zero()
+    # local shard: mean over the shard's rays (equal shards -> mean of means == global mean)
+    r = orc.render(fs, o[lo:hi], d[lo:hi], 19.0 / 60.0, u=u[lo:hi], train=True, white_bg=True, keep_ctx=True)
+    n = hi - lo
+    g = r.backward(fs, g_rgb=2 * (r.rgb - tgt[lo:hi]) / (n * 3))
+    r.free()
+    # PDE shard with the kept-count re-weighting
+    P = gold["A:pde:points"].shape[0]
+    plo, phi = shard_range(P, rank, world)
+    pde = orc.pde_loss(fs, gold["A:pde:points"][plo:phi], gold["A:pde:t"][plo:phi])
+    w = pde_rank_weight(pde["n_kept"])
+    with torch.no_grad():
+        for p, nm in zip(params, names):
+            p.grad += torch.from_numpy(g[nm] + w * pde["grads"][nm])
+    bucket.all_reduce_mean()
+    if rank == 0:
+        np.savez(out, **{nm: p.grad.detach().contiguous().numpy() for nm, p in zip(names, params)}, w=w, nk=pde["n_kept"])
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_match_single_process(tmp_path):
+    from oracle import oracle as orc
+    out = str(tmp_path / "g.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    gold = np.load(os.path.join(GOLD, "hotpath.npz"))
+    fs = orc.FieldSpec.from_npz(os.path.join(GOLD, "field_A.npz"))
+    o, d = gold["A:rays_o"], gold["A:rays_d"]
+    u, tgt = gold["A:train_nonkey:u"], gold["A:train_nonkey:target"]
+    R = o.shape[0]
+    r = orc.render(fs, o, d, 19.0 / 60.0, u=u, train=True, white_bg=True, keep_ctx=True)
+    g = r.backward(fs, g_rgb=2 * (r.rgb - tgt) / (R * 3))
+    r.free()
+    pde = orc.pde_loss(fs, gold["A:pde:points"], gold["A:pde:t"])
+    for nm in ["density_plane_space.0", "app_plane_time.1", "vel_net.weight_net.3.0.weight", "renderModule.mlp.0.bias"]:
+        ref = g[nm] + pde["grads"][nm]
+        err = np.abs(got[nm] - ref).max() / (np.abs(ref).max() + 1e-30)
+        assert err < 2e-5, (nm, err)
+    assert 0.5 < float(got["w"]) < 1.5
+
+
+def test_shard_range_covers_everything():
+    from nvfi_amd.dist import shard_range
+    for n in (0, 1, 7, 2048, 262145):
+        for w in (1, 2, 3, 8):
+            pieces = [shard_range(n, r, w) for r in range(w)]
+            assert pieces[0][0] == 0 and pieces[-1][1] == n
+            assert all(pieces[i][1] == pieces[i + 1][0] for i in range(w - 1))
