@@ -33,98 +33,100 @@ __global__ void k_pack(PackJobs jobs) {
 // MFMA step st pairs sample 16h+st of both operands.  Each wave is an independent worker that owns MT
 // row tiles x KT column tiles of G for a strided subset of the sample tiles and writes its own slab part;
 // k_wgrad_reduce sums the slabs and un-permutes into the logical gradient tensors.
-template <int MT, int KT>
+template <int MT, int KTW>   // MT: all row tiles of A; KTW: column tiles of B owned by one worker
 __device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int lane) {
     const int i = lane & 31, h = lane >> 5;
-    const int MTA = J.a_regs >> 4;
-    const int nhalves = MTA / MT;
-    const int mhalf = worker % nhalves, wslot = worker / nhalves;
+    const int KTB = J.b_regs >> 4;
+    const int nparts = KTB / KTW;                 // workers per slab: each owns KTW column tiles (B is transformed once, not per row half)
+    const int kpart = worker % nparts, wslot = worker / nparts;
     if (wslot >= J.nslab) return;
     const int a_rows = 2 * J.a_regs, b_rows = 2 * J.b_regs;
     int count = *J.count;
     int ntiles = (count + TILE - 1) / TILE;
     if (ntiles > J.cap_tiles) ntiles = J.cap_tiles;
     const int nitems = J.nrep * ntiles;
-    f32x16 acc[MT][KT];
+    f32x16 acc[MT][KTW];
     float bsum[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         bsum[mt] = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][kt][r] = 0.f;
     }
     // float offset of (row p, sample 16h) inside a tile image: p = 2*reg + hh -> reg*64 + hh*32
-    int aoff[MT], boff[KT];
+    int aoff[MT], boff[KTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { const int p = 32 * (mhalf * MT + mt) + i; aoff[mt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
+    for (int mt = 0; mt < MT; ++mt) { const int p = 32 * mt + i; aoff[mt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) { const int p = 32 * kt + i; boff[kt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
+    for (int kt = 0; kt < KTW; ++kt) { const int p = 32 * (kpart * KTW + kt) + i; boff[kt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
     for (int item = wslot; item < nitems; item += J.nslab) {
         const int rep = item / ntiles, tile = item - rep * ntiles;
         const float* At = J.A + (size_t)rep * J.a_rep_stride + (size_t)tile * J.a_tile_stride;
         const float* Bt = J.B + (size_t)rep * J.b_rep_stride + (size_t)tile * J.b_tile_stride;
         const float* B2t = J.B2 ? J.B2 + (size_t)rep * J.b2_rep_stride + (size_t)tile * J.b_tile_stride : nullptr;
-        float a[MT][16];
+        float b[KTW][16];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int kt = 0; kt < KTW; ++kt) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float4 t4 = *reinterpret_cast<const float4*>(At + aoff[mt] + 4 * v);
-                a[mt][4 * v] = t4.x; a[mt][4 * v + 1] = t4.y; a[mt][4 * v + 2] = t4.z; a[mt][4 * v + 3] = t4.w;
+                const float4 t4 = *reinterpret_cast<const float4*>(Bt + boff[kt] + 4 * v);
+                float z[4] = {t4.x, t4.y, t4.z, t4.w};
+                if (J.bmode == BM_SILU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) z[c] = act_f<1>(z[c]);
+                } else if (J.bmode == BM_RELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) z[c] = act_f<0>(z[c]);
+                } else if (J.bmode == BM_SILU_TAN || J.bmode == BM_RELU_TAN) {
+                    const float4 u4 = *reinterpret_cast<const float4*>(B2t + boff[kt] + 4 * v);
+                    const float z2[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) z[c] = (J.bmode == BM_SILU_TAN ? act_d1<1>(z[c]) : act_d1<0>(z[c])) * z2[c];
+                }
+                b[kt][4 * v] = z[0]; b[kt][4 * v + 1] = z[1]; b[kt][4 * v + 2] = z[2]; b[kt][4 * v + 3] = z[3];
             }
-#pragma unroll
-            for (int v = 0; v < 16; ++v) bsum[mt] += a[mt][v];
         }
-        // B operand in groups of two column tiles (keeps the live set under 256 VGPRs at 2 waves/SIMD)
-        constexpr int KG = KT >= 2 ? 2 : 1;
+        // A operand in groups of two row tiles (keeps the live set under 256 VGPRs at 2 waves/SIMD)
+        constexpr int MG = MT >= 2 ? 2 : 1;
 #pragma unroll
-        for (int k0 = 0; k0 < KT; k0 += KG) {
-            float b[KG][16];
+        for (int m0 = 0; m0 < MT; m0 += MG) {
+            float a[MG][16];
 #pragma unroll
-            for (int kk = 0; kk < KG; ++kk) {
-                const int kt = k0 + kk;
+            for (int mm = 0; mm < MG; ++mm) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(Bt + boff[kt] + 4 * v);
-                    float z[4] = {t4.x, t4.y, t4.z, t4.w};
-                    if (J.bmode == BM_SILU) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(At + aoff[m0 + mm] + 4 * v);
+                    a[mm][4 * v] = t4.x; a[mm][4 * v + 1] = t4.y; a[mm][4 * v + 2] = t4.z; a[mm][4 * v + 3] = t4.w;
+                }
+                if (kpart == 0) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) z[c] = act_f<1>(z[c]);
-                    } else if (J.bmode == BM_RELU) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) z[c] = act_f<0>(z[c]);
-                    } else if (J.bmode == BM_SILU_TAN || J.bmode == BM_RELU_TAN) {
-                        const float4 u4 = *reinterpret_cast<const float4*>(B2t + boff[kt] + 4 * v);
-                        const float z2[4] = {u4.x, u4.y, u4.z, u4.w};
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) z[c] = (J.bmode == BM_SILU_TAN ? act_d1<1>(z[c]) : act_d1<0>(z[c])) * z2[c];
-                    }
-                    b[kk][4 * v] = z[0]; b[kk][4 * v + 1] = z[1]; b[kk][4 * v + 2] = z[2]; b[kk][4 * v + 3] = z[3];
+                    for (int v = 0; v < 16; ++v) bsum[m0 + mm] += a[mm][v];
                 }
             }
 #pragma unroll
             for (int st = 0; st < 16; ++st)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mm = 0; mm < MG; ++mm)
 #pragma unroll
-                    for (int kk = 0; kk < KG; ++kk) acc[mt][k0 + kk] = MFMA32(a[mt][st], b[kk][st], acc[mt][k0 + kk]);
+                    for (int kt = 0; kt < KTW; ++kt) acc[m0 + mm][kt] = MFMA32(a[mm][st], b[kt][st], acc[m0 + mm][kt]);
         }
     }
     float* S = J.slabs + (size_t)wslot * ((size_t)a_rows * b_rows + a_rows);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = mhalf * MT + mt;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
-                S[(size_t)row * b_rows + 32 * kt + i] = acc[mt][kt][r];
+                const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                S[(size_t)row * b_rows + 32 * (kpart * KTW + kt) + i] = acc[mt][kt][r];
             }
-        float bs = bsum[mt] + __shfl_xor(bsum[mt], 32);
-        if (h == 0) S[(size_t)a_rows * b_rows + 32 * m + i] = bs;
+        if (kpart == 0) {
+            float bs = bsum[mt] + __shfl_xor(bsum[mt], 32);
+            if (h == 0) S[(size_t)a_rows * b_rows + 32 * mt + i] = bs;
+        }
     }
 }
 
@@ -132,9 +134,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgradJobs jobs) {
     const WgradJob& J = jobs.j[blockIdx.y];
     const int worker = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (J.a_regs == 64 && J.b_regs == 64) wgrad_worker<2, 4>(J, worker, lane);
-    else if (J.a_regs == 16 && J.b_regs == 64) wgrad_worker<1, 4>(J, worker, lane);
-    else if (J.a_regs == 64 && J.b_regs == 16) wgrad_worker<2, 1>(J, worker, lane);
+    if (J.a_regs == 64 && J.b_regs == 64) wgrad_worker<4, 2>(J, worker, lane);        // 2 workers per slab
+    else if (J.a_regs == 16 && J.b_regs == 64) wgrad_worker<1, 2>(J, worker, lane);   // 2 workers per slab
+    else if (J.a_regs == 64 && J.b_regs == 16) wgrad_worker<4, 1>(J, worker, lane);
     else if (J.a_regs == 16 && J.b_regs == 32) wgrad_worker<1, 2>(J, worker, lane);
 }
 
@@ -190,7 +192,7 @@ int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st) {
         const WgradJob& J = wj.j[i];
         const bool ok = (J.a_regs == 64 && J.b_regs == 64) || (J.a_regs == 16 && J.b_regs == 64) || (J.a_regs == 64 && J.b_regs == 16) || (J.a_regs == 16 && J.b_regs == 32);
         if (!ok) return nvfi_fail(5, "k_wgrad: unsupported tile shape a_regs=%d b_regs=%d", J.a_regs, J.b_regs);
-        const int w = J.nslab * (J.a_regs == 64 ? 2 : 1);
+        const int w = J.nslab * (J.b_regs == 64 ? 2 : 1);
         nworkers = w > nworkers ? w : nworkers;
     }
     ProfScope ps(PK_WGRAD, st);

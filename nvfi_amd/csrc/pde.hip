@@ -170,9 +170,11 @@ __device__ __forceinline__ void velnet_tangent_backward(const VelFrags& W, float
             for (int r = 0; r < 16; ++r) {
                 const int s = 16 * m + r;
                 const float z = zl[s * REGF + lane];
-                const float c = act_d2<ACT>(z) * zdl[s * REGF + lane] * acc[m][r];
+                float d1, d2;
+                act_d12<ACT>(z, d1, d2);
+                const float c = d2 * zdl[s * REGF + lane] * acc[m][r];
                 cl[s * REGF + lane] = first ? c : cl[s * REGF + lane] + c;
-                g[s] = act_d1<ACT>(z) * acc[m][r];
+                g[s] = d1 * acc[m][r];
             }
         stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
         if (l >= 1) {
