@@ -144,6 +144,41 @@ __device__ __forceinline__ void layer_mfma(const float* lds_w, int lane, const f
     }
 }
 
+// Tile-major layer: the MT output tiles are produced one after the other (64 back-to-back MFMAs on one accumulator:
+// the 32x32x2 f32 MFMA's dependent latency equals its issue interval), and `epi(m, acc)` - activation, stash stores,
+// derivative loads - of a finished tile is independent work the scheduler overlaps with the next tile's MFMAs.
+// Only 16 accumulator registers are live, which pays for a second activation array (ping-pong x -> xn).
+template <int MT, int NS, class Epi>
+__device__ __forceinline__ void layer_tiles(const float* lds_w, const float* lds_b, bool bias, int lane, int h, const float* x, Epi epi) {
+    f32x16 prev;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias ? lds_b[32 * m + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+        // region: MFMAs of tile m  +  epilogue of tile m-1 (independent: the scheduler interleaves them);
+        // the sched_barrier keeps the epilogue loads/temporaries of later tiles from being hoisted (register pressure)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            acc = MFMA32(lds_w[(m * NS + s) * 64 + lane], x[s], acc);
+        }
+        if (m > 0) {
+            epi(m - 1, prev);
+            // ask for the interleave explicitly: per MFMA one LDS operand read and a few of the epilogue's VALU / store ops
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (next A operand)
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU (epilogue of the previous tile)
+                if ((s & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x030, 1, 0);   // one VMEM op (stash store / z load)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        prev = acc;
+    }
+    epi(MT - 1, prev);
+}
+
 // store / load a block of NR stash registers (one 256-B row per register)
 template <int NR>
 __device__ __forceinline__ void stash_store(float* base, int lane, const float* v) {
@@ -202,40 +237,51 @@ template <int ACT>
 __device__ __forceinline__ void velnet_forward(const VelFrags& W, float* lds_w, float* lds_b, int lane,
                                                const float4& q, float* zst, float* x0st, float* out4) {
     const int h = lane >> 5;
-    float x[64];
-    f32x16 acc[4];
-    vel_encode_slots(q, h, x);
-    if (x0st) stash_store<16>(x0st, lane, x);
+    float xa[64], xb[64];
+    vel_encode_slots(q, h, xb);
+    if (x0st) stash_store<16>(x0st, lane, xb);
     __syncthreads();
     stage_frag(lds_w, lds_b, W.f[0], VEL_F0, W.b[0], 128);
     __syncthreads();
-    acc_init<4>(acc, lds_b, h, true);
-    layer_mfma<4, 14>(lds_w, lane, x, acc);
+    layer_tiles<4, 14>(lds_w, lds_b, true, lane, h, xb, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (zst) zst[(16 * m + r) * REGF + lane] = acc[r];
+            xa[16 * m + r] = act_f<ACT>(acc[r]);
+        }
+    });
 #pragma unroll 1
-    for (int l = 1; l <= 4; ++l) {
-        if (zst) stash_store_acc<4>(zst + (size_t)(l - 1) * 64 * REGF, lane, acc);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[16 * m + r] = act_f<ACT>(acc[m][r]);
+    for (int it = 0; it < 2; ++it) {
+        const int l = 1 + 2 * it;
+        float* z1 = zst ? zst + (size_t)l * 64 * REGF : nullptr;
+        float* z2 = zst ? zst + (size_t)(l + 1) * 64 * REGF : nullptr;
         __syncthreads();
         stage_frag(lds_w, lds_b, W.f[l], VEL_FH, W.b[l], 128);
         __syncthreads();
-        acc_init<4>(acc, lds_b, h, true);
-        layer_mfma<4, 64>(lds_w, lane, x, acc);
+        layer_tiles<4, 64>(lds_w, lds_b, true, lane, h, xa, [&](int m, const f32x16& acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (z1) z1[(16 * m + r) * REGF + lane] = acc[r];
+                xb[16 * m + r] = act_f<ACT>(acc[r]);
+            }
+        });
+        __syncthreads();
+        stage_frag(lds_w, lds_b, W.f[l + 1], VEL_FH, W.b[l + 1], 128);
+        __syncthreads();
+        layer_tiles<4, 64>(lds_w, lds_b, true, lane, h, xb, [&](int m, const f32x16& acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (z2) z2[(16 * m + r) * REGF + lane] = acc[r];
+                xa[16 * m + r] = act_f<ACT>(acc[r]);
+            }
+        });
     }
-    if (zst) stash_store_acc<4>(zst + (size_t)4 * 64 * REGF, lane, acc);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[16 * m + r] = act_f<ACT>(acc[m][r]);
     __syncthreads();
     stage_frag(lds_w, lds_b, W.f[5], VEL_F5, W.b[5], 32);
     __syncthreads();
-    f32x16 o[1];
-    acc_init<1>(o, lds_b, h, true);
-    layer_mfma<1, 64>(lds_w, lane, x, o);
-    out4[0] = o[0][0]; out4[1] = o[0][1]; out4[2] = o[0][2]; out4[3] = o[0][3];
+    layer_tiles<1, 64>(lds_w, lds_b, true, lane, h, xa, [&](int, const f32x16& acc) {
+        out4[0] = acc[0]; out4[1] = acc[1]; out4[2] = acc[2]; out4[3] = acc[3];
+    });
 }
 
 // both halves get the full 6-vector
@@ -265,6 +311,8 @@ __device__ __forceinline__ void acc_from_w(const float* aw, float x, float y, fl
 // Backward (dgrad) of one evaluation.  gw4: adjoint of the 6 outputs in D-layout regs 0..3 of this lane.
 // zst: z stash of the forward; gst: adjoint stash to fill (5*64 rows gz + 16 rows gw) for k_wgrad, or NULL.
 // Returns ge (16 regs, input-slot layout) in ge[].
+// (step-major accumulation: 4 live accumulator tiles, one 64-register adjoint array - the tile-major ping-pong form
+// of the forward pass spills here because the RK2 adjoint keeps more state live around the MLP pass)
 template <int ACT>
 __device__ __forceinline__ void velnet_backward(const VelFrags& W, float* lds_w, float* lds_b, int lane,
                                                 const float* gw4, const float* zst, float* gst, float* ge) {

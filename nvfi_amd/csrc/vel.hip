@@ -129,59 +129,49 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_bwd(Rk2Args a) {
     for (int s = a.nsteps - 1; s >= 0; --s) {
         const float dt = a.dt[s], tcur = a.tcur[s];
         const float* rc = a.rec + (size_t)s * RK_NF * a.cap + (active ? i : 0);
-        float x[3], pm[3], w1[6], w2[6];
-        int flags = 7;
-        if (active) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { x[c] = rc[c * a.cap]; pm[c] = rc[(3 + c) * a.cap]; }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { w1[k] = rc[(6 + k) * a.cap]; w2[k] = rc[(12 + k) * a.cap]; }
-            flags = __float_as_int(rc[18 * a.cap]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { x[c] = 0.f; pm[c] = 0.f; }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { w1[k] = 0.f; w2[k] = 0.f; }
-        }
+        const int flags = active ? __float_as_int(rc[18 * a.cap]) : 7;
         const bool g1 = flags & 1, g2 = flags & 2, rej = flags & 4;
-        size_t e1 = ((size_t)(2 * s) * a.cap_tiles + tile), e2 = ((size_t)(2 * s + 1) * a.cap_tiles + tile);
-        // ---- second evaluation: v2 = vel(pmid, tmid); x_new = x - dt*v2
-        float gv[3], gw[6], r4[4], ge[16], x0[16];
-        const bool on2 = active && !rej && !g2;
+        const size_t e1 = ((size_t)(2 * s) * a.cap_tiles + tile), e2 = ((size_t)(2 * s + 1) * a.cap_tiles + tile);
+        // The two network evaluations of the step are walked in reverse by ONE loop body (e = 1: v2 = vel(pmid, tmid),
+        // x_new = x - dt*v2;  e = 0: v1 = vel(x, t), pmid = x - dt/2*v1); records are re-read around the MLP pass
+        // instead of being kept live - the two 64-register adjoint arrays need the room.
+        float gacc[3] = {0.f, 0.f, 0.f};        // gpm after e=1, then + gx1
+        float gup[3] = {g3[0], g3[1], g3[2]};   // upstream of the evaluation being processed
+#pragma unroll 1
+        for (int e = 1; e >= 0; --e) {
+            const int po = e ? 3 : 0, wo = e ? 12 : 6;
+            const float coef = e ? -dt : -0.5f * dt;
+            const float te = e ? tcur - 0.5f * dt : tcur;
+            const bool gate = e ? g2 : g1;
+            const size_t es = ((size_t)(2 * s + e) * a.cap_tiles + tile);
+            float p[3], w[6], gv[3], gw[6], r4[4], gloc[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gv[c] = on2 ? -dt * g3[c] : 0.f;
-        gw[0] = gv[0]; gw[1] = gv[1]; gw[2] = gv[2];
-        gw[3] = pm[2] * gv[1] - pm[1] * gv[2];
-        gw[4] = -pm[2] * gv[0] + pm[0] * gv[2];
-        gw[5] = pm[1] * gv[0] - pm[0] * gv[1];
-        float gpm[3];
-        gpm[0] = -w2[5] * gv[1] + w2[4] * gv[2];
-        gpm[1] = w2[5] * gv[0] - w2[3] * gv[2];
-        gpm[2] = -w2[4] * gv[0] + w2[3] * gv[1];
-        scatter6(gw, h, r4);
-        velnet_backward<1>(a.Wv, lds_w, lds_b, lane, r4, a.zst + e2 * (VEL_Z_REGS * REGF),
-                           a.gst + e2 * (VEL_G_REGS * REGF), ge);
-        vel_encode_slots(make_float4(pm[0], pm[1], pm[2], tcur - 0.5f * dt), h, x0);
-        float4 gq = vel_encode_bwd(ge, x0, h);
-        gpm[0] += gq.x; gpm[1] += gq.y; gpm[2] += gq.z;
-        // ---- first evaluation: v1 = vel(x, t); pmid = x - 0.5*dt*v1
-        const bool on1 = active && !rej && !g1;
+            for (int c = 0; c < 3; ++c) p[c] = active ? rc[(po + c) * a.cap] : 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gv[c] = on1 ? -0.5f * dt * gpm[c] : 0.f;
-        gw[0] = gv[0]; gw[1] = gv[1]; gw[2] = gv[2];
-        gw[3] = x[2] * gv[1] - x[1] * gv[2];
-        gw[4] = -x[2] * gv[0] + x[0] * gv[2];
-        gw[5] = x[1] * gv[0] - x[0] * gv[1];
-        float gx1[3];
-        gx1[0] = -w1[5] * gv[1] + w1[4] * gv[2];
-        gx1[1] = w1[5] * gv[0] - w1[3] * gv[2];
-        gx1[2] = -w1[4] * gv[0] + w1[3] * gv[1];
-        scatter6(gw, h, r4);
-        velnet_backward<1>(a.Wv, lds_w, lds_b, lane, r4, a.zst + e1 * (VEL_Z_REGS * REGF),
-                           a.gst + e1 * (VEL_G_REGS * REGF), ge);
-        vel_encode_slots(make_float4(x[0], x[1], x[2], tcur), h, x0);
-        gq = vel_encode_bwd(ge, x0, h);
-        gx1[0] += gq.x; gx1[1] += gq.y; gx1[2] += gq.z;
+            for (int k = 0; k < 6; ++k) w[k] = active ? rc[(wo + k) * a.cap] : 0.f;
+            const bool on = active && !rej && !gate;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gv[c] = on ? coef * gup[c] : 0.f;
+            gw[0] = gv[0]; gw[1] = gv[1]; gw[2] = gv[2];
+            gw[3] = p[2] * gv[1] - p[1] * gv[2];
+            gw[4] = -p[2] * gv[0] + p[0] * gv[2];
+            gw[5] = p[1] * gv[0] - p[0] * gv[1];
+            gloc[0] = -w[5] * gv[1] + w[4] * gv[2];
+            gloc[1] = w[5] * gv[0] - w[3] * gv[2];
+            gloc[2] = -w[4] * gv[0] + w[3] * gv[1];
+            scatter6(gw, h, r4);
+            float ge[16];
+            velnet_backward<1>(a.Wv, lds_w, lds_b, lane, r4, a.zst + es * (VEL_Z_REGS * REGF), a.gst + es * (VEL_G_REGS * REGF), ge);
+            float x0[16];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[c] = active ? rc[(po + c) * a.cap] : 0.f;
+            vel_encode_slots(make_float4(p[0], p[1], p[2], te), h, x0);
+            const float4 gq = vel_encode_bwd(ge, x0, h);
+            gloc[0] += gq.x; gloc[1] += gq.y; gloc[2] += gq.z;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { gacc[c] += gloc[c]; gup[c] = gloc[c]; }
+        }
+        float gpm[3] = {gacc[0], gacc[1], gacc[2]}, gx1[3] = {0.f, 0.f, 0.f};
         if (active && !rej) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) g3[c] = g3[c] + gpm[c] + gx1[c];
