@@ -105,6 +105,8 @@ class Step:
         self.counters = []
         self.pde_counters = []
         self.fused_regs = True
+        self.inplace = True
+        model.nvfi.accumulate_grads_inplace = True   # .grad tensors are views of the GradBucket's flat buffer
 
     def rays(self):
         from nvfi_amd.models import Ray
@@ -138,11 +140,19 @@ class Step:
             loss = loss + self.L1w * f.density_L1() + self.tvd * f.TV_loss_density(self.tv) + self.tva * f.TV_loss_app(self.tv)
         if self.workload == "cfg3":
             self.vw *= self.lr_factor
-            lv = m.get_vel_loss(self.n_pts)
-            self.pde_counters.append(f.last_pde_counters)
-            w = pde_rank_weight(float(f.last_pde_out[1])) if self.world > 1 else 1.0
-            if not isinstance(lv, float):
-                loss = loss + (self.vw * w) * lv
+            if self.world == 1 and self.inplace:
+                # same term, fused: d(vw * loss_vel) is accumulated into .grad by the PDE kernels
+                m.vel_loss_weight = self.vw
+                lv = m.get_vel_loss(self.n_pts)
+                self.pde_counters.append(f.last_pde_counters)
+                self.last_lv = lv
+            else:
+                m.vel_loss_weight = None
+                lv = m.get_vel_loss(self.n_pts)
+                self.pde_counters.append(f.last_pde_counters)
+                w = pde_rank_weight(float(f.last_pde_out[1])) if self.world > 1 else 1.0
+                if not isinstance(lv, float):
+                    loss = loss + (self.vw * w) * lv
         loss.backward()
         if self.fused_regs:   # same regularisers + their gradients, fused into one pass per plane (nvfi_plane_regs)
             self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)

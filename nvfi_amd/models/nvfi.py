@@ -36,6 +36,12 @@ class NVFi(nn.Module):
             mn, mx = f.aabb
             points = torch.rand(int(n_pts), 3, device=f.aabb.device) * (mx - mn) + mn
             t = torch.rand(int(n_pts), 1, device=f.aabb.device)
+        if f.accumulate_grads_inplace and torch.is_grad_enabled() and getattr(self, "vel_loss_weight", None) is not None:
+            # fused value + backward: gradients of vel_loss_weight * loss go straight into .grad
+            out = f.pde_loss_backward_(points, t, self.vel_loss_weight)
+            if float(out[1]) == 0:
+                return 0.
+            return out[0]
         loss = f.pde_loss(points, t)
         if float(f.last_pde_out[1]) == 0:   # host sync, as `xyzt.shape[0] == 0` is in the reference
             return 0.

@@ -79,7 +79,21 @@ class _RenderFn(torch.autograd.Function):
         field = ctx.field
         desc = field._desc(params)
         need = ctx.needs_input_grad[6:]
-        grads = [torch.zeros_like(p) if n else None for p, n in zip(params, need)]
+        inplace = field.accumulate_grads_inplace
+        if inplace:
+            # kernels accumulate (+=) straight into the parameters' .grad (e.g. views of one flat GradBucket buffer):
+            # no zero-fill, no AccumulateGrad add per tensor.  Autograd then sees "no gradient" for these inputs.
+            cur = field._render_params()
+            grads = []
+            for p, n in zip(cur, need):
+                if not n:
+                    grads.append(None)
+                    continue
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                grads.append(p.grad)
+        else:
+            grads = [torch.zeros_like(p) if n else None for p, n in zip(params, need)]
         G = field._grads_struct(grads)
         gs = [None if g is None else g.contiguous() for g in (g_rgb, g_depth, g_acc, g_weights)]
         R = rays_o.shape[0]
@@ -87,6 +101,8 @@ class _RenderFn(torch.autograd.Function):
                                      C.c_int(ctx.flags), _lib.ptr(weights), _lib.ptr(gs[0]), _lib.ptr(gs[1]), _lib.ptr(gs[2]),
                                      _lib.ptr(gs[3]), C.byref(G), _lib.ptr(ctx.ws), C.c_int64(ctx.ws.numel()), _stream_ptr()))
         ctx.ws = None
+        if inplace:
+            return (None,) * (6 + len(params))
         return (None, None, None, None, None, None) + tuple(grads)
 
 
@@ -173,6 +189,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         if self.contract_ray:
             raise NotImplementedError("contract_ray is out of scope")
         self.last_counters = None
+        self.accumulate_grads_inplace = False   # True: backward kernels add into p.grad directly (see nvfi_amd.dist.GradBucket)
         self.pde_debug = 0   # >0: also return the kept mask and the first n Jacobians of get_vel_loss
         self.register_load_state_dict_post_hook(lambda m, k: m.update_stepSize(m.gridSize.tolist()))
 
@@ -423,6 +440,40 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         points = points.reshape(-1, 3).contiguous().float()
         t = t.reshape(-1).contiguous().float()
         return _PdeFn.apply(self, points, t, *self._pde_params())
+
+    @torch.no_grad()
+    def pde_loss_backward_(self, points, t, weight=1.0):
+        """Fused value + backward of `weight * get_vel_loss`: the gradient is ACCUMULATED into the .grad of both velocity
+        nets; returns the device tensor [loss, n_kept, sum div^2, sum transport^2] (un-weighted loss)."""
+        L = _lib.lib()
+        points = points.reshape(-1, 3).contiguous().float()
+        t = t.reshape(-1).contiguous().float()
+        P = points.shape[0]
+        desc = self._desc()
+        nbytes = C.c_int64(0)
+        _lib.check(L.nvfi_pde_workspace_bytes(C.byref(desc), C.c_int64(P), C.byref(nbytes)))
+        ws = self._scratch("pde", nbytes.value, points.device)
+        out = torch.zeros(4, device=points.device)
+        grads = []
+        for p in self._pde_params():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
+        G = self._grads_struct_vel(grads)
+        counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=points.device)
+        _lib.check(L.nvfi_pde_loss(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(float(weight)), _lib.ptr(out),
+                                   C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
+        self.last_pde_out, self.last_pde_counters = out, counters
+        return out
+
+    def _scratch(self, key, nbytes, device):
+        """Reusable workspace for calls whose workspace does not have to outlive the call."""
+        cache = self.__dict__.setdefault("_scratch_cache", {})
+        buf = cache.get(key)
+        if buf is None or buf.numel() < nbytes or buf.device != device:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            cache[key] = buf
+        return buf
 
     # ------------------------------------------------------------------ per-iteration regularisers (next-row f-1; torch ops)
     def density_L1(self):

@@ -245,3 +245,39 @@ def test_plane_regularisers(gold, models, kind):
             assert relerr(g[k], r) < 1e-5, k
             n += 1
     assert n == 9
+
+
+def test_inplace_gradient_accumulation_matches_autograd(gold, models):
+    """accumulate_grads_inplace (kernels add into p.grad / GradBucket views) == ordinary autograd gradients"""
+    from nvfi_amd.dist import GradBucket
+    model, meta = models["A"]
+    f = model.nvfi
+
+    def run(inplace):
+        model.zero_grad(set_to_none=True)
+        f.accumulate_grads_inplace = inplace
+        bucket = GradBucket([p for g in model.get_optparam_groups() for p in g["params"]]) if inplace else None
+        torch.manual_seed(21)
+        out = _render(model, meta, gold, "A", 19.0 / 60.0, "train")
+        loss = out[0].mean() + 0.01 * out[1].mean()
+        model.vel_loss_weight = 0.5 if inplace else None
+        lv = model.get_vel_loss(points=_cuda(gold["A:pde:points"]), t=_cuda(gold["A:pde:t"]))
+        if not inplace:
+            loss = loss + 0.5 * lv
+        loss.backward()
+        g = named_grads(model)
+        f.accumulate_grads_inplace = False
+        model.vel_loss_weight = None
+        return g, float(lv)
+
+    g0, l0 = run(False)
+    g1, l1 = run(True)
+    np.testing.assert_allclose(l0, l1, rtol=1e-5)
+    n = 0
+    for k, v in g0.items():
+        if v is None or not np.any(v):
+            continue
+        assert relerr(g1[k], v) < 2e-4, k
+        n += 1
+    assert n > 30
+    model.zero_grad(set_to_none=True)
