@@ -120,6 +120,23 @@ class Step:
         m.train()
         self.bucket.zero()
         loss = 0
+        # the PDE term goes first: its one host sync (kept count) then overlaps with nothing that is already queued,
+        # and the renders + backward + Adam that follow are launched without any host wait
+        if self.workload == "cfg3":
+            self.vw *= self.lr_factor
+            if self.world == 1 and self.inplace:
+                # same term, fused: d(vw * loss_vel) is accumulated into .grad by the PDE kernels
+                m.vel_loss_weight = self.vw
+                lv = m.get_vel_loss(self.n_pts)
+                self.pde_counters.append(f.last_pde_counters)
+                self.last_lv = lv
+            else:
+                m.vel_loss_weight = None
+                lv = m.get_vel_loss(self.n_pts)
+                self.pde_counters.append(f.last_pde_counters)
+                w = pde_rank_weight(float(f.last_pde_out[1])) if self.world > 1 else 1.0
+                if not isinstance(lv, float):
+                    loss = loss + (self.vw * w) * lv
         if self.workload == "cfg3":
             i = int(self.rng.integers(0, 46))
             while i % 3 == 0:                       # frame times i/60; keyframes every 0.05 = 3/60
@@ -138,21 +155,6 @@ class Step:
         self.L1w *= self.lr_factor; self.tvd *= self.lr_factor; self.tva *= self.lr_factor
         if not self.fused_regs:
             loss = loss + self.L1w * f.density_L1() + self.tvd * f.TV_loss_density(self.tv) + self.tva * f.TV_loss_app(self.tv)
-        if self.workload == "cfg3":
-            self.vw *= self.lr_factor
-            if self.world == 1 and self.inplace:
-                # same term, fused: d(vw * loss_vel) is accumulated into .grad by the PDE kernels
-                m.vel_loss_weight = self.vw
-                lv = m.get_vel_loss(self.n_pts)
-                self.pde_counters.append(f.last_pde_counters)
-                self.last_lv = lv
-            else:
-                m.vel_loss_weight = None
-                lv = m.get_vel_loss(self.n_pts)
-                self.pde_counters.append(f.last_pde_counters)
-                w = pde_rank_weight(float(f.last_pde_out[1])) if self.world > 1 else 1.0
-                if not isinstance(lv, float):
-                    loss = loss + (self.vw * w) * lv
         loss.backward()
         if self.fused_regs:   # same regularisers + their gradients, fused into one pass per plane (nvfi_plane_regs)
             self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)

@@ -399,6 +399,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_bwd(PdeJetArgs a) {
     velnet_value_backward<1, true>(a.Wv, lds_w, lds_b, lane, r4, T + PDE_Z * REGF, T + PDE_CORR * REGF, T + PDE_GA * REGF);
 }
 
+// tiny helpers that replace host->device copies (no synchronisation on the launch stream)
+__global__ void k_set_i64x8(int64_t* c8, int* i1, int v1, int64_t c0, int64_t c1, int64_t c3, int64_t c4) {
+    if (threadIdx.x == 0) {
+        if (i1) *i1 = v1;
+        if (c8) { c8[0] = c0; c8[1] = c1; c8[2] = 0; c8[3] = c3; c8[4] = c4; c8[5] = c8[6] = c8[7] = 0; }
+    }
+}
 __global__ void k_pde_finish(const double* sums, int64_t nk, float* out) {
     if (threadIdx.x == 0) {
         const double sd = sums[0], st = sums[1];
@@ -526,9 +533,8 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
     hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, nk, out);
     LAUNCHCK();
     if (counters) {
-        int64_t h[NVFI_NCOUNTERS] = {0, P, 0, evals, nk, 0, 0, 0};
-        HIPCK(hipMemcpyAsync(counters, h, sizeof(h), hipMemcpyHostToDevice, st));
-        HIPCK(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_set_i64x8, dim3(1), dim3(64), 0, st, counters, (int*)nullptr, 0, (int64_t)0, (int64_t)P, evals, nk);
+        LAUNCHCK();
     }
     return 0;
 }
@@ -542,10 +548,8 @@ extern "C" int nvfi_pde_loss(const nvfi_field_desc* f, int64_t P, const float* p
 int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st) {
     const size_t ts = (size_t)PDE_TILE_ROWS * REGF;
     const size_t slab = (size_t)PDE_NSLAB * (128 * 128 + 128);
-    // k_wgrad reads the sample count from device memory
-    const int hc = ntiles * TILE;
-    HIPCK(hipMemcpyAsync(dcount, &hc, sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCK(hipStreamSynchronize(st));
+    // k_wgrad reads the sample count from device memory (set by a one-thread kernel: no host sync)
+    hipLaunchKernelGGL(k_set_i64x8, dim3(1), dim3(64), 0, st, (int64_t*)nullptr, dcount, ntiles * TILE, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0);
     WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
     for (int net = 0; net < 2; ++net)
         for (int l = 0; l < 6; ++l) {

@@ -205,6 +205,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         self.nSamples = min(self.max_n_samples, int((self.aabbDiag / self.stepSize).item()) + 1)
         # host copies of the scalars the C ABI needs (no device sync per render call)
         self._aabb_host = [float(v) for v in self.aabb.detach().reshape(-1).cpu().tolist()]
+        self._grid_host = [int(g) for g in gridSize]
         self._step_host = float(self.stepSize)
 
     def _init_planes(self, n_component, gridSize, numFrames, scale, device):
@@ -277,8 +278,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         """nvfi_field_desc for the current parameters (or for the tensors saved by autograd)."""
         ps = self._render_params() if params is None else list(params)
         d = _lib.FieldDesc()
-        gs = [int(g) for g in self.gridSize.tolist()]
-        d.G[:] = gs
+        d.G[:] = self._grid_host
         d.K = int(self.num_keyframes)
         d.Cd, d.Ca, d.app_dim = int(self.density_n_comp[0]), int(self.app_n_comp[0]), int(self.app_dim)
         d.n_samples = int(self.nSamples)
@@ -348,7 +348,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         if training:
             flags |= _lib.NVFI_TRAIN
             # the reference draws the per-ray jitter on the CPU generator (tensorf_base.py:302-306)
-            jitter = torch.rand(R, 1).to(ray_o.device, non_blocking=True).reshape(-1)
+            jitter = self._jitter(R, ray_o.device)
         # white background or the training-time random-white coin, drawn on CPU (tensorf_keyframe.py:740)
         if white_bg or (training and bool(torch.rand((1,)) < 0.5)):
             flags |= _lib.NVFI_WHITE_BG
@@ -465,6 +465,24 @@ class TensorVMKeyframeTimeKplane(nn.Module):
                                    C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
         self.last_pde_out, self.last_pde_counters = out, counters
         return out
+
+    def _jitter(self, R, device):
+        """Per-ray jitter drawn on the CPU generator like the reference (tensorf_base.py:302-306), staged through a small
+        ring of pinned buffers so the upload is asynchronous."""
+        ov = self.__dict__.get("jitter_override")
+        if ov is not None:       # tests: explicit per-ray jitter instead of a draw
+            return ov.to(device).reshape(-1).float().contiguous()
+        ring = self.__dict__.setdefault("_jit_ring", [])
+        idx = self.__dict__.get("_jit_idx", 0)
+        if len(ring) < 4:
+            ring.append(torch.empty(max(R, 4096), 1).pin_memory())
+        buf = ring[idx % len(ring)]
+        if buf.shape[0] < R:
+            buf = ring[idx % len(ring)] = torch.empty(R, 1).pin_memory()
+        self.__dict__["_jit_idx"] = idx + 1
+        view = buf[:R]
+        torch.rand(R, 1, out=view)
+        return view.to(device, non_blocking=True).reshape(-1)
 
     def _scratch(self, key, nbytes, device):
         """Reusable workspace for calls whose workspace does not have to outlive the call."""

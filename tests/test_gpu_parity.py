@@ -161,23 +161,15 @@ def test_render_vs_oracle_bigger(fields, models, kind):
     f = model.nvfi
     f.train()
     model.zero_grad(set_to_none=True)
-    # drive the field directly with an explicit jitter: monkeypatch the CPU RNG draw
-    orig = torch.rand
-    calls = []
-    def fake_rand(*a, **k):
-        calls.append(a)
-        if len(calls) == 1:
-            return torch.from_numpy(u.copy())
-        return torch.tensor([0.9])
-    torch.rand = fake_rand
+    f.jitter_override = torch.from_numpy(u.copy())     # explicit per-ray jitter instead of the CPU-RNG draw
     try:
-        out = f(t, _cuda(o), _cuda(d), wb)
+        out = f(t, _cuda(o), _cuda(d), wb or True)
     finally:
-        torch.rand = orig
+        f.jitter_override = None
     tg = _cuda(rng.uniform(0, 1, (R, 3)).astype(np.float32))
     loss = torch.nn.functional.mse_loss(out[0], tg) + 0.01 * out[1].mean()
     loss.backward()
-    ref = orc.render(fs, o, d, t, u=u, train=True, white_bg=wb, keep_ctx=True)
+    ref = orc.render(fs, o, d, t, u=u, train=True, white_bg=True, keep_ctx=True)
     rgb = out[0].detach().cpu().numpy()
     np.testing.assert_allclose(rgb, ref.rgb, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(out[1].detach().cpu().numpy(), ref.depth, rtol=1e-4, atol=1e-4 * ref.depth.max())
