@@ -104,43 +104,50 @@ __device__ __forceinline__ void encode_tangent(const float* x0, int h, int j, fl
         }
 }
 
+// The tangent forward pass uses the tile-major form (engine.h: layer_tiles): while the MFMAs of output tile m run, the
+// epilogue of tile m-1 - its stash loads (z, zd), derivative math and stash stores - is independent work.
+
 template <int ACT>
 __device__ __forceinline__ void velnet_tangent_forward(const VelFrags& W, float* lds_w, float* lds_b, int lane, const float* xd16,
                                                        const float* zst, float* zdst, float* out4) {
-    float x[64];
-    f32x16 acc[4];
+    float xa[64], xb[64];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) x[s] = xd16[s];
+    for (int s = 0; s < 16; ++s) xb[s] = xd16[s];
+#define TAN_FWD_EPI(L, XOUT)                                                                  \
+    [&](int m, const f32x16& acc) {                                                           \
+        const float* zl = zst + (size_t)(L) * 64 * REGF; float* zd = zdst + (size_t)(L) * 64 * REGF; \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
+            zd[(16 * m + r) * REGF + lane] = acc[r];                                          \
+            XOUT[16 * m + r] = act_d1<ACT>(zl[(16 * m + r) * REGF + lane]) * acc[r];          \
+        }                                                                                     \
+    }
     __syncthreads();
     stage_frag(lds_w, lds_b, W.f[0], VEL_F0, nullptr, 0);
     __syncthreads();
-    acc_init<4>(acc, lds_b, 0, false);
-    layer_mfma<4, 14>(lds_w, lane, x, acc);
+    layer_tiles<4, 14>(lds_w, lds_b, false, lane, 0, xb, TAN_FWD_EPI(0, xa));
 #pragma unroll 1
-    for (int l = 1; l <= 5; ++l) {
-        const float* zl = zst + (size_t)(l - 1) * 64 * REGF;
-        stash_store_acc<4>(zdst + (size_t)(l - 1) * 64 * REGF, lane, acc);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[16 * m + r] = act_d1<ACT>(zl[(16 * m + r) * REGF + lane]) * acc[m][r];
+    for (int it = 0; it < 2; ++it) {
+        const int l = 1 + 2 * it;
         __syncthreads();
-        if (l <= 4) {
-            stage_frag(lds_w, lds_b, W.f[l], VEL_FH, nullptr, 0);
-            __syncthreads();
-            acc_init<4>(acc, lds_b, 0, false);
-            layer_mfma<4, 64>(lds_w, lane, x, acc);
-        } else {
-            stage_frag(lds_w, lds_b, W.f[5], VEL_F5, nullptr, 0);
-            __syncthreads();
-            f32x16 o[1];
-            acc_init<1>(o, lds_b, 0, false);
-            layer_mfma<1, 64>(lds_w, lane, x, o);
-            out4[0] = o[0][0]; out4[1] = o[0][1]; out4[2] = o[0][2]; out4[3] = o[0][3];
-        }
+        stage_frag(lds_w, lds_b, W.f[l], VEL_FH, nullptr, 0);
+        __syncthreads();
+        layer_tiles<4, 64>(lds_w, lds_b, false, lane, 0, xa, TAN_FWD_EPI(l, xb));
+        __syncthreads();
+        stage_frag(lds_w, lds_b, W.f[l + 1], VEL_FH, nullptr, 0);
+        __syncthreads();
+        layer_tiles<4, 64>(lds_w, lds_b, false, lane, 0, xb, TAN_FWD_EPI(l + 1, xa));
     }
+#undef TAN_FWD_EPI
+    __syncthreads();
+    stage_frag(lds_w, lds_b, W.f[5], VEL_F5, nullptr, 0);
+    __syncthreads();
+    layer_tiles<1, 64>(lds_w, lds_b, false, lane, 0, xa, [&](int, const f32x16& acc) {
+        out4[0] = acc[0]; out4[1] = acc[1]; out4[2] = acc[2]; out4[3] = acc[3];
+    });
 }
 
+// (the two adjoint passes keep the step-major form: measured faster here - the tile-major epilogue with its three
+// stash streams spills)
 // adjoint of one tangent column: seeds gwd (D-layout regs) -> gzd stash (A operand of k_wgrad) and the
 // second-derivative correction corr_l (+)= act''(z_l) * zd_l * ghd_l for the value-adjoint pass
 template <int ACT>
