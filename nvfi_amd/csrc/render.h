@@ -70,6 +70,8 @@ struct ScatterArgs {
     const float* gxpre;   // density: one upstream gradient per sample
     const float* gg;      // appearance: (M,48)
     nvfi_grads g;
+    int y0, gmax;         // LDS variant: first time row touched by this call, max grid extent
+    int plane_mask;       // debug: bit p enables scattering into plane p (default 63)
 };
 
 __global__ void k_counters(const int* c, int nsteps, int64_t* out);

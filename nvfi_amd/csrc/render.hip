@@ -11,6 +11,7 @@
 // loads; per-ray scans/reductions are wave-level; the MLP contractions run on the MFMA engine.
 #include "common.h"
 #include "render.h"
+#include <stdlib.h>
 
 // ================================================================ sampling + compaction
 __global__ void k_any_inside(nvfi_field_desc f, int64_t R, const float* __restrict__ o, int* flag) {
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(256) void k_plane_scatter(ScatterArgs a) {
         for (int p = 4; p >= 0; --p) Rr[p] = Rr[p + 1] * val[p + 1];
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
-            if (!gp[p] || !lane_on) continue;
+            if (!gp[p] || !lane_on || !((a.plane_mask >> p) & 1)) continue;
             const float o = L[p] * Rr[p];
             if (C == 24) {
                 const bool my0 = dx0 ? b[p].m1 : b[p].m0, my1 = dx0 ? b[p].m3 : b[p].m2;
@@ -693,6 +694,131 @@ __global__ __launch_bounds__(256) void k_plane_scatter(ScatterArgs a) {
             }
         }
     }
+}
+
+
+// Variant with LDS-privatised TIME planes.  The time coordinate is a per-call scalar, so every sample scatters into the
+// same two rows of the three time planes (2 x G x C floats each): per-workgroup LDS accumulators absorb that contention
+// and are flushed once; space planes keep the coalesced global atomics.  A workgroup handles 24 channels starting at c0
+// of planes with CT channels per texel (density: CT=24, one group; appearance: CT=48, two groups on blockIdx.y).
+template <int CT>
+__global__ __launch_bounds__(512) void k_plane_scatter_lds(ScatterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float acc_lds[];   // [3 planes][2 rows][gmax][24]
+    const nvfi_field_desc& f = a.f;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    const int c0 = blockIdx.y * 24;
+    const int gmax = a.gmax;
+    for (int k = threadIdx.x; k < 6 * gmax * 24; k += blockDim.x) acc_lds[k] = 0.f;
+    __syncthreads();
+    const int count = *a.count;
+    const float* pl[6]; float* gp[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        pl[p] = CT == 24 ? f.dps[p] : f.aps[p]; pl[3 + p] = CT == 24 ? f.dpt[p] : f.apt[p];
+        gp[p] = CT == 24 ? a.g.dps[p] : a.g.aps[p];
+    }
+    const int ch = lane >> 1, dx0 = lane & 1;
+    const bool lane_on = lane < 48;
+    const int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * nwv + wv), wave_total = gridDim.x * nwv;
+#pragma unroll 1
+    for (int i = wave_global; i < count; i += wave_total) {
+        const int n = __builtin_amdgcn_readfirstlane(a.list[i]);
+        const float4 q = a.xw[n];
+        Bl b[6];
+        plane_setups(f, q.x, q.y, q.z, a.tn, b);
+        float gch;
+        if (CT == 24) gch = a.gxpre[n];
+        else gch = lane_on ? a.gg[(size_t)i * 48 + c0 + ch] : 0.f;
+        float val[6];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            const bool my0 = dx0 ? b[p].m1 : b[p].m0, my1 = dx0 ? b[p].m3 : b[p].m2;
+            const float wx = dx0 ? b[p].w : b[p].e;
+            const size_t o0 = (size_t)(b[p].base + dx0) * CT + c0 + ch, o1 = o0 + (size_t)b[p].W * CT;
+            const float v0 = (lane_on && my0) ? pl[p][o0] : 0.f, v1 = (lane_on && my1) ? pl[p][o1] : 0.f;
+            const float part = v0 * (wx * b[p].s) + v1 * (wx * b[p].n);
+            val[p] = part + dpp_xor1(part);
+        }
+        float L[6], Rr[6];
+        L[0] = gch;
+#pragma unroll
+        for (int p = 1; p < 6; ++p) L[p] = L[p - 1] * val[p - 1];
+        Rr[5] = 1.f;
+#pragma unroll
+        for (int p = 4; p >= 0; --p) Rr[p] = Rr[p + 1] * val[p + 1];
+        if (lane_on) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {       // space planes: coalesced global atomics
+                if (!gp[p]) continue;
+                const float o = L[p] * Rr[p];
+                const bool my0 = dx0 ? b[p].m1 : b[p].m0, my1 = dx0 ? b[p].m3 : b[p].m2;
+                const float wx = dx0 ? b[p].w : b[p].e;
+                const size_t o0 = (size_t)(b[p].base + dx0) * CT + c0 + ch, o1 = o0 + (size_t)b[p].W * CT;
+                if (my0) atomicAdd(gp[p] + o0, (wx * b[p].s) * o);
+                if (my1) atomicAdd(gp[p] + o1, (wx * b[p].n) * o);
+            }
+#pragma unroll
+            for (int p = 3; p < 6; ++p) {       // time planes: workgroup-private LDS rows (y0, y0+1 are call constants)
+                const float o = L[p] * Rr[p];
+                const bool my0 = dx0 ? b[p].m1 : b[p].m0, my1 = dx0 ? b[p].m3 : b[p].m2;
+                const float wx = dx0 ? b[p].w : b[p].e;
+                const int x = b[p].base - a.y0 * b[p].W + dx0;        // column inside the row
+                float* r0 = acc_lds + ((size_t)((p - 3) * 2 + 0) * gmax + x) * 24 + ch;
+                if (my0) atomicAdd(r0, (wx * b[p].s) * o);
+                if (my1) atomicAdd(r0 + (size_t)gmax * 24, (wx * b[p].n) * o);
+            }
+        }
+    }
+    __syncthreads();
+    // flush the private rows
+    const int Gc[3] = {f.G[2], f.G[1], f.G[0]};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        float* g = CT == 24 ? a.g.dpt[p] : a.g.apt[p];
+        if (!g) continue;
+        for (int dy = 0; dy < 2; ++dy) {
+            const int y = a.y0 + dy;
+            if (y < 0 || y >= f.K) continue;
+            for (int k = threadIdx.x; k < Gc[p] * 24; k += blockDim.x) {
+                const int x = k / 24, c = k - 24 * x;
+                const float v = acc_lds[((size_t)(p * 2 + dy) * gmax + x) * 24 + c];
+                if (v != 0.f) atomicAdd(g + ((size_t)y * Gc[p] + x) * CT + c0 + c, v);
+            }
+        }
+    }
+}
+
+static int scatter_mask() { static int m = -1; if (m < 0) { const char* e = getenv("NVFI_SCATTER_MASK"); m = e ? atoi(e) : 63; } return m; }
+
+
+// plane-gradient scatter: LDS-privatised time rows when they fit, plain channel-parallel atomics otherwise
+static int launch_scatter(const nvfi_field_desc* f, ScatterArgs& sa, int C, int64_t N, float tn, hipStream_t st) {
+    int gmax = f->G[0] > f->G[1] ? f->G[0] : f->G[1];
+    gmax = gmax > f->G[2] ? gmax : f->G[2];
+    const size_t lds = (size_t)6 * gmax * 24 * sizeof(float);
+    static int use_lds = -1;
+    if (use_lds < 0) { const char* e = getenv("NVFI_SCATTER_LDS"); use_lds = e ? atoi(e) : 1; }
+    if (use_lds && lds <= 150 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            HIPCK(hipFuncSetAttribute((const void*)k_plane_scatter_lds<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            HIPCK(hipFuncSetAttribute((const void*)k_plane_scatter_lds<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            attr = true;
+        }
+        // row y0 of the time planes: same arithmetic as bl_setup on the per-call time coordinate
+        const float y = (tn + 1.f) * ((float)(f->K - 1) / 2.f);
+        float yf = floorf(y);
+        yf = fminf(fmaxf(yf, -4.f), (float)f->K + 2.f);
+        sa.y0 = (int)yf; sa.gmax = gmax;
+        if (C == 24) hipLaunchKernelGGL(k_plane_scatter_lds<24>, dim3(256, 1), dim3(512), lds, st, sa);
+        else hipLaunchKernelGGL(k_plane_scatter_lds<48>, dim3(256, 2), dim3(512), lds, st, sa);
+    } else {
+        const unsigned sc_blocks = (unsigned)((N + 4 * SCATTER_SPW - 1) / (4 * SCATTER_SPW));
+        if (C == 24) hipLaunchKernelGGL(k_plane_scatter<24>, dim3(sc_blocks), dim3(256), 0, st, sa);
+        else hipLaunchKernelGGL(k_plane_scatter<48>, dim3(sc_blocks), dim3(256), 0, st, sa);
+    }
+    LAUNCHCK();
+    return 0;
 }
 
 // ================================================================ host: fragment jobs, launches, ABI
@@ -936,12 +1062,11 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     aa.g_rgb = g_rgb; aa.rgb_pre = P.rgb_pre; aa.weight = weights; aa.gxw = P.gxw; aa.gg = P.gg;
     const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
     { ProfScope ps(PK_APP_BWD, st); hipLaunchKernelGGL(k_app_bwd, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa); }
-    const unsigned sc_blocks = (unsigned)((N + 4 * SCATTER_SPW - 1) / (4 * SCATTER_SPW));
     if (grads->aps[0] || grads->apt[0]) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
-        sa.f = *f; sa.count = P.counters + 1; sa.list = P.mlist; sa.xw = P.xw; sa.tn = tn; sa.gg = P.gg; sa.g = *grads;
+        sa.f = *f; sa.count = P.counters + 1; sa.list = P.mlist; sa.xw = P.xw; sa.tn = tn; sa.gg = P.gg; sa.g = *grads; sa.plane_mask = scatter_mask();
         ProfScope ps(PK_APP_SCATTER, st);
-        hipLaunchKernelGGL(k_plane_scatter<48>, dim3(sc_blocks), dim3(256), 0, st, sa);
+        if (launch_scatter(f, sa, 48, N, tn, st)) return 1;
     }
     LAUNCHCK();
     // render-MLP weight gradients
@@ -980,9 +1105,9 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     if (nsteps > 0) { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
     if (grads->dps[0] || grads->dpt[0]) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
-        sa.f = *f; sa.count = P.counters + 0; sa.list = P.vlist; sa.xw = P.xw; sa.tn = tn; sa.gxpre = P.gxpre; sa.g = *grads;
+        sa.f = *f; sa.count = P.counters + 0; sa.list = P.vlist; sa.xw = P.xw; sa.tn = tn; sa.gxpre = P.gxpre; sa.g = *grads; sa.plane_mask = scatter_mask();
         ProfScope ps(PK_DENSITY_SCATTER, st);
-        hipLaunchKernelGGL(k_plane_scatter<24>, dim3(sc_blocks), dim3(256), 0, st, sa);
+        if (launch_scatter(f, sa, 24, N, tn, st)) return 1;
     }
     LAUNCHCK();
     // RK2 adjoint + velocity-net weight gradients
