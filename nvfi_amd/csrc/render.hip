@@ -888,7 +888,9 @@ struct RenderPlan {
     float *slabs;
     int64_t total;
 };
-#define NSLAB 256
+#define NSLAB_MAX 1024
+static int nslab_rt() { static int n = -1; if (n < 0) { const char* e = getenv("NVFI_NSLAB"); n = e ? atoi(e) : 256; if (n < 1) n = 1; if (n > NSLAB_MAX) n = NSLAB_MAX; } return n; }
+#define NSLAB (nslab_rt())
 #define SLAB_FLOATS (128 * 128 + 128)
 
 static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nsteps, void* ws, RenderPlan* P) {
@@ -913,7 +915,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
         P->gg = B.take<float>(N * 48);
         P->app_f = B.take<float>(P->cap_tiles * (int64_t)(APP_F_ROWS * REGF));
         P->app_b = B.take<float>(P->cap_tiles * (int64_t)(APP_B_ROWS * REGF));
-        P->slabs = B.take<float>((int64_t)NSLAB * SLAB_FLOATS * 6);
+        P->slabs = B.take<float>((int64_t)NSLAB_MAX * SLAB_FLOATS * 6);
         if (nsteps > 0) {
             const int64_t nev = 2 * (int64_t)nsteps;
             P->zst = B.take<float>(nev * P->cap_tiles * (int64_t)(VEL_Z_REGS * REGF));
@@ -1085,10 +1087,10 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
             Q.row_kind = RK_NATURAL; Q.slot_kind = sk; Q.scale = 1.f;
         };
         float* sl = P.slabs;
-        if (grads->rW[2] || grads->rb[2]) add(P.app_b + 0, 16, P.app_f + 160 * REGF, 64, sl + 0 * (size_t)NSLAB * SLAB_FLOATS, grads->rW[2], grads->rb[2], 3, 128, SK_HIDDEN);
-        if (grads->rW[1] || grads->rb[1]) add(P.app_b + 16 * REGF, 64, P.app_f + 96 * REGF, 64, sl + 1 * (size_t)NSLAB * SLAB_FLOATS, grads->rW[1], grads->rb[1], 128, 128, SK_HIDDEN);
-        if (grads->rW[0] || grads->rb[0]) add(P.app_b + 80 * REGF, 64, P.app_f + 32 * REGF, 64, sl + 2 * (size_t)NSLAB * SLAB_FLOATS, grads->rW[0], grads->rb[0], 128, 110, SK_RENDER_IN);
-        if (grads->basis) add(P.app_b + 144 * REGF, 16, P.app_f + 0, 32, sl + 3 * (size_t)NSLAB * SLAB_FLOATS, grads->basis, nullptr, f->app_dim, f->Ca, SK_HIDDEN);
+        if (grads->rW[2] || grads->rb[2]) add(P.app_b + 0, 16, P.app_f + 160 * REGF, 64, sl + 0 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->rW[2], grads->rb[2], 3, 128, SK_HIDDEN);
+        if (grads->rW[1] || grads->rb[1]) add(P.app_b + 16 * REGF, 64, P.app_f + 96 * REGF, 64, sl + 1 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->rW[1], grads->rb[1], 128, 128, SK_HIDDEN);
+        if (grads->rW[0] || grads->rb[0]) add(P.app_b + 80 * REGF, 64, P.app_f + 32 * REGF, 64, sl + 2 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->rW[0], grads->rb[0], 128, 110, SK_RENDER_IN);
+        if (grads->basis) add(P.app_b + 144 * REGF, 16, P.app_f + 0, 32, sl + 3 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->basis, nullptr, f->app_dim, f->Ca, SK_HIDDEN);
         if (launch_wgrad(wj, rj, st)) return 1;
     }
     // composites + raw2alpha
