@@ -229,11 +229,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the NVFi hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev          # (ranks share a device only in the single-GPU logic test, see NVFI_BENCH_BACKEND)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("NVFI_BENCH_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" only to exercise the path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     from nvfi_amd import _lib
     L = _lib.lib()
 
@@ -283,8 +289,13 @@ def main():
     if dom:
         ms, n = times[dom]
         ach = flops[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch of that kernel class from the committed PMC passes (profiles/README.md)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["bytes_per_launch"].get(dom)
+        except Exception:
+            pass
         roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=PEAK_FP32_MFMA, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA,
-                    traffic=None, launches=int(n), avg_launch_ms=ms / max(n, 1), flop_per_launch=flops[dom] / max(n, 1),
+                    traffic=traffic, launches=int(n), avg_launch_ms=ms / max(n, 1), flop_per_launch=flops[dom] / max(n, 1),
                     per_class_ms_per_step={k: times[k][0] / args.steps for k in times})
 
     out = {
