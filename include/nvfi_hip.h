@@ -63,6 +63,7 @@ typedef struct nvfi_grads {
 #define NVFI_TRAIN     1  /* training mode: jitter used, alpha mask ignored, intermediates kept for backward */
 #define NVFI_WHITE_BG  2  /* rgb += 1-acc  (white_bg or the random-white coin, tensorf_keyframe.py:740) */
 #define NVFI_TRANSFER  4  /* transfer_vel: base time 0 (models/nvfi.py:30) */
+#define NVFI_WANT_MASK 8  /* plan workspace room for nvfi_render_mask (mask_field attached) */
 
 /* counters written by nvfi_render_fwd (device int64[8]):
  * 0 valid samples V, 1 warped samples N, 2 appearance-masked samples M, 3 velocity-net evaluations */
@@ -108,6 +109,21 @@ int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float* points, c
                      float loss_scale, float* out, const nvfi_grads* grads,
                      void* workspace, int64_t workspace_bytes, int64_t* counters,
                      uint8_t* kept_out, float* jac_out, int64_t n_jac, void* stream);
+
+/* ---- mask branch of render_pts (models/tensorf_keyframe.py:673-676, 749-753) with the MaskField as train_segm.py:97-102
+ *      builds it: 3 -> n_dim x n_layer (ReLU) -> mask_dim, softmax.  Call after nvfi_render_fwd with the same workspace:
+ *      mask_map[R][mask_dim] = sum over appearance-masked samples of weight * softmax(MaskField(warped xyz)). Inference only. */
+typedef struct nvfi_mask_desc {
+    int32_t n_layer;         /* hidden layers (4) */
+    int32_t n_dim;           /* hidden width (128) */
+    int32_t mask_dim;        /* outputs (<= 32) */
+    const float* W[5];       /* point_fc.{0..3}.weight (n_dim,3|n_dim), mask_fc.weight (mask_dim,n_dim) */
+    const float* b[5];
+} nvfi_mask_desc;
+int nvfi_render_mask(const nvfi_field_desc* f, const nvfi_mask_desc* m, int64_t R, float t, int flags, const float* weights,
+                     float* mask_map, void* workspace, int64_t workspace_bytes, void* stream);
+/* SHRender (models/tensorf_model_utils.py:292-296 with models/sh.py:87-110, degree 2): view (N,3), feat (N,27) -> rgb (N,3) */
+int nvfi_sh_render(int64_t N, const float* view, const float* feat27, float* rgb, void* stream);
 
 /* ---- per-iteration plane regularisers (next-row f-1): density_L1, TV_loss_density, TV_loss_app
  *      (models/tensorf_keyframe.py:188-231, utils/tensorf_utils.py:139-158) in one pass.  out3 (device float[3]) receives the

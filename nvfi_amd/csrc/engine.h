@@ -45,7 +45,7 @@ __host__ __device__ inline int dinv_p(int rho) {
     return 2 * (16 * m + r) + h;
 }
 
-enum { SK_HIDDEN = 0, SK_VEL_IN = 1, SK_RENDER_IN = 2 };
+enum { SK_HIDDEN = 0, SK_VEL_IN = 1, SK_RENDER_IN = 2, SK_XYZ = 3 };
 // slot p = 2*s + h  ->  logical input feature index of the layer (or -1: unused slot)
 __host__ __device__ inline int slot_logical(int kind, int p) {
     int s = p >> 1, h = p & 1;
@@ -56,6 +56,7 @@ __host__ __device__ inline int slot_logical(int kind, int p) {
         if (s < 14) { int k = (s - 2) >> 2, c = (s - 2) & 3; return (h ? 8 : 4) + 8 * k + c; }  // sin | cos
         return -1;
     }
+    if (kind == SK_XYZ) return p < 3 ? p : -1;   // MaskField input: (x | y), (z | -)
     // SK_RENDER_IN: [feat32 | view3 | pts3 | sin(pts)18 | cos(pts)18 | sin(view)18 | cos(view)18]
     if (s < 16) return dmap(s, h);
     if (s < 19) return (h ? 35 : 32) + (s - 16);

@@ -884,7 +884,7 @@ struct RenderPlan {
     float4 *xw, *rgbs, *rgb_pre, *gxw, *gxk;
     float *xpre, *gxpre;
     float *vel_frag, *render_frag;
-    float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg;
+    float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     float *slabs;
     int64_t total;
 };
@@ -908,6 +908,8 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->xpre = B.take<float>(N);
     P->vel_frag = B.take<float>(VEL_FRAG_FLOATS);
     P->render_frag = B.take<float>(RENDER_FRAG_FLOATS);
+    P->maskv = (flags & NVFI_WANT_MASK) ? B.take<float>(N * 32) : nullptr;
+    P->mask_frag = (flags & NVFI_WANT_MASK) ? B.take<float>(64 * 1024) : nullptr;
     P->app_f = P->app_b = P->zst = P->x0st = P->rec = P->gst = P->slabs = nullptr;
     P->gxw = P->gxk = nullptr; P->gxpre = nullptr; P->gg = nullptr;
     if (train) {
@@ -1195,4 +1197,156 @@ extern "C" int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyz
 __global__ void k_unpack_rgb(const float4* in, float* out, int64_t N) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < N) { float4 v = in[i]; out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z; }
+}
+
+
+// ================================================================ a-19 mask branch (inference)
+struct MaskFrags { const float* f[5]; const float* b[5]; };
+struct MaskArgs {
+    MaskFrags W; int mask_dim;
+    const int* count; const int* list; const float4* xw;
+    float* maskv;        // (M, 32) softmax outputs per masked sample
+    int64_t R; const int* off_m; const float* weight; float* mask_map;
+};
+
+__global__ __launch_bounds__(WG_THREADS, 2) void k_mask_fwd(MaskArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int count = *a.count;
+    if ((int)(blockIdx.x * WG_SAMPLES) >= count) return;
+    const int tile = blockIdx.x * 4 + wave_id();
+    const int i = tile * TILE + (lane & 31);
+    const bool active = i < count;
+    const float4 q = active ? a.xw[a.list[i]] : zero4();
+    float xa[64], xb[64];
+    xb[0] = h ? q.y : q.x; xb[1] = h ? 0.f : q.z;
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f[0], 4 * 2 * 64, a.W.b[0], 128);
+    __syncthreads();
+    layer_tiles<4, 2>(lds_w, lds_b, true, lane, h, xb, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xa[16 * m + r] = fmaxf(acc[r], 0.f);
+    });
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f[1], 4 * 64 * 64, a.W.b[1], 128);
+    __syncthreads();
+    layer_tiles<4, 64>(lds_w, lds_b, true, lane, h, xa, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xb[16 * m + r] = fmaxf(acc[r], 0.f);
+    });
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f[2], 4 * 64 * 64, a.W.b[2], 128);
+    __syncthreads();
+    layer_tiles<4, 64>(lds_w, lds_b, true, lane, h, xb, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xa[16 * m + r] = fmaxf(acc[r], 0.f);
+    });
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f[3], 4 * 64 * 64, a.W.b[3], 128);
+    __syncthreads();
+    layer_tiles<4, 64>(lds_w, lds_b, true, lane, h, xa, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xb[16 * m + r] = fmaxf(acc[r], 0.f);
+    });
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f[4], 1 * 64 * 64, a.W.b[4], 32);
+    __syncthreads();
+    float o[16];
+    layer_tiles<1, 64>(lds_w, lds_b, true, lane, h, xb, [&](int, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = acc[r];
+    });
+    // softmax over the mask_dim logits of the sample: rows (r&3)+8(r>>2)+4h live in this lane, the rest in lane^32
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int row = (r & 3) + 8 * (r >> 2) + 4 * h; if (row < a.mask_dim) mx = fmaxf(mx, o[r]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int row = (r & 3) + 8 * (r >> 2) + 4 * h; o[r] = row < a.mask_dim ? expf(o[r] - mx) : 0.f; sum += o[r]; }
+    sum += __shfl_xor(sum, 32);
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int row = (r & 3) + 8 * (r >> 2) + 4 * h; if (row < a.mask_dim) a.maskv[(size_t)i * 32 + row] = o[r] / sum; }
+    }
+}
+// mask_map[r][k] = sum_j w_j mask_j[k] over the ray's masked samples (tensorf_keyframe.py:753)
+__global__ __launch_bounds__(256) void k_mask_final(MaskArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int b0 = a.off_m[r], b1 = a.off_m[r + 1];
+    // lane = (entry parity, channel): 2 entries per pass x 32 channels
+    const int k = lane & 31, e0 = lane >> 5;
+    float s = 0.f;
+    for (int i = b0 + e0; i < b1; i += 2) s += a.weight[a.list[i]] * (k < a.mask_dim ? a.maskv[(size_t)i * 32 + k] : 0.f);
+    s += __shfl_xor(s, 32);
+    if (lane < a.mask_dim) a.mask_map[r * a.mask_dim + lane] = s;
+}
+
+extern "C" int nvfi_render_mask(const nvfi_field_desc* f, const nvfi_mask_desc* m, int64_t R, float t, int flags, const float* weights,
+                                float* mask_map, void* workspace, int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (check_desc(f)) return 2;
+    if (m->n_layer != 4 || m->n_dim != 128 || m->mask_dim < 1 || m->mask_dim > 32)
+        return nvfi_fail(2, "mask field must be 3->128x4->mask_dim<=32 (train_segm.py:97-102); got n_layer=%d n_dim=%d mask_dim=%d", m->n_layer, m->n_dim, m->mask_dim);
+    if (R <= 0) return 0;
+    float base, dts[MAX_RK_STEPS], tcs[MAX_RK_STEPS];
+    const int nsteps = rk_schedule(f, t, flags, &base, dts, tcs);
+    RenderPlan P;
+    plan_render(f, R, flags, nsteps < 0 ? 0 : nsteps, workspace, &P);
+    if (P.total > workspace_bytes) return nvfi_fail(4, "workspace too small");
+    static bool attr = false;
+    if (!attr) { HIPCK(hipFuncSetAttribute((const void*)k_mask_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES)); attr = true; }
+    if (!P.mask_frag) return nvfi_fail(2, "nvfi_render_mask needs a workspace planned with NVFI_WANT_MASK in flags");
+    float* frag = P.mask_frag;
+    PackJobs jobs; jobs.n = 0;
+    MaskArgs a; memset(&a, 0, sizeof(a));
+    float* p = frag;
+    for (int l = 0; l < 5; ++l) {
+        PackJob& J = jobs.j[jobs.n++];
+        const int MT = l < 4 ? 4 : 1, NS = l == 0 ? 2 : 64;
+        J.W = m->W[l]; J.b = m->b[l]; J.frag = p; p += MT * NS * 64; J.bfrag = p; p += 128;
+        J.out = l < 4 ? 128 : m->mask_dim; J.in = l == 0 ? 3 : 128; J.MT = MT; J.NS = NS;
+        J.row_kind = RK_NATURAL; J.slot_kind = l == 0 ? SK_XYZ : SK_HIDDEN; J.transposed = 0;
+        a.W.f[l] = J.frag; a.W.b[l] = J.bfrag;
+    }
+    if (launch_pack(jobs, st)) return 1;
+    a.mask_dim = m->mask_dim; a.count = P.counters + 1; a.list = P.mlist; a.xw = P.xw;
+    a.R = R; a.off_m = P.off_m; a.weight = weights; a.mask_map = mask_map;
+    if (!P.maskv) return nvfi_fail(2, "nvfi_render_mask needs a workspace planned with NVFI_WANT_MASK in flags");
+    a.maskv = P.maskv;
+    const unsigned wgs = (unsigned)((P.N + WG_SAMPLES - 1) / WG_SAMPLES);
+    hipLaunchKernelGGL(k_mask_fwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
+    hipLaunchKernelGGL(k_mask_final, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, a);
+    LAUNCHCK();
+    return 0;
+}
+
+// ================================================================ a-17 SHRender (degree 2 real SH, relu(sum + 0.5))
+__global__ void k_sh_render(int64_t N, const float* __restrict__ view, const float* __restrict__ ft, float* __restrict__ rgb) {
+    const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    const float x = view[3 * n], y = view[3 * n + 1], z = view[3 * n + 2];
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    float b[9];
+    b[0] = C0; b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
+    b[4] = C2[0] * xy; b[5] = C2[1] * yz; b[6] = C2[2] * (2.0f * zz - xx - yy); b[7] = C2[3] * xz; b[8] = C2[4] * (xx - yy);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s += b[k] * ft[27 * n + 9 * c + k];
+        s += 0.5f;
+        rgb[3 * n + c] = s > 0.f ? s : 0.f;
+    }
+}
+extern "C" int nvfi_sh_render(int64_t N, const float* view, const float* feat27, float* rgb, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(k_sh_render, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, view, feat27, rgb);
+    LAUNCHCK();
+    return 0;
 }

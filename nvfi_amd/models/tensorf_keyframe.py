@@ -66,6 +66,7 @@ class _RenderFn(torch.autograd.Function):
                                      C.c_float(t), C.c_int(flags), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc),
                                      _lib.ptr(weights), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
         field.last_counters = counters
+        field._last_ws = ws if (flags & _lib.NVFI_WANT_MASK) else None
         if flags & _lib.NVFI_TRAIN:
             ctx.field, ctx.t, ctx.flags, ctx.ws = field, t, flags, ws
             ctx.save_for_backward(rays_o, rays_d, weights, *params)
@@ -339,6 +340,8 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             raise NotImplementedError("ndc rays are out of scope (ndc: False in every shipped config)")
         if N_samples > 0 and N_samples != self.nSamples:
             raise NotImplementedError("per-call N_samples override is not supported")
+        if not ray_o.is_cuda or not self.aabb.is_cuda:
+            raise _lib.NvfiError("NVFi HIP kernels need the field and the rays on the GPU (no CPU fallback exists)")
         ray_o = ray_o.reshape(-1, 3).contiguous().float()
         ray_d = ray_d.reshape(-1, 3).contiguous().float()
         R = ray_o.shape[0]
@@ -354,6 +357,8 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             flags |= _lib.NVFI_WHITE_BG
         if transfer_vel:
             flags |= _lib.NVFI_TRANSFER
+        if self.mask_field is not None:
+            flags |= _lib.NVFI_WANT_MASK
         t = float(np.float32(float(t)))
         params = self._render_params()
         if training and torch.is_grad_enabled():
@@ -361,9 +366,28 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         else:
             with torch.no_grad():
                 rgb, depth, acc, weights, _ = _RenderFn.apply(self, t, ray_o, ray_d, jitter, flags, *params)
-        mask_dim = 3 if self.mask_field is None else self.mask_field.mask_dim
-        mask_map = torch.zeros(R, mask_dim, device=ray_o.device)
+        if self.mask_field is None:
+            mask_map = torch.zeros(R, 3, device=ray_o.device)
+        else:
+            mask_map = self._mask_map(t, flags, R, weights)
         return rgb, depth, acc, weights, mask_map
+
+    @torch.no_grad()
+    def _mask_map(self, t, flags, R, weights):
+        """mask branch of render_pts (tensorf_keyframe.py:673-676, 749-753); inference only."""
+        L = _lib.lib()
+        mf = self.mask_field
+        md = _lib.MaskDesc()
+        md.n_layer, md.n_dim, md.mask_dim = len(mf.point_fc), mf.point_fc[0].out_features, mf.mask_dim
+        lins = list(mf.point_fc) + [mf.mask_fc]
+        for i, lin in enumerate(lins):
+            md.W[i] = _lib.ptr(lin.weight); md.b[i] = _lib.ptr(lin.bias)
+        out = torch.empty(R, mf.mask_dim, device=weights.device)
+        desc = self._desc()
+        ws = self._last_ws
+        _lib.check(L.nvfi_render_mask(C.byref(desc), C.byref(md), C.c_int64(R), C.c_float(t), C.c_int(flags), _lib.ptr(weights.detach()),
+                                      _lib.ptr(out), _lib.ptr(ws), C.c_int64(ws.numel()), _stream_ptr()))
+        return out
 
     # ------------------------------------------------------------------ building blocks (inference, no autograd)
     def normalize_coord(self, xyz_sampled):
@@ -417,6 +441,17 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         desc = self._desc()
         _lib.check(L.nvfi_density_at(C.byref(desc), C.c_int64(N), _lib.ptr(q), _lib.ptr(feat), _lib.ptr(sigma), _stream_ptr()))
         return feat.unsqueeze(-1)
+
+    @staticmethod
+    @torch.no_grad()
+    def sh_render(viewdirs, features):
+        """SHRender (tensorf_model_utils.py:292-296): degree-2 real SH, relu(sum + 0.5); features (N,27)."""
+        L = _lib.lib()
+        v = viewdirs.reshape(-1, 3).contiguous().float()
+        ft = features.reshape(-1, 27).contiguous().float()
+        rgb = torch.empty(v.shape[0], 3, device=v.device)
+        _lib.check(L.nvfi_sh_render(C.c_int64(v.shape[0]), _lib.ptr(v), _lib.ptr(ft), _lib.ptr(rgb), _stream_ptr()))
+        return rgb
 
     def feature2density(self, density_features, x=None):
         return F.softplus(density_features[..., 0] + self.density_shift)

@@ -273,3 +273,31 @@ def test_inplace_gradient_accumulation_matches_autograd(gold, models):
         n += 1
     assert n > 30
     model.zero_grad(set_to_none=True)
+
+
+def test_mask_branch(gold, models):
+    """a-19: composited MaskField map (golden captured by calling the reference field directly, bypassing Renderer's reshape bug)"""
+    from nvfi_amd.models import MaskField
+    model, meta = models["A"]
+    f = model.nvfi
+    mf = MaskField(n_layer=4, n_dim=128, skips=[], mask_dim=8).cuda()
+    sd = {k[len("A:mask:sd:"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("A:mask:sd:")}
+    mf.load_state_dict(sd)
+    f.mask_field = mf
+    f.eval()
+    try:
+        with torch.no_grad():
+            out = f(19.0 / 60.0, _cuda(gold["A:rays_o"]), _cuda(gold["A:rays_d"]), True, False)
+    finally:
+        f.mask_field = None
+    ref = gold["A:mask:map"]
+    assert out[4].shape == ref.shape
+    np.testing.assert_allclose(out[4].cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * ref.max())
+    np.testing.assert_allclose(out[0].cpu().numpy(), gold["A:render_nonkey:rgb"], rtol=1e-4, atol=1e-4)
+
+
+def test_sh_render(gold):
+    """a-17"""
+    from nvfi_amd.models import TensorVMKeyframeTimeKplane
+    rgb = TensorVMKeyframeTimeKplane.sh_render(_cuda(gold["sh:view"]), _cuda(gold["sh:feat"])).cpu().numpy()
+    np.testing.assert_allclose(rgb, gold["sh:rgb"], rtol=1e-5, atol=1e-6)
