@@ -150,6 +150,14 @@ int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, const fl
 int nvfi_prof_enable(int on);
 int nvfi_prof_collect(double* total_ms, int64_t* count);
 int nvfi_prof_nclasses(void);
+/* compute_alpha (tensorf_keyframe.py:508-537) for a per-call time: xyz (N,3) WORLD coordinates -> normalise, snap to the keyframe
+ * (base 0 when transfer), RK2 back-advect, density, alpha = 1-exp(-sigma*length); alpha_out[n] = max(alpha_out[n], alpha) when
+ * accumulate_max != 0 (getDenseAlpha's running maximum over the 60 frame times, :476-497), plain store otherwise. */
+int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const float* xyz_world, float t, int transfer, float length,
+                       int accumulate_max, float* alpha_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* Camera.get_ray_bundle + pixel selection (models/camera.py:112-138,159-172): pose (device float[12], row-major 3x4 c2w),
+ * pixel ids (device int64[n], row-major y*W+x) -> rays_o (n,3), rays_d (n,3) */
+int nvfi_gen_rays(const float* pose3x4, int H, int W, float focal, int64_t n, const int64_t* pixel_ids, float* rays_o, float* rays_d, void* stream);
 /* MFMA fragment-layout self test: returns max abs error of a 128x128 fp32 layer against a VALU loop (host float*) */
 int nvfi_selftest(float* max_err_host, void* stream);
 

@@ -62,6 +62,75 @@ extern "C" int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const flo
     return launch_rk2_fwd(a, N, false, false, st);
 }
 
+// ---------------------------------------------------------------- compute_alpha / device-side rays (next rows f-3, f-2)
+__global__ void k_alpha_prep(nvfi_field_desc f, int64_t N, const float* xyz, float tn, float4* xw) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < N) xw[i] = make_float4(norm_coord(f, 0, xyz[3 * i]), norm_coord(f, 1, xyz[3 * i + 1]), norm_coord(f, 2, xyz[3 * i + 2]), tn);
+}
+__global__ void k_alpha_finish(nvfi_field_desc f, int64_t N, const float4* xw, float length, int acc_max, float* out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float4 q = xw[i];
+    const float sigma = softplus_f(density_feature(f, q.x, q.y, q.z, q.w) + f.density_shift);
+    const float a = 1.f - expf(-sigma * length);
+    out[i] = acc_max ? fmaxf(out[i], a) : a;
+}
+extern "C" int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const float* xyz_world, float t, int transfer, float length,
+                                  int accumulate_max, float* alpha_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 0) return 0;
+    if (N >= (1ll << 31) - 256) return nvfi_fail(2, "N too large for one call; chunk the points");
+    Bump B{(char*)workspace, 0, 0};
+    float* fv = B.take<float>(VEL_FRAG_FLOATS);
+    float4* xw = B.take<float4>(N);
+    if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
+    const float base = transfer ? 0.f : snap_base(*f, t);
+    const unsigned nb = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(k_alpha_prep, dim3(nb), dim3(256), 0, st, *f, N, xyz_world, norm_time(*f, base), xw);
+    if (f->use_vel && !is_close(t, base)) {
+        Rk2Args a; memset(&a, 0, sizeof(a));
+        const float dtm = dt_max_of(*f);
+        float off = t - base, tc = t;
+        int n = 0;
+        while (fabsf(off) > 0.f) {
+            if (n >= MAX_RK_STEPS) return nvfi_fail(2, "t=%g needs more than %d RK2 steps", t, MAX_RK_STEPS);
+            const float m = fabsf(off) < dtm ? fabsf(off) : dtm;
+            const float dt = off > 0.f ? m : -m;
+            a.dt[n] = dt; a.tcur[n] = tc;
+            off = off - dt; tc = tc - dt; ++n;
+        }
+        PackJobs jobs; jobs.n = 0;
+        if (pack_vel_frags(f->vW, f->vb, fv, &a.Wv, &jobs)) return 3;
+        if (launch_pack(jobs, st)) return 1;
+        a.f = *f; a.count = nullptr; a.n_direct = N; a.list = nullptr; a.xw = xw; a.xout = nullptr; a.nsteps = n;
+        if (launch_rk2_fwd(a, N, true, false, st)) return 1;
+    }
+    hipLaunchKernelGGL(k_alpha_finish, dim3(nb), dim3(256), 0, st, *f, N, xw, length, accumulate_max, alpha_out);
+    LAUNCHCK();
+    return 0;
+}
+
+__global__ void k_gen_rays(const float* __restrict__ pose, int H, int W, float focal, int64_t n, const int64_t* __restrict__ ids,
+                           float* __restrict__ ro, float* __restrict__ rd) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t pid = ids ? ids[i] : i;
+    const float X = (float)(pid % W), Y = (float)(pid / W);
+    // directions = ((X - W/2)/focal, -(Y - H/2)/focal, -1); ray_d = sum(directions * pose[:3,:3], -1) (camera.py:112-131)
+    const float d0 = (X - W * 0.5f) / focal, d1 = -(Y - H * 0.5f) / focal, d2 = -1.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        rd[3 * i + r] = d0 * pose[4 * r + 0] + d1 * pose[4 * r + 1] + d2 * pose[4 * r + 2];
+        ro[3 * i + r] = pose[4 * r + 3];
+    }
+}
+extern "C" int nvfi_gen_rays(const float* pose3x4, int H, int W, float focal, int64_t n, const int64_t* pixel_ids, float* rays_o, float* rays_d, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_gen_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pose3x4, H, W, focal, n, pixel_ids, rays_o, rays_d);
+    LAUNCHCK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- MFMA layout self test
 __global__ __launch_bounds__(WG_THREADS) void k_selftest(const float* frag, const float* W, const float* X, float* out) {
     // one workgroup, wave 0 only does the maths: out[o][j] = sum_k W[o][k] X[k][j], 128x128 by 128x32

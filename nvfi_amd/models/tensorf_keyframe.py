@@ -594,6 +594,81 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             kw["alphaMask_grid"] = self.alphaMask.gridSize
         return kw
 
+    # ------------------------------------------------------------------ occupancy grid maintenance (next-row f-3)
+    @torch.no_grad()
+    def compute_alpha(self, xyzt_locs, length=0.01, times=None, time_offset=None, transfer=False):
+        """tensorf_keyframe.py:508-537 with per-point times (xyzt_locs[..., 3] raw t, [..., :3] world xyz)."""
+        pts = self.normalize_coord(xyzt_locs[..., :3].reshape(-1, 3))
+        t = xyzt_locs[..., -1:].reshape(-1, 1).float()
+        ts = self.tmax / (self.num_keyframes - 1) if self.num_keyframes > 1 else 1
+        base = torch.zeros_like(t) if transfer else torch.round((t / ts).clamp(0.0, self.num_keyframes - 1)) * ts
+        prev = self.integrate_pos(pts, t, base) if self.use_vel else pts
+        feat = self.compute_densityfeature(torch.cat([prev, self.normalize_time_coord(base)], dim=-1))
+        sigma = self.feature2density(feat, {})
+        return (1 - torch.exp(-sigma * length)).view(xyzt_locs.shape[:-1])
+
+    @torch.no_grad()
+    def getDenseAlpha(self, gridSize=None, transfer=False):
+        """tensorf_keyframe.py:461-499: running maximum of alpha over the 60 frame times i/60 on a dense grid."""
+        L = _lib.lib()
+        dev = self.aabb.device
+        samples = torch.stack(torch.meshgrid(torch.linspace(0, 1, gridSize[0]), torch.linspace(0, 1, gridSize[1]),
+                                             torch.linspace(0, 1, gridSize[2]), indexing="ij"), -1).to(dev)
+        dense_xyz = self.aabb[0] * (1 - samples) + self.aabb[1] * samples
+        flat = dense_xyz.reshape(-1, 3).contiguous()
+        N = flat.shape[0]
+        alpha = torch.zeros(N, device=dev)
+        ws = self._scratch("alpha", 4 * 160000 + 16 * N + 8192, dev)
+        desc = self._desc()
+        for t in (np.linspace(0, 59, 60) / 60):
+            _lib.check(L.nvfi_compute_alpha(C.byref(desc), C.c_int64(N), _lib.ptr(flat), C.c_float(float(np.float32(t))), C.c_int(int(transfer)),
+                                            C.c_float(self._step_host), C.c_int(1), _lib.ptr(alpha), _lib.ptr(ws), C.c_int64(ws.numel()), _stream_ptr()))
+        return alpha.view(gridSize[0], gridSize[1], gridSize[2]), dense_xyz
+
+    @torch.no_grad()
+    def updateAlphaMask(self, gridSize=(200, 200, 200), transfer=False):
+        """tensorf_keyframe.py:379-405: dilate (3^3 max-pool), threshold, build the AlphaGridMask, return the tight aabb."""
+        gridSize = [int(g) for g in gridSize]
+        alpha, dense_xyz = self.getDenseAlpha(gridSize, transfer=transfer)
+        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
+        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+        alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1).view(gridSize[::-1])
+        alpha[alpha >= self.alphaMask_thres] = 1
+        alpha[alpha < self.alphaMask_thres] = 0
+        self.alphaMask = AlphaGridMask(self.aabb.device, self.aabb, alpha)
+        valid_xyz = dense_xyz[alpha > 0.5]
+        return torch.stack((valid_xyz.amin(0), valid_xyz.amax(0)))
+
+    @torch.no_grad()
+    def shrink(self, new_aabb):
+        """tensorf_keyframe.py:407-458: crop every plane to the voxel range of new_aabb."""
+        xyz_min, xyz_max = new_aabb
+        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.gridSize]).amin(0)
+        tl, br = t_l.tolist(), b_r.tolist()
+
+        def crop(space, time):
+            ns, nt = [], []
+            for i in range(3):
+                a, b = self.matModeSpace[i]
+                c = self.matModeTime[i][0]
+                ns.append(nn.Parameter(_cl(space[i].data[..., tl[b]:br[b], tl[a]:br[a]].clone())))
+                nt.append(nn.Parameter(_cl(time[i].data[..., :, tl[c]:br[c]].clone())))
+            return nn.ParameterList(ns), nn.ParameterList(nt)
+
+        self.density_plane_space, self.density_plane_time = crop(self.density_plane_space, self.density_plane_time)
+        self.app_plane_space, self.app_plane_time = crop(self.app_plane_space, self.app_plane_time)
+        if self.alphaMask is not None and not torch.all(self.alphaMask.gridSize == self.gridSize):
+            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
+            correct = torch.zeros_like(new_aabb)
+            correct[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
+            correct[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
+            new_aabb = correct
+        newSize = b_r - t_l
+        self.aabb.copy_(new_aabb)       # the surround-box gate keeps the INITIAL aabb (velocity_field.py:44 quirk)
+        self.update_stepSize([int(v) for v in newSize.tolist()])
+
     # ------------------------------------------------------------------ grid maintenance (next-row f-3; torch ops)
     @torch.no_grad()
     def upsample_volume_grid(self, res_target, new_keyframes):

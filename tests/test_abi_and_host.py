@@ -92,3 +92,20 @@ def test_upsample_keeps_layout_and_matches_reference_formula():
     ref = torch.nn.functional.interpolate(before, size=(24, 26), mode="bilinear", align_corners=True)
     assert torch.allclose(p, ref)
     assert f.gridSize.tolist() == [26, 24, 22] and f._step_host == float(f.stepSize)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """f-4: the reference's checkpoint dictionary layout; planes come back channels_last with identical values"""
+    from nvfi_amd.utils import save_checkpoint, load_checkpoint, load_model_checkpoint
+    from helpers import field_cfg
+    model, meta = make_model("A", device="cpu")
+    opt = torch.optim.Adam(model.get_optparam_groups(), betas=(0.9, 0.99))
+    path = save_checkpoint(str(tmp_path), model, opt, epoch=12)
+    assert path.endswith("model_00012.ckpt")
+    ck = load_checkpoint(str(tmp_path))
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "nvfi_kwarg"}
+    assert ck["model_state_dict"]["nvfi.density_plane_space.0"].is_contiguous()    # logical NCHW on disk
+    m2, _ = load_model_checkpoint(field_cfg(meta), ck, "cpu")
+    for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert m2.nvfi.density_plane_space[0].is_contiguous(memory_format=torch.channels_last)

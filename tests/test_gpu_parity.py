@@ -301,3 +301,56 @@ def test_sh_render(gold):
     from nvfi_amd.models import TensorVMKeyframeTimeKplane
     rgb = TensorVMKeyframeTimeKplane.sh_render(_cuda(gold["sh:view"]), _cuda(gold["sh:feat"])).cpu().numpy()
     np.testing.assert_allclose(rgb, gold["sh:rgb"], rtol=1e-5, atol=1e-6)
+
+
+def test_dense_alpha_and_alpha_mask(fields, models):
+    """f-3: getDenseAlpha / updateAlphaMask / shrink against the oracle composed from its building blocks"""
+    from oracle import oracle as orc
+    model, meta = make_model("A")        # private copy: shrink() replaces the planes
+    f = model.nvfi
+    fs = fields["A"]
+    gs = [int(g) for g in meta["gridSize"]]
+    alpha, dense = f.getDenseAlpha(gs)
+    pts = dense.reshape(-1, 3).cpu().numpy()
+    aabb = fs.aabb
+    pn = ((pts - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1).astype(np.float32)
+    ts = float(meta["tmax"]) / (int(meta["num_keyframes"]) - 1)
+    ref = np.zeros(pts.shape[0], np.float32)
+    for t in (np.linspace(0, 59, 60) / 60)[::7]:        # a subset of the 60 frame times keeps the oracle fast
+        tt = np.full((pts.shape[0], 1), np.float32(t), np.float32)
+        base = (np.round(np.clip(tt / np.float32(ts), 0, int(meta["num_keyframes"]) - 1)) * np.float32(ts)).astype(np.float32)
+        prev = orc.integrate_pos(fs, pn, tt, base)
+        tn = (base * 2 / np.float32(meta["tmax"]) - 1).astype(np.float32)
+        sig = orc.feature2density(fs, orc.density_feature(fs, np.concatenate([prev, tn], 1)))
+        ref = np.maximum(ref, 1 - np.exp(-sig * np.float32(meta["stepSize"])))
+        a1 = f.compute_alpha(torch.cat([dense.reshape(-1, 3), torch.full((pts.shape[0], 1), float(t), device="cuda")], -1), length=float(meta["stepSize"]))
+        np.testing.assert_allclose(a1.cpu().numpy(), 1 - np.exp(-sig * np.float32(meta["stepSize"])), rtol=2e-4, atol=2e-6)
+    got = alpha.reshape(-1).cpu().numpy()
+    assert (got >= ref - 1e-5).all()        # the full 60-time maximum dominates the 9-time subset
+    new_aabb = f.updateAlphaMask(gs)
+    assert f.alphaMask is not None and tuple(f.alphaMask.alpha_volume.shape[-3:]) == (gs[2], gs[1], gs[0])
+    assert (new_aabb[0] >= f.aabb[0] - 1e-5).all() and (new_aabb[1] <= f.aabb[1] + 1e-5).all()
+    before = f.gridSize.tolist()
+    f.shrink(new_aabb)
+    after = f.gridSize.tolist()
+    assert all(a <= b for a, b in zip(after, before))
+    for p in list(f.density_plane_space) + list(f.app_plane_time):
+        assert p.is_contiguous(memory_format=torch.channels_last)
+    f.eval()
+    from nvfi_amd.models import Renderer, Ray
+    o, d = _cuda(np.load(__import__("os").path.join(__import__("conftest").GOLD, "hotpath.npz"))["A:rays_o"]), None
+    out = f(0.3, o, _cuda(np.load(__import__("os").path.join(__import__("conftest").GOLD, "hotpath.npz"))["A:rays_d"]), True)
+    assert torch.isfinite(out[0]).all()
+
+
+def test_device_side_rays(gold):
+    """f-2: nvfi_gen_rays == Camera.get_ray_bundle at the selected pixels"""
+    import bench
+    from nvfi_amd.models import Camera
+    pose = bench.pose_spherical(30.0, -30.0, 4.0).cuda()
+    cam = Camera(pose, 120, 160, 210.0, torch.zeros(1, 1, 3, device="cuda"), 1.0, 8.0)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    rays, ids = cam.sample_rays_device(777, generator=g)
+    yy, xx = ids // 160, ids % 160
+    assert torch.allclose(rays.ray_directions, cam.rays.ray_directions[yy, xx], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(rays.ray_origins, cam.rays.ray_origins[yy, xx])
