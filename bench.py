@@ -137,7 +137,7 @@ class Step:
                 m.vel_loss_weight = None
                 lv = m.get_vel_loss(self.n_pts)
                 self.pde_counters.append(f.last_pde_counters)
-                w = pde_rank_weight(float(f.last_pde_out[1])) if self.world > 1 else 1.0
+                w = pde_rank_weight(float(f.last_pde_n_kept)) if self.world > 1 else 1.0
                 if not isinstance(lv, float):
                     loss = loss + (self.vw * w) * lv
         if self.workload == "cfg3":

@@ -104,11 +104,12 @@ int nvfi_pde_loss(const nvfi_field_desc* f, int64_t P, const float* points, cons
                   void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream);
 
 /* same, with optional diagnostics: kept (device uint8[P]), jac (device float[n_jac][6][4], rows 3..5 zero: the loss
- * does not use the acceleration Jacobian) for the first n_jac kept points */
+ * does not use the acceleration Jacobian) for the first n_jac kept points; host_info (HOST int64[2], optional) receives the kept
+ * count and the number of prefilter net evaluations, which the call knows after its one internal synchronisation */
 int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float* points, const float* t,
                      float loss_scale, float* out, const nvfi_grads* grads,
                      void* workspace, int64_t workspace_bytes, int64_t* counters,
-                     uint8_t* kept_out, float* jac_out, int64_t n_jac, void* stream);
+                     uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream);
 
 /* ---- mask branch of render_pts (models/tensorf_keyframe.py:673-676, 749-753) with the MaskField as train_segm.py:97-102
  *      builds it: 3 -> n_dim x n_layer (ReLU) -> mask_dim, softmax.  Call after nvfi_render_fwd with the same workspace:

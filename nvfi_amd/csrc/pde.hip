@@ -469,7 +469,7 @@ static int ensure_pde_attrs() {
 
 extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, float loss_scale,
                                 float* out, const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters,
-                                uint8_t* kept_out, float* jac_out, int64_t n_jac, void* stream) {
+                                uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (P <= 0) return nvfi_fail(2, "P must be positive");
     if (P >= (1ll << 31) - 256) return nvfi_fail(2, "P too large");
@@ -508,6 +508,7 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
     const int64_t nk = hcnt[PDE_MAX_CLASS];
     int64_t evals = 0;
     for (int c = 0; c < PDE_MAX_CLASS; ++c) evals += 2ll * c * hcnt[c];
+    if (host_info) { host_info[0] = nk; host_info[1] = evals; }   // known on the host already: callers need no second sync
     if (kept_out) HIPCK(hipMemcpyAsync(kept_out, L.flags, (size_t)P, hipMemcpyDeviceToDevice, st));
     if (nk > 0) {
         const float inv_n = 1.f / (float)nk;
@@ -548,7 +549,7 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
 
 extern "C" int nvfi_pde_loss(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, float loss_scale, float* out,
                              const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream) {
-    return nvfi_pde_loss_ex(f, P, points, t, loss_scale, out, grads, workspace, workspace_bytes, counters, nullptr, nullptr, 0, stream);
+    return nvfi_pde_loss_ex(f, P, points, t, loss_scale, out, grads, workspace, workspace_bytes, counters, nullptr, nullptr, 0, nullptr, stream);
 }
 
 // weight gradients of both nets from one chunk's stash

@@ -39,10 +39,10 @@ class NVFi(nn.Module):
         if f.accumulate_grads_inplace and torch.is_grad_enabled() and getattr(self, "vel_loss_weight", None) is not None:
             # fused value + backward: gradients of vel_loss_weight * loss go straight into .grad
             out = f.pde_loss_backward_(points, t, self.vel_loss_weight)
-            if float(out[1]) == 0:
+            if f.last_pde_n_kept == 0:
                 return 0.
             return out[0]
         loss = f.pde_loss(points, t)
-        if float(f.last_pde_out[1]) == 0:   # host sync, as `xyzt.shape[0] == 0` is in the reference
+        if f.last_pde_n_kept == 0:   # known on the host from the call's one internal sync (`xyzt.shape[0] == 0` in the reference)
             return 0.
         return loss

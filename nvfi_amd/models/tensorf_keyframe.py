@@ -125,10 +125,12 @@ class _PdeFn(torch.autograd.Function):
         counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=dev)
         kept = torch.zeros(P, dtype=torch.uint8, device=dev) if field.pde_debug else None
         jac = torch.zeros(field.pde_debug, 6, 4, device=dev) if field.pde_debug else None
+        info = (C.c_int64 * 2)()
         _lib.check(L.nvfi_pde_loss_ex(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(1.0), _lib.ptr(out),
                                       C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters),
-                                      _lib.ptr(kept), _lib.ptr(jac), C.c_int64(int(field.pde_debug)), _stream_ptr()))
+                                      _lib.ptr(kept), _lib.ptr(jac), C.c_int64(int(field.pde_debug)), info, _stream_ptr()))
         field.last_pde_kept, field.last_pde_jac = kept, jac
+        field.last_pde_n_kept = int(info[0])
         field.last_pde_out = out
         field.last_pde_counters = counters
         ctx.save_for_backward(*grads)
@@ -496,9 +498,12 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             grads.append(p.grad)
         G = self._grads_struct_vel(grads)
         counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=points.device)
-        _lib.check(L.nvfi_pde_loss(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(float(weight)), _lib.ptr(out),
-                                   C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
+        info = (C.c_int64 * 2)()
+        _lib.check(L.nvfi_pde_loss_ex(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(float(weight)), _lib.ptr(out),
+                                      C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), None, None, C.c_int64(0), info,
+                                      _stream_ptr()))
         self.last_pde_out, self.last_pde_counters = out, counters
+        self.last_pde_n_kept = int(info[0])     # host value: no extra synchronisation to decide "nothing occupied"
         return out
 
     def _jitter(self, R, device):
