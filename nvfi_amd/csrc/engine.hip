@@ -33,12 +33,15 @@ __global__ void k_pack(PackJobs jobs) {
 // MFMA step st pairs sample 16h+st of both operands.  Each wave is an independent worker that owns MT
 // row tiles x KT column tiles of G for a strided subset of the sample tiles and writes its own slab part;
 // k_wgrad_reduce sums the slabs and un-permutes into the logical gradient tensors.
-template <int MT, int KTW>   // MT: all row tiles of A; KTW: column tiles of B owned by one worker
+#ifndef WGRAD_MT
+#define WGRAD_MT 4        // row tiles per worker for 128-row A images (4: 2 workers/slab, 2 waves/SIMD; 2: 4 workers/slab, 3 waves/SIMD)
+#endif
+#define WGRAD_WAVES (WGRAD_MT == 4 ? 2 : 3)
+template <int MT, int KTW>   // MT: row tiles of A, KTW: column tiles of B owned by one worker
 __device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int lane) {
     const int i = lane & 31, h = lane >> 5;
-    const int KTB = J.b_regs >> 4;
-    const int nparts = KTB / KTW;                 // workers per slab: each owns KTW column tiles (B is transformed once, not per row half)
-    const int kpart = worker % nparts, wslot = worker / nparts;
+    const int kparts = (J.b_regs >> 4) / KTW, mparts = (J.a_regs >> 4) / MT;   // workers per slab = mparts * kparts
+    const int kpart = worker % kparts, mpart = (worker / kparts) % mparts, wslot = worker / (kparts * mparts);
     if (wslot >= J.nslab) return;
     const int a_rows = 2 * J.a_regs, b_rows = 2 * J.b_regs;
     int count = *J.count;
@@ -58,7 +61,7 @@ __device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int 
     // float offset of (row p, sample 16h) inside a tile image: p = 2*reg + hh -> reg*64 + hh*32
     int aoff[MT], boff[KTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { const int p = 32 * mt + i; aoff[mt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
+    for (int mt = 0; mt < MT; ++mt) { const int p = 32 * (mpart * MT + mt) + i; aoff[mt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
 #pragma unroll
     for (int kt = 0; kt < KTW; ++kt) { const int p = 32 * (kpart * KTW + kt) + i; boff[kt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
     for (int item = wslot; item < nitems; item += J.nslab) {
@@ -120,23 +123,23 @@ __device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int 
         for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = 32 * (mpart * MT + mt) + (r & 3) + 8 * (r >> 2) + 4 * h;
                 S[(size_t)row * b_rows + 32 * (kpart * KTW + kt) + i] = acc[mt][kt][r];
             }
         if (kpart == 0) {
             float bs = bsum[mt] + __shfl_xor(bsum[mt], 32);
-            if (h == 0) S[(size_t)a_rows * b_rows + 32 * mt + i] = bs;
+            if (h == 0) S[(size_t)a_rows * b_rows + 32 * (mpart * MT + mt) + i] = bs;
         }
     }
 }
 
-__global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgradJobs jobs) {
+__global__ __launch_bounds__(WG_THREADS, WGRAD_WAVES) void k_wgrad(WgradJobs jobs) {
     const WgradJob& J = jobs.j[blockIdx.y];
     const int worker = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (J.a_regs == 64 && J.b_regs == 64) wgrad_worker<4, 2>(J, worker, lane);        // 2 workers per slab
+    if (J.a_regs == 64 && J.b_regs == 64) wgrad_worker<WGRAD_MT, 2>(J, worker, lane);
     else if (J.a_regs == 16 && J.b_regs == 64) wgrad_worker<1, 2>(J, worker, lane);   // 2 workers per slab
-    else if (J.a_regs == 64 && J.b_regs == 16) wgrad_worker<4, 1>(J, worker, lane);
+    else if (J.a_regs == 64 && J.b_regs == 16) wgrad_worker<WGRAD_MT, 1>(J, worker, lane);
     else if (J.a_regs == 16 && J.b_regs == 32) wgrad_worker<1, 2>(J, worker, lane);
 }
 
@@ -192,7 +195,7 @@ int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st) {
         const WgradJob& J = wj.j[i];
         const bool ok = (J.a_regs == 64 && J.b_regs == 64) || (J.a_regs == 16 && J.b_regs == 64) || (J.a_regs == 64 && J.b_regs == 16) || (J.a_regs == 16 && J.b_regs == 32);
         if (!ok) return nvfi_fail(5, "k_wgrad: unsupported tile shape a_regs=%d b_regs=%d", J.a_regs, J.b_regs);
-        const int w = J.nslab * (J.b_regs == 64 ? 2 : 1);
+        const int w = J.nslab * (J.b_regs == 64 ? 2 : 1) * (J.a_regs == 64 ? 4 / WGRAD_MT : 1);
         nworkers = w > nworkers ? w : nworkers;
     }
     ProfScope ps(PK_WGRAD, st);
