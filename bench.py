@@ -120,7 +120,8 @@ class Step:
     def __call__(self):
         from nvfi_amd.dist import pde_rank_weight
         m, f = self.m, self.m.nvfi
-        m.train()
+        if not m.training:
+            m.train()
         self.bucket.zero()
         loss = 0
         # the PDE term goes first: its one host sync (kept count) then overlaps with nothing that is already queued,

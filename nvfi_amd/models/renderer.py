@@ -31,8 +31,10 @@ class Renderer(nn.Module):
 
     def render(self, t, rays, white_background=False, mode="train", transfer_vel=False):
         if mode == "train":
-            self.tensorf.train()
+            if not self.tensorf.training:     # (the reference calls .train()/.eval() unconditionally; the recursion is pure host cost)
+                self.tensorf.train()
             return self.forward(t, rays, white_background)
-        self.tensorf.eval()
+        if self.tensorf.training:
+            self.tensorf.eval()
         with torch.no_grad():
             return self.forward(t, rays, white_background, transfer_vel=transfer_vel)
