@@ -109,6 +109,8 @@ class Step:
         self.pde_counters = []
         self.fused_regs = True
         self.inplace = True
+        from nvfi_amd.dist import PdeGradStage
+        self.pde_stage = PdeGradStage(model.nvfi._pde_params()) if world > 1 else None
         model.nvfi.accumulate_grads_inplace = True   # .grad tensors are views of the GradBucket's flat buffer
 
     def rays(self):
@@ -128,19 +130,17 @@ class Step:
         # and the renders + backward + Adam that follow are launched without any host wait
         if self.workload == "cfg3":
             self.vw *= self.lr_factor
-            if self.world == 1 and self.inplace:
-                # same term, fused: d(vw * loss_vel) is accumulated into .grad by the PDE kernels
-                m.vel_loss_weight = self.vw
-                lv = m.get_vel_loss(self.n_pts)
-                self.pde_counters.append(f.last_pde_counters)
-                self.last_lv = lv
-            else:
-                m.vel_loss_weight = None
-                lv = m.get_vel_loss(self.n_pts)
-                self.pde_counters.append(f.last_pde_counters)
-                w = pde_rank_weight(float(f.last_pde_n_kept)) if self.world > 1 else 1.0
-                if not isinstance(lv, float):
-                    loss = loss + (self.vw * w) * lv
+            # same term as `loss += vw * get_vel_loss()`, fused: d(vw * loss_vel) is accumulated by the PDE kernels - straight into
+            # .grad on one GPU, through a small staging buffer re-weighted by W*n_r/sum(n_r) (device-side) on several
+            m.vel_loss_weight = self.vw
+            if self.world > 1:
+                self.pde_stage.zero()
+                m.vel_grad_targets = self.pde_stage.views
+            lv = m.get_vel_loss(self.n_pts)
+            self.pde_counters.append(f.last_pde_counters)
+            if self.world > 1:
+                self.pde_stage.commit(f.last_pde_n_kept)
+            self.last_lv = lv
         if self.workload == "cfg3":
             i = int(self.rng.integers(0, 46))
             while i % 3 == 0:                       # frame times i/60; keyframes every 0.05 = 3/60

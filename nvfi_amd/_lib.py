@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "csrc", "libnvfi_hip.so")
+SO = os.environ.get("NVFI_LIB", os.path.join(HERE, "csrc", "libnvfi_hip.so"))   # NVFI_LIB: alternative build (experiments)
 fp = C.c_void_p
 
 NVFI_TRAIN, NVFI_WHITE_BG, NVFI_TRANSFER, NVFI_WANT_MASK = 1, 2, 4, 8

@@ -8,8 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["engine.hip", "vel.hip", "render.hip", "pde.hip", "regs.hip", "abi.hip"]
 HEADERS = ["engine.h", "common.h", "vel.h", "render.h", "pde.h", os.path.join("..", "..", "include", "nvfi_hip.h")]
-SO = os.path.join(CSRC, "libnvfi_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+SO = os.environ.get("NVFI_BUILD_SO", os.path.join(CSRC, "libnvfi_hip.so"))   # experiments build a second library elsewhere
+OBJDIR = os.environ.get("NVFI_BUILD_OBJDIR", CSRC)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"] + os.environ.get("NVFI_EXTRA_FLAGS", "").split()
 
 
 def _newer(a, b):
@@ -24,7 +25,7 @@ def build(force=False, verbose=False):
     todo = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
             todo.append((src, obj))

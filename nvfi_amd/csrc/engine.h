@@ -124,6 +124,9 @@ __device__ __forceinline__ void stage_frag(float* lds_w, float* lds_b, const flo
                                            const float* __restrict__ bfrag, int nb) {
     const float4* src = reinterpret_cast<const float4*>(frag);
     float4* dst = reinterpret_cast<float4*>(lds_w);
+#ifdef NVFI_EXP_NOSTAGE   // timing experiment only: results are garbage
+    if (nfloats < 0)
+#endif
     for (int i = threadIdx.x; i < (nfloats >> 2); i += WG_THREADS) dst[i] = src[i];
     if (threadIdx.x < nb) lds_b[threadIdx.x] = bfrag ? bfrag[threadIdx.x] : 0.f;
 }

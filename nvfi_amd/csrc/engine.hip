@@ -108,12 +108,21 @@ __device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int 
                     for (int v = 0; v < 16; ++v) bsum[m0 + mm] += a[mm][v];
                 }
             }
+#ifdef NVFI_EXP_WGRAD_NOMFMA   // timing experiment: loads only (keep the operands alive)
+#pragma unroll
+            for (int mm = 0; mm < MG; ++mm)
+#pragma unroll
+                for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) acc[m0 + mm][kt][st] += a[mm][st] * b[kt][st];
+#else
 #pragma unroll
             for (int st = 0; st < 16; ++st)
 #pragma unroll
                 for (int mm = 0; mm < MG; ++mm)
 #pragma unroll
                     for (int kt = 0; kt < KTW; ++kt) acc[m0 + mm][kt] = MFMA32(a[mm][st], b[kt][st], acc[m0 + mm][kt]);
+#endif
         }
     }
     float* S = J.slabs + (size_t)wslot * ((size_t)a_rows * b_rows + a_rows);

@@ -61,3 +61,36 @@ def shard_range(n, rank, world):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+class PdeGradStage:
+    """Small flat buffer that receives the PDE-term gradients of the two velocity nets, so that they can be re-weighted by
+    W * n_r / sum_r n_r (computed ON DEVICE from an all-reduced kept count: no host sync) before entering the main bucket."""
+
+    def __init__(self, pde_params):
+        self.params = list(pde_params)
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def commit(self, n_kept_local):
+        """p.grad += flat_view * (W * n_r / sum_r n_r)"""
+        w = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            n = torch.tensor([float(n_kept_local)], dtype=torch.float32, device=self.flat.device)
+            tot = n.clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            w = dist.get_world_size() * n / torch.clamp(tot, min=1.0)
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            if w is None:
+                p.grad.add_(v)
+            else:
+                p.grad.addcmul_(v, w.expand_as(v))

@@ -38,7 +38,7 @@ class NVFi(nn.Module):
             t = torch.rand(int(n_pts), 1, device=f.aabb.device)
         if f.accumulate_grads_inplace and torch.is_grad_enabled() and getattr(self, "vel_loss_weight", None) is not None:
             # fused value + backward: gradients of vel_loss_weight * loss go straight into .grad
-            out = f.pde_loss_backward_(points, t, self.vel_loss_weight)
+            out = f.pde_loss_backward_(points, t, self.vel_loss_weight, getattr(self, "vel_grad_targets", None))
             if f.last_pde_n_kept == 0:
                 return 0.
             return out[0]

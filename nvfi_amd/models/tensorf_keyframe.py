@@ -479,9 +479,10 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         return _PdeFn.apply(self, points, t, *self._pde_params())
 
     @torch.no_grad()
-    def pde_loss_backward_(self, points, t, weight=1.0):
+    def pde_loss_backward_(self, points, t, weight=1.0, grad_targets=None):
         """Fused value + backward of `weight * get_vel_loss`: the gradient is ACCUMULATED into the .grad of both velocity
-        nets; returns the device tensor [loss, n_kept, sum div^2, sum transport^2] (un-weighted loss)."""
+        nets (or into `grad_targets`, 24 tensors in _pde_params() order); returns the device tensor
+        [loss, n_kept, sum div^2, sum transport^2] (un-weighted loss)."""
         L = _lib.lib()
         points = points.reshape(-1, 3).contiguous().float()
         t = t.reshape(-1).contiguous().float()
@@ -492,10 +493,13 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         ws = self._scratch("pde", nbytes.value, points.device)
         out = torch.zeros(4, device=points.device)
         grads = []
-        for p in self._pde_params():
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            grads.append(p.grad)
+        if grad_targets is not None:
+            grads = list(grad_targets)
+        else:
+            for p in self._pde_params():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                grads.append(p.grad)
         G = self._grads_struct_vel(grads)
         counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=points.device)
         info = (C.c_int64 * 2)()

@@ -16,7 +16,7 @@ def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as orc
-    from nvfi_amd.dist import GradBucket, pde_rank_weight, shard_range
+    from nvfi_amd.dist import GradBucket, PdeGradStage, pde_rank_weight, shard_range
     orc.set_threads(2)
     gold = np.load(os.path.join(GOLD, "hotpath.npz"))
     fs = orc.FieldSpec.from_npz(os.path.join(GOLD, "field_A.npz"))
@@ -45,9 +45,13 @@ def _worker(rank, world, port, out):
     plo, phi = shard_range(P, rank, world)
     pde = orc.pde_loss(fs, gold["A:pde:points"][plo:phi], gold["A:pde:t"][plo:phi])
     w = pde_rank_weight(pde["n_kept"])
+    # the PDE gradients enter through the staging buffer (device-side W*n_r/sum(n_r) weighting), as bench.py does
+    stage = PdeGradStage([params[2]])
     with torch.no_grad():
+        stage.views[0].copy_(torch.from_numpy(pde["grads"][names[2]]))
         for p, nm in zip(params, names):
-            p.grad += torch.from_numpy(g[nm] + w * pde["grads"][nm])
+            p.grad += torch.from_numpy(g[nm])
+    stage.commit(pde["n_kept"])
     bucket.all_reduce_mean()
     if rank == 0:
         np.savez(out, **{nm: p.grad.detach().contiguous().numpy() for nm, p in zip(names, params)}, w=w, nk=pde["n_kept"])
