@@ -33,11 +33,45 @@ __global__ void k_pack(PackJobs jobs) {
 // MFMA step st pairs sample 16h+st of both operands.  Each wave is an independent worker that owns MT
 // row tiles x KT column tiles of G for a strided subset of the sample tiles and writes its own slab part;
 // k_wgrad_reduce sums the slabs and un-permutes into the logical gradient tensors.
+//
+// Measured facts that shape the loop (tools/probes/):
+//  * the kernel is bound by the LATENCY of the stash reads, not their bandwidth or pattern (cache-hot and fully
+//    coalesced variants run at the same speed), so the operands of the next item must be in flight while MFMAs run;
+//  * a wave does not issue its own VALU instructions in the shadow of its own MFMAs (64 cycles per 32x32x2 with nothing
+//    between, +5 cycles per interleaved VALU instruction; a second wave on the SIMD hides only half of that), so the
+//    non-MFMA work per item is kept minimal: wave-uniform addressing in SGPRs, activations only on the B side.
+// One wave per SIMD with the whole 512-register file: two complete operand sets alternate (explicitly, so the register
+// allocator cannot merge them) - while the 128 MFMAs of one item read one set, the loads of the next item fill the other.
+// (Quarter-tile rolling refills at 2 waves/SIMD were tried: 4x2 tiles spill, 2x2 tiles were 20 % slower overall.)
 #ifndef WGRAD_MT
-#define WGRAD_MT 4        // row tiles per worker for 128-row A images (4: 2 workers/slab, 2 waves/SIMD; 2: 4 workers/slab, 3 waves/SIMD)
+#define WGRAD_MT 4        // row tiles per worker for 128-row A images
 #endif
-#define WGRAD_WAVES (WGRAD_MT == 4 ? 2 : 3)
-template <int MT, int KTW>   // MT: row tiles of A, KTW: column tiles of B owned by one worker
+template <int MT, int KTW, bool TAN>
+struct WgradOps { float4 a[MT][4]; float4 b[KTW][4]; float4 b2[TAN ? KTW : 1][4]; };
+
+template <int MT, int KTW, bool TAN>
+__device__ __forceinline__ void wgrad_load(WgradOps<MT, KTW, TAN>& o, const WgradJob& J, int item, int ntiles, const int (&aoff)[MT], const int (&boff)[KTW]) {
+    const int rep = item / ntiles, tile = item - rep * ntiles;
+    const float* At = J.A + (size_t)rep * J.a_rep_stride + (size_t)tile * J.a_tile_stride;
+    const float* Bt = J.B + (size_t)rep * J.b_rep_stride + (size_t)tile * J.b_tile_stride;
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o.b[kt][v] = *reinterpret_cast<const float4*>(Bt + boff[kt] + 4 * v);
+    if (TAN) {
+        const float* B2t = J.B2 + (size_t)rep * J.b2_rep_stride + (size_t)tile * J.b_tile_stride;
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) o.b2[kt][v] = *reinterpret_cast<const float4*>(B2t + boff[kt] + 4 * v);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o.a[mt][v] = *reinterpret_cast<const float4*>(At + aoff[mt] + 4 * v);
+}
+
+template <int MT, int KTW, int BM>   // MT: row tiles of A, KTW: column tiles of B owned by one worker, BM: how B is formed from the stash
 __device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int lane) {
     const int i = lane & 31, h = lane >> 5;
     const int kparts = (J.b_regs >> 4) / KTW, mparts = (J.a_regs >> 4) / MT;   // workers per slab = mparts * kparts
@@ -48,8 +82,9 @@ __device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int 
     int ntiles = (count + TILE - 1) / TILE;
     if (ntiles > J.cap_tiles) ntiles = J.cap_tiles;
     const int nitems = J.nrep * ntiles;
+    constexpr bool tan = BM == BM_SILU_TAN || BM == BM_RELU_TAN;
     f32x16 acc[MT][KTW];
-    float bsum[MT];
+    float bsum[MT];            // bias sums (column-part worker 0 only)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         bsum[mt] = 0.f;
@@ -64,65 +99,67 @@ __device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int 
     for (int mt = 0; mt < MT; ++mt) { const int p = 32 * (mpart * MT + mt) + i; aoff[mt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
 #pragma unroll
     for (int kt = 0; kt < KTW; ++kt) { const int p = 32 * (kpart * KTW + kt) + i; boff[kt] = (p >> 1) * 64 + (p & 1) * 32 + 16 * h; }
-    for (int item = wslot; item < nitems; item += J.nslab) {
-        const int rep = item / ntiles, tile = item - rep * ntiles;
-        const float* At = J.A + (size_t)rep * J.a_rep_stride + (size_t)tile * J.a_tile_stride;
-        const float* Bt = J.B + (size_t)rep * J.b_rep_stride + (size_t)tile * J.b_tile_stride;
-        const float* B2t = J.B2 ? J.B2 + (size_t)rep * J.b2_rep_stride + (size_t)tile * J.b_tile_stride : nullptr;
+    auto consume = [&](const WgradOps<MT, KTW, tan>& cur) {
         float b[KTW][16];
 #pragma unroll
         for (int kt = 0; kt < KTW; ++kt) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float4 t4 = *reinterpret_cast<const float4*>(Bt + boff[kt] + 4 * v);
+                const float4 t4 = cur.b[kt][v];
                 float z[4] = {t4.x, t4.y, t4.z, t4.w};
-                if (J.bmode == BM_SILU) {
+                if (BM == BM_SILU) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) z[c] = act_f<1>(z[c]);
-                } else if (J.bmode == BM_RELU) {
+                } else if (BM == BM_RELU) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) z[c] = act_f<0>(z[c]);
-                } else if (J.bmode == BM_SILU_TAN || J.bmode == BM_RELU_TAN) {
-                    const float4 u4 = *reinterpret_cast<const float4*>(B2t + boff[kt] + 4 * v);
+                } else if (tan) {
+                    const float4 u4 = cur.b2[kt][v];
                     const float z2[4] = {u4.x, u4.y, u4.z, u4.w};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) z[c] = (J.bmode == BM_SILU_TAN ? act_d1<1>(z[c]) : act_d1<0>(z[c])) * z2[c];
+                    for (int c = 0; c < 4; ++c) z[c] = (BM == BM_SILU_TAN ? act_d1<1>(z[c]) : act_d1<0>(z[c])) * z2[c];
                 }
                 b[kt][4 * v] = z[0]; b[kt][4 * v + 1] = z[1]; b[kt][4 * v + 2] = z[2]; b[kt][4 * v + 3] = z[3];
             }
         }
-        // A operand in groups of two row tiles (keeps the live set under 256 VGPRs at 2 waves/SIMD)
-        constexpr int MG = MT >= 2 ? 2 : 1;
+        if (kpart == 0) {
 #pragma unroll
-        for (int m0 = 0; m0 < MT; m0 += MG) {
-            float a[MG][16];
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mm = 0; mm < MG; ++mm) {
+                for (int v = 0; v < 4; ++v) bsum[mt] += (cur.a[mt][v].x + cur.a[mt][v].y) + (cur.a[mt][v].z + cur.a[mt][v].w);
+        }
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(At + aoff[m0 + mm] + 4 * v);
-                    a[mm][4 * v] = t4.x; a[mm][4 * v + 1] = t4.y; a[mm][4 * v + 2] = t4.z; a[mm][4 * v + 3] = t4.w;
-                }
-                if (kpart == 0) {
+        for (int st = 0; st < 16; ++st)
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) bsum[m0 + mm] += a[mm][v];
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                const float4 a4 = cur.a[mt][st >> 2];
+                const float av = (st & 3) == 0 ? a4.x : (st & 3) == 1 ? a4.y : (st & 3) == 2 ? a4.z : a4.w;
+#pragma unroll
+                for (int kt = 0; kt < KTW; ++kt) acc[mt][kt] = MFMA32(av, b[kt][st], acc[mt][kt]);
             }
-#ifdef NVFI_EXP_WGRAD_NOMFMA   // timing experiment: loads only (keep the operands alive)
-#pragma unroll
-            for (int mm = 0; mm < MG; ++mm)
-#pragma unroll
-                for (int kt = 0; kt < KTW; ++kt)
-#pragma unroll
-                    for (int st = 0; st < 16; ++st) acc[m0 + mm][kt][st] += a[mm][st] * b[kt][st];
-#else
-#pragma unroll
-            for (int st = 0; st < 16; ++st)
-#pragma unroll
-                for (int mm = 0; mm < MG; ++mm)
-#pragma unroll
-                    for (int kt = 0; kt < KTW; ++kt) acc[m0 + mm][kt] = MFMA32(a[mm][st], b[kt][st], acc[m0 + mm][kt]);
-#endif
+    };
+    WgradOps<MT, KTW, tan> o0, o1;
+    if (wslot < nitems) {
+        // prefetches are unconditional (the last one re-reads a valid item) so that the loop is straight-line code and the
+        // compiler's vmcnt bookkeeping leaves exactly the newest set in flight
+        const int last = nitems - 1;
+        int item = wslot;
+        wgrad_load<MT, KTW, tan>(o0, J, item, ntiles, aoff, boff);
+#pragma unroll 1
+        while (true) {
+            int ni = item + J.nslab;
+            wgrad_load<MT, KTW, tan>(o1, J, ni < last ? ni : last, ntiles, aoff, boff);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (the scheduler would sink it to save registers)
+            consume(o0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ni >= nitems) break;
+            item = ni; ni = item + J.nslab;
+            wgrad_load<MT, KTW, tan>(o0, J, ni < last ? ni : last, ntiles, aoff, boff);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(o1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ni >= nitems) break;
+            item = ni;
         }
     }
     float* S = J.slabs + (size_t)wslot * ((size_t)a_rows * b_rows + a_rows);
@@ -136,20 +173,29 @@ __device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int 
                 S[(size_t)row * b_rows + 32 * (kpart * KTW + kt) + i] = acc[mt][kt][r];
             }
         if (kpart == 0) {
-            float bs = bsum[mt] + __shfl_xor(bsum[mt], 32);
+            float bs = bsum[mt];
+            bs += __shfl_xor(bs, 32);
             if (h == 0) S[(size_t)a_rows * b_rows + 32 * (mpart * MT + mt) + i] = bs;
         }
     }
 }
 
-__global__ __launch_bounds__(WG_THREADS, WGRAD_WAVES) void k_wgrad(WgradJobs jobs) {
+__global__ __launch_bounds__(WG_THREADS, 1) void k_wgrad(WgradJobs jobs) {
     const WgradJob& J = jobs.j[blockIdx.y];
-    const int worker = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int worker = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: item addressing stays in SGPRs
     const int lane = threadIdx.x & 63;
-    if (J.a_regs == 64 && J.b_regs == 64) wgrad_worker<WGRAD_MT, 2>(J, worker, lane);
-    else if (J.a_regs == 16 && J.b_regs == 64) wgrad_worker<1, 2>(J, worker, lane);   // 2 workers per slab
-    else if (J.a_regs == 64 && J.b_regs == 16) wgrad_worker<WGRAD_MT, 1>(J, worker, lane);
-    else if (J.a_regs == 16 && J.b_regs == 32) wgrad_worker<1, 2>(J, worker, lane);
+#define WGRAD_MODES(MT_, KT_)                                                             \
+    switch (J.bmode) {                                                                    \
+        case BM_RAW: wgrad_worker<MT_, KT_, BM_RAW>(J, worker, lane); break;              \
+        case BM_SILU: wgrad_worker<MT_, KT_, BM_SILU>(J, worker, lane); break;            \
+        case BM_RELU: wgrad_worker<MT_, KT_, BM_RELU>(J, worker, lane); break;            \
+        case BM_SILU_TAN: wgrad_worker<(MT_ > 2 ? 2 : MT_), KT_, BM_SILU_TAN>(J, worker, lane); break;    \
+        default: wgrad_worker<(MT_ > 2 ? 2 : MT_), KT_, BM_RELU_TAN>(J, worker, lane); break;             \
+    }
+    if (J.a_regs == 64 && J.b_regs == 64) { WGRAD_MODES(WGRAD_MT, 2) }
+    else if (J.a_regs == 16 && J.b_regs == 64) { WGRAD_MODES(1, 2) }   // 2 workers per slab
+    else if (J.a_regs == 64 && J.b_regs == 16) wgrad_worker<WGRAD_MT, 1, BM_RAW>(J, worker, lane);
+    else if (J.a_regs == 16 && J.b_regs == 32) wgrad_worker<1, 2, BM_RAW>(J, worker, lane);
 }
 
 // 64 G entries per workgroup; 4 threads per entry each sum a quarter of the slabs
@@ -199,17 +245,42 @@ int launch_pack(const PackJobs& jobs, hipStream_t st) {
 }
 int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st) {
     if (wj.n == 0) return 0;
-    int nworkers = 0;
-    for (int i = 0; i < wj.n; ++i) {
-        const WgradJob& J = wj.j[i];
+    // Each job's nslab is the capacity of its slab buffer.
+    // NVFI_WGRAD_WAVES caps the number of workers and shares them between the jobs in proportion to their work; unset, every
+    // job gets as many slabs as its buffer holds (measured best: many short workers balance the ragged job mix).
+    static int resident = 0;
+    if (!resident) {
+        const char* e = getenv("NVFI_WGRAD_WAVES");
+        resident = (e && atoi(e) > 0) ? atoi(e) : (1 << 28);
+    }
+    WgradJobs bj = wj; ReduceJobs br = rj;
+    double cost[MAX_WGRAD_JOBS], total = 0.0; int wps[MAX_WGRAD_JOBS];
+    for (int i = 0; i < bj.n; ++i) {
+        const WgradJob& J = bj.j[i];
         const bool ok = (J.a_regs == 64 && J.b_regs == 64) || (J.a_regs == 16 && J.b_regs == 64) || (J.a_regs == 64 && J.b_regs == 16) || (J.a_regs == 16 && J.b_regs == 32);
         if (!ok) return nvfi_fail(5, "k_wgrad: unsupported tile shape a_regs=%d b_regs=%d", J.a_regs, J.b_regs);
-        const int w = J.nslab * (J.b_regs == 64 ? 2 : 1) * (J.a_regs == 64 ? 4 / WGRAD_MT : 1);
+        const bool tanm = J.bmode == BM_SILU_TAN || J.bmode == BM_RELU_TAN;   // tangent jobs carry a second B stream: 2 row tiles per worker
+        const int mt = J.a_regs == 64 ? (tanm ? 2 : WGRAD_MT) : 1, ktw = J.b_regs == 16 ? 1 : 2;
+        wps[i] = ((J.a_regs >> 4) / mt) * ((J.b_regs >> 4) / ktw);
+        cost[i] = (double)(J.nrep > 0 ? J.nrep : 1) * wps[i] * (mt + ktw * (J.B2 ? 2 : 1));
+        total += cost[i];
+    }
+    int nworkers = 0;
+    for (int i = 0; i < bj.n; ++i) {
+        WgradJob& J = bj.j[i];
+        int ns = (int)((double)resident * cost[i] / total / wps[i]);
+        ns = ns < 1 ? 1 : ns; ns = ns > J.nslab ? J.nslab : ns;
+        for (int k = 0; k < br.n; ++k) {
+            if (br.j[k].slabs == J.slabs) br.j[k].nslab = ns;
+            if (br.j[k].slabs2 == J.slabs) br.j[k].nslab2 = ns;
+        }
+        J.nslab = ns;
+        const int w = ns * wps[i];
         nworkers = w > nworkers ? w : nworkers;
     }
     ProfScope ps(PK_WGRAD, st);
-    hipLaunchKernelGGL(k_wgrad, dim3((nworkers + 3) / 4, wj.n), dim3(WG_THREADS), 0, st, wj);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(260, rj.n), dim3(256), 0, st, rj);
+    hipLaunchKernelGGL(k_wgrad, dim3((nworkers + 3) / 4, bj.n), dim3(WG_THREADS), 0, st, bj);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(260, br.n), dim3(256), 0, st, br);
     LAUNCHCK();
     return 0;
 }

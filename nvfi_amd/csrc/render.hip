@@ -412,11 +412,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
         const float fr = (float)(1 << k);
         const float pc = c == 0 ? q.x : (c == 1 ? q.y : q.z);
         const float vc = c == 0 ? vd[0] : (c == 1 ? vd[1] : vd[2]);
-        float sn, cs;
-        sincosf(pc * fr, &sn, &cs);
-        scr[e * 256 + threadIdx.x] = h ? cs : sn;
-        sincosf(vc * fr, &sn, &cs);
-        scr[(18 + e) * 256 + threadIdx.x] = h ? cs : sn;
+        scr[e * 256 + threadIdx.x] = trig_sel(pc * fr, h);
+        scr[(18 + e) * 256 + threadIdx.x] = trig_sel(vc * fr, h);
     }
     // basis_mat: 48 -> 32 (no bias); its fragment occupies LDS rows below SCR_OFF
     __syncthreads();
@@ -702,7 +699,7 @@ __global__ __launch_bounds__(256) void k_plane_scatter(ScatterArgs a) {
 // and are flushed once; space planes keep the coalesced global atomics.  A workgroup handles 24 channels starting at c0
 // of planes with CT channels per texel (density: CT=24, one group; appearance: CT=48, two groups on blockIdx.y).
 template <int CT>
-__global__ __launch_bounds__(512) void k_plane_scatter_lds(ScatterArgs a) {
+__global__ __launch_bounds__(1024) void k_plane_scatter_lds(ScatterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];   // [3 planes][2 rows][gmax][24]
     const nvfi_field_desc& f = a.f;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
@@ -720,52 +717,74 @@ __global__ __launch_bounds__(512) void k_plane_scatter_lds(ScatterArgs a) {
     const int ch = lane >> 1, dx0 = lane & 1;
     const bool lane_on = lane < 48;
     const int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * nwv + wv), wave_total = gridDim.x * nwv;
+    // two samples per trip: the dependent chain list -> position -> taps is pure latency, so both chains are issued together
+    constexpr int U = 2;
+    // each wave walks a contiguous run of the (ray-ordered) list: neighbouring samples share texels, so their atomics
+    // stay in one wave / one XCD's L2 instead of bouncing the same lines between XCDs
+#ifdef NVFI_EXP_SCATTER_STRIDED
+    const int i_lo = wave_global, i_hi = count, i_step = U * wave_total, u_step = wave_total;
+#else
+    const int chunk = (count + wave_total - 1) / wave_total;
+    const int i_lo = wave_global * chunk, i_hi = min(count, i_lo + chunk), i_step = U, u_step = 1;
+#endif
 #pragma unroll 1
-    for (int i = wave_global; i < count; i += wave_total) {
-        const int n = __builtin_amdgcn_readfirstlane(a.list[i]);
-        const float4 q = a.xw[n];
-        Bl b[6];
-        plane_setups(f, q.x, q.y, q.z, a.tn, b);
-        float gch;
-        if (CT == 24) gch = a.gxpre[n];
-        else gch = lane_on ? a.gg[(size_t)i * 48 + c0 + ch] : 0.f;
-        float val[6];
+    for (int i0 = i_lo; i0 < i_hi; i0 += i_step) {
+        float4 q[U]; float gch[U]; bool on[U]; float o[U][6];
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
-            const bool my0 = dx0 ? b[p].m1 : b[p].m0, my1 = dx0 ? b[p].m3 : b[p].m2;
-            const float wx = dx0 ? b[p].w : b[p].e;
-            const size_t o0 = (size_t)(b[p].base + dx0) * CT + c0 + ch, o1 = o0 + (size_t)b[p].W * CT;
-            const float v0 = (lane_on && my0) ? pl[p][o0] : 0.f, v1 = (lane_on && my1) ? pl[p][o1] : 0.f;
-            const float part = v0 * (wx * b[p].s) + v1 * (wx * b[p].n);
-            val[p] = part + dpp_xor1(part);
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * u_step;
+            on[u] = i < i_hi;
+            const int n = __builtin_amdgcn_readfirstlane(a.list[on[u] ? i : i0]);
+            q[u] = a.xw[n];
+            if (CT == 24) gch[u] = a.gxpre[n];
+            else gch[u] = (lane_on && on[u]) ? a.gg[(size_t)i * 48 + c0 + ch] : 0.f;
         }
-        float L[6], Rr[6];
-        L[0] = gch;
 #pragma unroll
-        for (int p = 1; p < 6; ++p) L[p] = L[p - 1] * val[p - 1];
-        Rr[5] = 1.f;
+        for (int u = 0; u < U; ++u) {
+            Bl b[6];
+            plane_setups(f, q[u].x, q[u].y, q[u].z, a.tn, b);
+            float val[6];
 #pragma unroll
-        for (int p = 4; p >= 0; --p) Rr[p] = Rr[p + 1] * val[p + 1];
-        if (lane_on) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {       // space planes: coalesced global atomics
-                if (!gp[p]) continue;
-                const float o = L[p] * Rr[p];
+            for (int p = 0; p < 6; ++p) {
                 const bool my0 = dx0 ? b[p].m1 : b[p].m0, my1 = dx0 ? b[p].m3 : b[p].m2;
                 const float wx = dx0 ? b[p].w : b[p].e;
                 const size_t o0 = (size_t)(b[p].base + dx0) * CT + c0 + ch, o1 = o0 + (size_t)b[p].W * CT;
-                if (my0) atomicAdd(gp[p] + o0, (wx * b[p].s) * o);
-                if (my1) atomicAdd(gp[p] + o1, (wx * b[p].n) * o);
+                const float v0 = (lane_on && my0) ? pl[p][o0] : 0.f, v1 = (lane_on && my1) ? pl[p][o1] : 0.f;
+                const float part = v0 * (wx * b[p].s) + v1 * (wx * b[p].n);
+                val[p] = part + dpp_xor1(part);
+            }
+            float L[6], Rr[6];
+            L[0] = gch[u];
+#pragma unroll
+            for (int p = 1; p < 6; ++p) L[p] = L[p - 1] * val[p - 1];
+            Rr[5] = 1.f;
+#pragma unroll
+            for (int p = 4; p >= 0; --p) Rr[p] = Rr[p + 1] * val[p + 1];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) o[u][p] = L[p] * Rr[p];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!(lane_on && on[u])) continue;
+            Bl b[6];
+            plane_setups(f, q[u].x, q[u].y, q[u].z, a.tn, b);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {       // space planes: coalesced global atomics
+                if (!gp[p]) continue;
+                const bool my0 = dx0 ? b[p].m1 : b[p].m0, my1 = dx0 ? b[p].m3 : b[p].m2;
+                const float wx = dx0 ? b[p].w : b[p].e;
+                const size_t o0 = (size_t)(b[p].base + dx0) * CT + c0 + ch, o1 = o0 + (size_t)b[p].W * CT;
+                if (my0) atomicAdd(gp[p] + o0, (wx * b[p].s) * o[u][p]);
+                if (my1) atomicAdd(gp[p] + o1, (wx * b[p].n) * o[u][p]);
             }
 #pragma unroll
             for (int p = 3; p < 6; ++p) {       // time planes: workgroup-private LDS rows (y0, y0+1 are call constants)
-                const float o = L[p] * Rr[p];
                 const bool my0 = dx0 ? b[p].m1 : b[p].m0, my1 = dx0 ? b[p].m3 : b[p].m2;
                 const float wx = dx0 ? b[p].w : b[p].e;
                 const int x = b[p].base - a.y0 * b[p].W + dx0;        // column inside the row
                 float* r0 = acc_lds + ((size_t)((p - 3) * 2 + 0) * gmax + x) * 24 + ch;
-                if (my0) atomicAdd(r0, (wx * b[p].s) * o);
-                if (my1) atomicAdd(r0 + (size_t)gmax * 24, (wx * b[p].n) * o);
+                if (my0) atomicAdd(r0, (wx * b[p].s) * o[u][p]);
+                if (my1) atomicAdd(r0 + (size_t)gmax * 24, (wx * b[p].n) * o[u][p]);
             }
         }
     }
@@ -788,6 +807,23 @@ __global__ __launch_bounds__(512) void k_plane_scatter_lds(ScatterArgs a) {
     }
 }
 
+// Side stream for the plane-gradient scatters: they are bound by L2 atomics and leave the MFMA pipes idle, so the backward forks
+// them next to the weight-gradient / RK2-adjoint kernels and joins before returning (NVFI_SIDE_STREAM=0: everything in order).
+struct SideStream {
+    hipStream_t s = nullptr; hipEvent_t fork[2] = {nullptr, nullptr}, join = nullptr; int state = -1;
+    int get() {
+        if (state >= 0) return state;
+        const char* e = getenv("NVFI_SIDE_STREAM");
+        state = (e && atoi(e) == 0) ? 0 : 1;
+        if (state) {
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) state = 0;
+            for (int i = 0; i < 2 && state; ++i) if (hipEventCreateWithFlags(&fork[i], hipEventDisableTiming) != hipSuccess) state = 0;
+            if (state && hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) state = 0;
+        }
+        return state;
+    }
+};
+static SideStream g_side;
 static int scatter_mask() { static int m = -1; if (m < 0) { const char* e = getenv("NVFI_SCATTER_MASK"); m = e ? atoi(e) : 63; } return m; }
 
 
@@ -810,8 +846,8 @@ static int launch_scatter(const nvfi_field_desc* f, ScatterArgs& sa, int C, int6
         float yf = floorf(y);
         yf = fminf(fmaxf(yf, -4.f), (float)f->K + 2.f);
         sa.y0 = (int)yf; sa.gmax = gmax;
-        if (C == 24) hipLaunchKernelGGL(k_plane_scatter_lds<24>, dim3(256, 1), dim3(512), lds, st, sa);
-        else hipLaunchKernelGGL(k_plane_scatter_lds<48>, dim3(256, 2), dim3(512), lds, st, sa);
+        if (C == 24) hipLaunchKernelGGL(k_plane_scatter_lds<24>, dim3(256, 1), dim3(1024), lds, st, sa);
+        else hipLaunchKernelGGL(k_plane_scatter_lds<48>, dim3(256, 2), dim3(1024), lds, st, sa);
     } else {
         const unsigned sc_blocks = (unsigned)((N + 4 * SCATTER_SPW - 1) / (4 * SCATTER_SPW));
         if (C == 24) hipLaunchKernelGGL(k_plane_scatter<24>, dim3(sc_blocks), dim3(256), 0, st, sa);
@@ -889,7 +925,7 @@ struct RenderPlan {
     int64_t total;
 };
 #define NSLAB_MAX 1024
-static int nslab_rt() { static int n = -1; if (n < 0) { const char* e = getenv("NVFI_NSLAB"); n = e ? atoi(e) : 256; if (n < 1) n = 1; if (n > NSLAB_MAX) n = NSLAB_MAX; } return n; }
+static int nslab_rt() { static int n = -1; if (n < 0) { const char* e = getenv("NVFI_NSLAB"); n = e ? atoi(e) : 512; if (n < 1) n = 1; if (n > NSLAB_MAX) n = NSLAB_MAX; } return n; }
 #define NSLAB (nslab_rt())
 #define SLAB_FLOATS (128 * 128 + 128)
 
@@ -1059,6 +1095,8 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     if (f->use_vel && nsteps > 0) pack_vel_frags(f->vW, f->vb, P.vel_frag, &VW, &dummy);
     dummy.n = 0;
     pack_render_frags(f, P.render_frag, &RW, &dummy);
+    const bool side = g_side.get() != 0;
+    bool forked = false;
     // appearance branch
     AppArgs aa; memset(&aa, 0, sizeof(aa));
     aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S;
@@ -1069,8 +1107,10 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     if (grads->aps[0] || grads->apt[0]) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
         sa.f = *f; sa.count = P.counters + 1; sa.list = P.mlist; sa.xw = P.xw; sa.tn = tn; sa.gg = P.gg; sa.g = *grads; sa.plane_mask = scatter_mask();
-        ProfScope ps(PK_APP_SCATTER, st);
-        if (launch_scatter(f, sa, 48, N, tn, st)) return 1;
+        hipStream_t ss = st;
+        if (side) { HIPCK(hipEventRecord(g_side.fork[0], st)); HIPCK(hipStreamWaitEvent(g_side.s, g_side.fork[0], 0)); ss = g_side.s; forked = true; }
+        ProfScope ps(PK_APP_SCATTER, ss);
+        if (launch_scatter(f, sa, 48, N, tn, ss)) return 1;
     }
     LAUNCHCK();
     // render-MLP weight gradients
@@ -1110,8 +1150,10 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     if (grads->dps[0] || grads->dpt[0]) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
         sa.f = *f; sa.count = P.counters + 0; sa.list = P.vlist; sa.xw = P.xw; sa.tn = tn; sa.gxpre = P.gxpre; sa.g = *grads; sa.plane_mask = scatter_mask();
-        ProfScope ps(PK_DENSITY_SCATTER, st);
-        if (launch_scatter(f, sa, 24, N, tn, st)) return 1;
+        hipStream_t ss = st;
+        if (side) { HIPCK(hipEventRecord(g_side.fork[1], st)); HIPCK(hipStreamWaitEvent(g_side.s, g_side.fork[1], 0)); ss = g_side.s; forked = true; }
+        ProfScope ps(PK_DENSITY_SCATTER, ss);
+        if (launch_scatter(f, sa, 24, N, tn, ss)) return 1;
     }
     LAUNCHCK();
     // RK2 adjoint + velocity-net weight gradients
@@ -1125,6 +1167,7 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
         if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 0, (int)P.cap_tiles, 2 * nsteps, BM_SILU, P.slabs, NSLAB,
                              grads->vW, grads->vb, 1.f, st)) return 1;
     }
+    if (forked) { HIPCK(hipEventRecord(g_side.join, g_side.s)); HIPCK(hipStreamWaitEvent(st, g_side.join, 0)); }
     return 0;
 }
 
