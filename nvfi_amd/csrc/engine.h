@@ -385,6 +385,95 @@ __device__ __forceinline__ void velnet_backward(const VelFrags& W, float* lds_w,
     for (int r = 0; r < 16; ++r) ge[r] = o[0][r];
 }
 
+// ---------------------------------------------------------------- pipelined backward (one workgroup per CU)
+// The adjoint passes were dominated by exposed latency (PMC: 40-66 % of the wave cycles in s_waitcnt): every layer
+// waited for its weight fragment (global -> LDS between two barriers) and then for the z stash in the epilogue.
+// Here the workgroup owns the CU (one wave per SIMD, 512 registers, 2 x 64 KB fragment buffers):
+//   issue   : the NEXT layer's fragment is loaded into 64 registers and the NEXT epilogue's z rows into 64 more,
+//   compute : 256 MFMAs read the current fragment from LDS buffer `cur`,
+//   commit  : the in-flight fragment is written to the other buffer, ONE barrier, buffers flip.
+// A buffer is only overwritten after every wave has passed the barrier that followed its last read of it.
+#define ENGINE2_LDS_BYTES (2 * LDS_W_FLOATS * 4)
+struct FragPipe {
+    float* base; int cur; float4 r[16]; int n4;
+    __device__ __forceinline__ void init(float* lds) { base = lds; cur = 0; n4 = 0; }
+    __device__ __forceinline__ const float* w() const { return base + cur * LDS_W_FLOATS; }
+    __device__ __forceinline__ void issue(const float* __restrict__ frag, int nfloats) {
+        const float4* src = reinterpret_cast<const float4*>(frag);
+        n4 = frag ? nfloats >> 2 : 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = threadIdx.x + k * WG_THREADS;
+            if (idx < n4) r[k] = src[idx];
+        }
+    }
+    __device__ __forceinline__ void commit() {
+        float4* dst = reinterpret_cast<float4*>(base + (cur ^ 1) * LDS_W_FLOATS);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = threadIdx.x + k * WG_THREADS;
+            if (idx < n4) dst[idx] = r[k];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+};
+
+template <int NR>
+__device__ __forceinline__ void stash_load(const float* base, int lane, float* v) {
+#pragma unroll
+    for (int s = 0; s < NR; ++s) v[s] = base[s * REGF + lane];
+}
+
+// Backward (dgrad) of one evaluation, pipelined form.  On entry the pipe's current buffer holds W.t[5]; on exit it holds
+// `next_frag` (next_n floats: the first fragment of whatever pass follows - usually W.t[5] again), so consecutive
+// evaluations chain without an exposed staging step.  Same results as velnet_backward.
+template <int ACT>
+__device__ __forceinline__ void velnet_backward_p(const VelFrags& W, FragPipe& P, int lane, const float* gw4, const float* zst,
+                                                  float* gst, float* ge, const float* next_frag, int next_n) {
+    float g[64], zp[64];
+    f32x16 acc[4];
+    g[0] = gw4[0]; g[1] = gw4[1]; g[2] = gw4[2]; g[3] = gw4[3];
+    if (gst) {
+        float* gw_rows = gst + (size_t)5 * 64 * REGF;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
+    }
+    P.issue(W.t[4], VEL_FH);
+    stash_load<64>(zst + (size_t)4 * 64 * REGF, lane, zp);
+    __builtin_amdgcn_sched_barrier(0);
+    acc_init<4>(acc, nullptr, 0, false);
+    layer_mfma<4, 4>(P.w(), lane, g, acc);
+    P.commit();
+#pragma unroll 1
+    for (int l = 4; l >= 1; --l) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = acc[m][r] * act_d1<ACT>(zp[16 * m + r]);
+        if (gst) stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
+        if (l > 1) P.issue(W.t[l - 1], VEL_FH); else P.issue(W.t[0], VEL_T0);
+        stash_load<64>(zst + (size_t)(l - 1) * 64 * REGF, lane, zp);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetches ahead of the MFMAs (the scheduler would sink them to save registers)
+        acc_init<4>(acc, nullptr, 0, false);
+        layer_mfma<4, 64>(P.w(), lane, g, acc);
+        P.commit();
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[16 * m + r] = acc[m][r] * act_d1<ACT>(zp[16 * m + r]);
+    if (gst) stash_store<64>(gst, lane, g);
+    P.issue(next_frag, next_n);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 o[1];
+    acc_init<1>(o, nullptr, 0, false);
+    layer_mfma<1, 64>(P.w(), lane, g, o);
+    P.commit();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ge[r] = o[0][r];
+}
+
 // adjoint of the PositionEncoder slots: ge (16 regs of this lane) + the forward slots x0 -> (gx,gy,gz,gt) summed over both halves
 __device__ __forceinline__ float4 vel_encode_bwd(const float* ge, const float* x0, int h) {
     // lane h=0 holds (x | z) raw and the sin slots; lane h=1 holds (y | t) raw and the cos slots.

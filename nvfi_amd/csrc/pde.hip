@@ -236,6 +236,132 @@ __device__ __forceinline__ void velnet_value_backward(const VelFrags& W, float* 
     }
 }
 
+// Pipelined forms (engine.h: FragPipe - one workgroup per CU, next fragment and next epilogue's stash rows in flight behind
+// the MFMAs).  On entry the pipe's current buffer holds W.t[5].
+template <int ACT>
+__device__ __forceinline__ void velnet_tangent_backward_p(const VelFrags& W, FragPipe& P, int lane, const float* seed4,
+                                                          const float* zst, const float* zdst, float* corr, float* gst) {
+    float g[64], zp[64], zdp[64];
+    f32x16 acc[4];
+    g[0] = seed4[0]; g[1] = seed4[1]; g[2] = seed4[2]; g[3] = seed4[3];
+    {
+        float* gw_rows = gst + (size_t)5 * 64 * REGF;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
+    }
+    P.issue(W.t[4], VEL_FH);
+    stash_load<64>(zst + (size_t)4 * 64 * REGF, lane, zp);
+    stash_load<64>(zdst + (size_t)4 * 64 * REGF, lane, zdp);
+    __builtin_amdgcn_sched_barrier(0);
+    acc_init<4>(acc, nullptr, 0, false);
+    layer_mfma<4, 4>(P.w(), lane, g, acc);
+    P.commit();
+#pragma unroll 1
+    for (int l = 4; l >= 0; --l) {
+        float* cl = corr + (size_t)l * 64 * REGF;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int s = 16 * m + r;
+                float d1, d2;
+                act_d12<ACT>(zp[s], d1, d2);
+                cl[s * REGF + lane] = d2 * zdp[s] * acc[m][r];
+                g[s] = d1 * acc[m][r];
+            }
+        stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
+        if (l >= 1) {
+            if (l > 1) P.issue(W.t[l - 1], VEL_FH); else P.issue(nullptr, 0);
+            stash_load<64>(zst + (size_t)(l - 1) * 64 * REGF, lane, zp);
+            stash_load<64>(zdst + (size_t)(l - 1) * 64 * REGF, lane, zdp);
+            __builtin_amdgcn_sched_barrier(0);
+            acc_init<4>(acc, nullptr, 0, false);
+            layer_mfma<4, 64>(P.w(), lane, g, acc);
+            P.commit();
+        }
+    }
+}
+// tangent forward of one column, pipelined.  On entry the pipe's current buffer holds W.f[0].
+template <int ACT>
+__device__ __forceinline__ void velnet_tangent_forward_p(const VelFrags& W, FragPipe& P, int lane, const float* xd16,
+                                                         const float* zst, float* zdst, float* out4) {
+    float x[64], zp[64];
+    f32x16 acc[4];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) x[s] = xd16[s];
+    P.issue(W.f[1], VEL_FH);
+    stash_load<64>(zst, lane, zp);
+    __builtin_amdgcn_sched_barrier(0);
+    acc_init<4>(acc, nullptr, 0, false);
+    layer_mfma<4, 14>(P.w(), lane, x, acc);
+    P.commit();
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        float* zd = zdst + (size_t)l * 64 * REGF;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                zd[(16 * m + r) * REGF + lane] = acc[m][r];
+                x[16 * m + r] = act_d1<ACT>(zp[16 * m + r]) * acc[m][r];
+            }
+        if (l < 3) P.issue(W.f[l + 2], VEL_FH); else P.issue(W.f[5], VEL_F5);
+        stash_load<64>(zst + (size_t)(l + 1) * 64 * REGF, lane, zp);
+        __builtin_amdgcn_sched_barrier(0);
+        acc_init<4>(acc, nullptr, 0, false);
+        layer_mfma<4, 64>(P.w(), lane, x, acc);
+        P.commit();
+    }
+    {
+        float* zd = zdst + (size_t)4 * 64 * REGF;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                zd[(16 * m + r) * REGF + lane] = acc[m][r];
+                x[16 * m + r] = act_d1<ACT>(zp[16 * m + r]) * acc[m][r];
+            }
+    }
+    f32x16 o[1];
+    acc_init<1>(o, nullptr, 0, false);
+    layer_mfma<1, 64>(P.w(), lane, x, o);
+    out4[0] = o[0][0]; out4[1] = o[0][1]; out4[2] = o[0][2]; out4[3] = o[0][3];
+}
+template <int ACT>
+__device__ __forceinline__ void velnet_value_backward_p(const VelFrags& W, FragPipe& P, int lane, const float* seed4,
+                                                        const float* zst, float* gst) {
+    float g[64], zp[64];
+    f32x16 acc[4];
+    g[0] = seed4[0]; g[1] = seed4[1]; g[2] = seed4[2]; g[3] = seed4[3];
+    {
+        float* gw_rows = gst + (size_t)5 * 64 * REGF;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
+    }
+    P.issue(W.t[4], VEL_FH);
+    stash_load<64>(zst + (size_t)4 * 64 * REGF, lane, zp);
+    __builtin_amdgcn_sched_barrier(0);
+    acc_init<4>(acc, nullptr, 0, false);
+    layer_mfma<4, 4>(P.w(), lane, g, acc);
+    P.commit();
+#pragma unroll 1
+    for (int l = 4; l >= 0; --l) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = act_d1<ACT>(zp[16 * m + r]) * acc[m][r];
+        stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
+        if (l >= 1) {
+            if (l > 1) P.issue(W.t[l - 1], VEL_FH); else P.issue(nullptr, 0);
+            stash_load<64>(zst + (size_t)(l - 1) * 64 * REGF, lane, zp);
+            __builtin_amdgcn_sched_barrier(0);
+            acc_init<4>(acc, nullptr, 0, false);
+            layer_mfma<4, 64>(P.w(), lane, g, acc);
+            P.commit();
+        }
+    }
+}
+
 // ---- column-parallel jet kernels: the value column, the 4 tangent columns and the a_weight_net column of a
 // tile run in DIFFERENT workgroups (blockIdx.y = column) so that a few ten-thousand kept points still fill 256 CUs.
 
@@ -260,20 +386,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_fwd(PdeJetArgs a) {
     }
 }
 // K2: tangent column j = blockIdx.y of weight_net
-__global__ __launch_bounds__(WG_THREADS, 2) void k_pde_tangent_fwd(PdeJetArgs a) {
+__global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_fwd(PdeJetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int j = blockIdx.y;
     const int tile = blockIdx.x * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
+    FragPipe pipe; pipe.init(lds);
+    pipe.issue(a.Wv.f[0], VEL_F0);
     float x0[16], xd[16], o4[4], wd[6];
 #pragma unroll
     for (int s = 0; s < 16; ++s) x0[s] = T[(PDE_X0 + s) * REGF + lane];
+    pipe.cur = 1; pipe.commit();          // first fragment into buffer 0
     encode_tangent(x0, h, j, xd);
     stash_store<16>(T + (PDE_X0D + 16 * j) * REGF, lane, xd);
-    velnet_tangent_forward<1>(a.Wv, lds_w, lds_b, lane, xd, T + PDE_Z * REGF, T + (PDE_ZD + 320 * j) * REGF, o4);
+    velnet_tangent_forward_p<1>(a.Wv, pipe, lane, xd, T + PDE_Z * REGF, T + (PDE_ZD + 320 * j) * REGF, o4);
     gather6(o4, h, wd);
     if (h == 0 && i < a.cap) {
         float* o = a.wout + (size_t)(6 + 6 * j) * a.cap + i;
@@ -368,9 +496,8 @@ __global__ __launch_bounds__(256) void k_pde_seeds(PdeJetArgs a) {
     }
 }
 // K4: tangent-adjoint column j = blockIdx.y (0..3) or the a_weight_net adjoint (y = 4)
-__global__ __launch_bounds__(WG_THREADS, 2) void k_pde_tangent_bwd(PdeJetArgs a) {
+__global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_bwd(PdeJetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int j = blockIdx.y;
     const int tile = blockIdx.x * 4 + wave_id();
@@ -378,16 +505,19 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_tangent_bwd(PdeJetArgs a)
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
     const size_t cs = a.cap;
     const bool ok = i < a.cap;
+    FragPipe pipe; pipe.init(lds);
+    pipe.issue(j < 4 ? a.Wv.t[5] : a.Wa.t[5], VEL_T5);
+    pipe.cur = 1; pipe.commit();          // first fragment into buffer 0
     float r4[4], s6[6];
     const int sbase = j < 4 ? 6 + 6 * j : 30;
 #pragma unroll
     for (int k = 0; k < 6; ++k) s6[k] = ok ? a.seeds[(size_t)(sbase + k) * cs + i] : 0.f;
     scatter6(s6, h, r4);
     if (j < 4)
-        velnet_tangent_backward<1>(a.Wv, lds_w, lds_b, lane, r4, T + PDE_Z * REGF, T + (PDE_ZD + 320 * j) * REGF,
-                                   T + (PDE_CORR + 320 * j) * REGF, true, T + (PDE_GA + 336 * (1 + j)) * REGF);
+        velnet_tangent_backward_p<1>(a.Wv, pipe, lane, r4, T + PDE_Z * REGF, T + (PDE_ZD + 320 * j) * REGF,
+                                     T + (PDE_CORR + 320 * j) * REGF, T + (PDE_GA + 336 * (1 + j)) * REGF);
     else
-        velnet_value_backward<0, false>(a.Wa, lds_w, lds_b, lane, r4, T + PDE_ZA * REGF, nullptr, T + PDE_GAA * REGF);
+        velnet_value_backward_p<0>(a.Wa, pipe, lane, r4, T + PDE_ZA * REGF, T + PDE_GAA * REGF);
 }
 // K5: value adjoint of weight_net with the summed second-derivative corrections
 __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_bwd(PdeJetArgs a) {
@@ -460,8 +590,8 @@ static int ensure_pde_attrs() {
     static bool done = false;
     if (done) return 0;
     HIPCK(hipFuncSetAttribute((const void*)k_pde_value_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_pde_tangent_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_pde_tangent_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_pde_tangent_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE2_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_pde_tangent_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE2_LDS_BYTES));
     HIPCK(hipFuncSetAttribute((const void*)k_pde_value_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     done = true;
     return 0;
@@ -523,13 +653,13 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
             {
                 ProfScope ps(PK_PDE_FWD, st);
                 hipLaunchKernelGGL(k_pde_value_fwd, dim3(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
-                hipLaunchKernelGGL(k_pde_tangent_fwd, dim3(wgs, 4), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                hipLaunchKernelGGL(k_pde_tangent_fwd, dim3(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
                 hipLaunchKernelGGL(k_pde_seeds, dim3((unsigned)(cap / 256 + 1)), dim3(256), 0, st, ja);
             }
             if (grads) {
                 {
                     ProfScope ps(PK_PDE_BWD, st);
-                    hipLaunchKernelGGL(k_pde_tangent_bwd, dim3(wgs, 5), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                    hipLaunchKernelGGL(k_pde_tangent_bwd, dim3(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
                     hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
                 }
                 LAUNCHCK();

@@ -114,12 +114,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_fwd(Rk2Args a) {
 }
 
 // ---------------------------------------------------------------- RK2 adjoint (render backward)
-__global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_bwd(Rk2Args a) {
+__global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_bwd(Rk2Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int count = *a.count;
     if ((int)(blockIdx.x * WG_SAMPLES) >= count) return;
+    FragPipe pipe; pipe.init(lds);
+    pipe.issue(a.Wv.t[5], VEL_T5);
+    pipe.cur = 1; pipe.commit();          // first fragment into buffer 0
     const int tile = blockIdx.x * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     const bool active = i < count;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_bwd(Rk2Args a) {
             gloc[2] = -w[4] * gv[0] + w[3] * gv[1];
             scatter6(gw, h, r4);
             float ge[16];
-            velnet_backward<1>(a.Wv, lds_w, lds_b, lane, r4, a.zst + es * (VEL_Z_REGS * REGF), a.gst + es * (VEL_G_REGS * REGF), ge);
+            velnet_backward_p<1>(a.Wv, pipe, lane, r4, a.zst + es * (VEL_Z_REGS * REGF), a.gst + es * (VEL_G_REGS * REGF), ge, a.Wv.t[5], VEL_T5);
             float x0[16];
 #pragma unroll
             for (int c = 0; c < 3; ++c) p[c] = active ? rc[(po + c) * a.cap] : 0.f;
@@ -187,7 +189,7 @@ int ensure_lds_attrs() {
     HIPCK(hipFuncSetAttribute((const void*)k_rk2_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     HIPCK(hipFuncSetAttribute((const void*)k_rk2_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     HIPCK(hipFuncSetAttribute((const void*)k_rk2_fwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_rk2_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_rk2_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE2_LDS_BYTES));
     done = true;
     return 0;
 }
@@ -217,7 +219,7 @@ int launch_rk2_bwd(const Rk2Args& a, int64_t cap_samples, hipStream_t st) {
     int64_t nwg = (cap_samples + WG_SAMPLES - 1) / WG_SAMPLES;
     if (nwg <= 0) return 0;
     ProfScope ps(PK_RK2_BWD, st);
-    hipLaunchKernelGGL(k_rk2_bwd, dim3((unsigned)nwg), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
+    hipLaunchKernelGGL(k_rk2_bwd, dim3((unsigned)nwg), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, a);
     LAUNCHCK();
     return 0;
 }
