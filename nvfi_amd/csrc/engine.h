@@ -393,12 +393,13 @@ __device__ __forceinline__ void velnet_backward(const VelFrags& W, float* lds_w,
 //   compute : 256 MFMAs read the current fragment from LDS buffer `cur`,
 //   commit  : the in-flight fragment is written to the other buffer, ONE barrier, buffers flip.
 // A buffer is only overwritten after every wave has passed the barrier that followed its last read of it.
-#define ENGINE2_LDS_BYTES (2 * LDS_W_FLOATS * 4)
+#define ENGINE2_LDS_BYTES ((2 * LDS_W_FLOATS + 2 * LDS_B_FLOATS) * 4)
 struct FragPipe {
-    float* base; int cur; float4 r[16]; int n4;
-    __device__ __forceinline__ void init(float* lds) { base = lds; cur = 0; n4 = 0; }
+    float* base; int cur; float4 r[16]; int n4; float rb; int nb;
+    __device__ __forceinline__ void init(float* lds) { base = lds; cur = 0; n4 = 0; nb = 0; rb = 0.f; }
     __device__ __forceinline__ const float* w() const { return base + cur * LDS_W_FLOATS; }
-    __device__ __forceinline__ void issue(const float* __restrict__ frag, int nfloats) {
+    __device__ __forceinline__ const float* b() const { return base + 2 * LDS_W_FLOATS + cur * LDS_B_FLOATS; }
+    __device__ __forceinline__ void issue(const float* __restrict__ frag, int nfloats, const float* __restrict__ bfrag = nullptr, int nbias = 0) {
         const float4* src = reinterpret_cast<const float4*>(frag);
         n4 = frag ? nfloats >> 2 : 0;
 #pragma unroll
@@ -406,6 +407,8 @@ struct FragPipe {
             const int idx = threadIdx.x + k * WG_THREADS;
             if (idx < n4) r[k] = src[idx];
         }
+        nb = bfrag ? nbias : 0;
+        if ((int)threadIdx.x < nb) rb = bfrag[threadIdx.x];
     }
     __device__ __forceinline__ void commit() {
         float4* dst = reinterpret_cast<float4*>(base + (cur ^ 1) * LDS_W_FLOATS);
@@ -414,6 +417,7 @@ struct FragPipe {
             const int idx = threadIdx.x + k * WG_THREADS;
             if (idx < n4) dst[idx] = r[k];
         }
+        if ((int)threadIdx.x < nb) base[2 * LDS_W_FLOATS + (cur ^ 1) * LDS_B_FLOATS + threadIdx.x] = rb;
         __syncthreads();
         cur ^= 1;
     }
@@ -425,6 +429,9 @@ __device__ __forceinline__ void stash_load(const float* base, int lane, float* v
     for (int s = 0; s < NR; ++s) v[s] = base[s * REGF + lane];
 }
 
+// (A pipelined FORWARD was built the same way and measured: rk2_fwd unchanged, the PDE prefilter 12 % slower - the forward
+// has no stash reads to hide, its staging is already covered by the second workgroup of the CU, and at one wave per SIMD
+// the SiLU epilogue is no longer hidden at all.  The forward kernels therefore keep two workgroups per CU.)
 // Backward (dgrad) of one evaluation, pipelined form.  On entry the pipe's current buffer holds W.t[5]; on exit it holds
 // `next_frag` (next_n floats: the first fragment of whatever pass follows - usually W.t[5] again), so consecutive
 // evaluations chain without an exposed staging step.  Same results as velnet_backward.
