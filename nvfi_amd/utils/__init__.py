@@ -1,4 +1,4 @@
 from .cfgnode import CfgNode
 from .metrics import mse2psnr
 from .tensorf_utils import TVLoss, N_to_reso
-from .evaluation_utils import save_checkpoint, load_checkpoint, load_model_checkpoint
+from .evaluation_utils import save_checkpoint, load_checkpoint, load_model_checkpoint, render_test_evaluation

@@ -38,3 +38,39 @@ def load_model_checkpoint(cfg, ckpt, device):
     renderer = Renderer(nvfi, cfg.renderer.batch_size, cfg.renderer.test_batch_size, cfg.renderer.n_rays,
                         cfg.renderer.distance_scale, tensorf_sample=cfg.renderer.tensorf_sample, ndc=cfg.renderer.ndc) if "renderer" in cfg else None
     return nvfi, renderer
+
+
+def render_test_evaluation(nvfi, renderer, poses, times, targets, H, W, focal, near, far, white_background=True,
+                           savedir=None, update_alpha_mask=True, device=None):
+    """Eval driver (train_nvfi.py:395-459 without the dataset / wandb plumbing): optional `updateAlphaMask` at the current grid
+    (`:413`), one `Renderer.render(mode='test')` per (pose, time) frame (`:437`), 8-bit PNGs named r_%03d.png (`:449-451`,
+    written with PIL - imageio is not a dependency here) and per-frame / mean PSNR against `targets` (H,W,3 in [0,1]).
+
+    Returns {"psnr": [..], "mean_psnr": float, "images": uint8 array (N,H,W,3)}."""
+    import numpy as np
+    from ..models import Camera
+    from .metrics import mse2psnr
+    device = device or next(nvfi.parameters()).device
+    nvfi.eval()
+    if update_alpha_mask:
+        nvfi.nvfi.updateAlphaMask(nvfi.nvfi.gridSize)
+    imgs, psnrs = [], []
+    with torch.no_grad():
+        for idx in range(len(poses)):
+            pose = torch.as_tensor(poses[idx], dtype=torch.float32, device=device)
+            cam = Camera(pose, H, W, focal, None, near, far)
+            rgb = renderer.render(float(times[idx]), cam.rays.to(device), white_background=white_background, mode="test")[0]
+            rgb = rgb.reshape(H, W, 3)
+            if targets is not None:
+                tgt = torch.as_tensor(targets[idx], dtype=torch.float32, device=device).reshape(H, W, 3)
+                psnrs.append(mse2psnr(float(torch.mean((rgb - tgt) ** 2))))
+            imgs.append((rgb.clamp(0, 1).cpu().numpy() * 255.0).astype(np.uint8))
+    if savedir is not None:
+        os.makedirs(savedir, exist_ok=True)
+        try:
+            from PIL import Image
+            for idx, img in enumerate(imgs):
+                Image.fromarray(img).save(os.path.join(savedir, "r_%03d.png" % idx))
+        except ImportError:      # no image writer in this environment: keep the raw frames
+            np.save(os.path.join(savedir, "frames.npy"), np.stack(imgs))
+    return {"psnr": psnrs, "mean_psnr": (sum(psnrs) / len(psnrs)) if psnrs else None, "images": np.stack(imgs)}

@@ -354,3 +354,46 @@ def test_device_side_rays(gold):
     yy, xx = ids // 160, ids % 160
     assert torch.allclose(rays.ray_directions, cam.rays.ray_directions[yy, xx], rtol=1e-6, atol=1e-6)
     assert torch.allclose(rays.ray_origins, cam.rays.ray_origins[yy, xx])
+
+
+def test_eval_driver_psnr_and_png(fields, models, tmp_path):
+    """f-4: render_test_evaluation renders pose/time frames in test mode, writes r_%03d.png and reports PSNR.  Targets are the
+    oracle's renders of the same frames, so the PSNR measures the HIP-vs-reference image error: > 70 dB (rgb within ~1e-4),
+    and the PSNR against a noisy target agrees with the oracle's own PSNR within the 0.05 dB contract of BASELINE.json."""
+    from oracle import oracle as orc
+    from nvfi_amd.models import Renderer, Camera
+    from nvfi_amd.utils.evaluation_utils import render_test_evaluation
+    from nvfi_amd.utils import mse2psnr
+    model, meta = models["A"]
+    fs = fields["A"]
+    model.nvfi.alphaMask = None
+    H = W = 24
+    focal = 30.0
+    poses, times, targets, noisy = [], [], [], []
+    rng = np.random.default_rng(3)
+    for k, (th, t) in enumerate([(20.0, 0.30), (75.0, 19 / 60.0)]):
+        c, s = np.cos(np.deg2rad(th)), np.sin(np.deg2rad(th))
+        R_ = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float32)
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, :3] = R_
+        pose[:3, 3] = R_ @ np.array([0, 0, 4.0], np.float32) + (fs.aabb[0] + fs.aabb[1]) * 0.5
+        cam = Camera(torch.from_numpy(pose), H, W, focal, None, float(meta["near"]), float(meta["far"]))
+        o = cam.rays.ray_origins.reshape(-1, 3).numpy().astype(np.float32)
+        d = cam.rays.ray_directions.reshape(-1, 3).numpy().astype(np.float32)
+        ref = orc.render(fs, o, d, t, train=False, white_bg=bool(meta["white_background"]))
+        poses.append(pose); times.append(t)
+        targets.append(ref.rgb.reshape(H, W, 3))
+        noisy.append(np.clip(ref.rgb.reshape(H, W, 3) + rng.normal(0, 0.05, (H, W, 3)).astype(np.float32), 0, 1))
+    ren = Renderer(model, 0, 0, 2048)
+    near, far = float(meta["near"]), float(meta["far"])
+    res = render_test_evaluation(model, ren, poses, times, targets, H, W, focal, near, far, white_background=bool(meta["white_background"]),
+                                 savedir=str(tmp_path), update_alpha_mask=False)
+    assert min(res["psnr"]) > 70.0, res["psnr"]
+    res2 = render_test_evaluation(model, ren, poses, times, noisy, H, W, focal, near, far, white_background=bool(meta["white_background"]),
+                                  savedir=None, update_alpha_mask=False)
+    for k in range(2):
+        ref_psnr = mse2psnr(float(np.mean((targets[k] - noisy[k]) ** 2)))
+        assert abs(res2["psnr"][k] - ref_psnr) < 0.05, (res2["psnr"][k], ref_psnr)      # BASELINE.json: PSNR within 0.05 dB
+    from PIL import Image
+    img = np.asarray(Image.open(str(tmp_path / "r_001.png")))
+    assert img.shape == (H, W, 3) and np.array_equal(img, res["images"][1])
