@@ -19,35 +19,71 @@ struct RegJob {
 };
 struct RegJobs { RegJob j[12]; int n; float* out; };
 
-__global__ __launch_bounds__(256) void k_plane_regs(RegJobs jobs) {
-    __shared__ float red[2][4];
+// One thread handles 4 consecutive channels of a texel (C is a multiple of 4, so they share x and y): 16-byte loads of the
+// texel and its four neighbours, 32-bit index arithmetic (the largest plane has 1.9 M elements).
+__global__ __launch_bounds__(1024) void k_plane_regs(RegJobs jobs) {
+    __shared__ float red[2][16];
     const RegJob& J = jobs.j[blockIdx.y];
-    const int64_t total = (int64_t)J.H * J.W * J.C;
-    const int64_t rowf = (int64_t)J.W * J.C;
+    const int total4 = (J.H * J.W * J.C) >> 2;
+    const int rowf = J.W * J.C;
     float l1 = 0.f, tv = 0.f;
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t y = idx / rowf;
-        const int x = (int)((idx - y * rowf) / J.C);
-        const float v = J.p[idx];
-        float g = 0.f;
-        if (J.l1_mode == 1) { l1 += fabsf(v); g += J.l1_grad * (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)); }
-        else if (J.l1_mode == 2) { const float u = 1.f - v; l1 += fabsf(u); g -= J.l1_grad * (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)); }
-        if (J.tv_slot) {
-            float gh = 0.f, gw = 0.f;
-            if (y + 1 < J.H) { const float d = J.p[idx + rowf] - v; tv += J.h_val * d * d; gh -= d; }
-            if (y > 0) gh += v - J.p[idx - rowf];
-            if (x + 1 < J.W) { const float d = J.p[idx + J.C] - v; tv += J.w_val * d * d; gw -= d; }
-            if (x > 0) gw += v - J.p[idx - J.C];
-            g += J.tv_w * 2.f * (J.h_val * gh + J.w_val * gw);
+    for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += gridDim.x * blockDim.x) {
+        const int idx = i4 << 2;
+        const int y = idx / rowf;
+        const int x = (idx - y * rowf) / J.C;
+        const float4 v4 = *reinterpret_cast<const float4*>(J.p + idx);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        if (J.l1_mode == 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { l1 += fabsf(v[c]); g[c] += J.l1_grad * (v[c] > 0.f ? 1.f : (v[c] < 0.f ? -1.f : 0.f)); }
+        } else if (J.l1_mode == 2) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float u = 1.f - v[c]; l1 += fabsf(u); g[c] -= J.l1_grad * (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)); }
         }
-        if (J.g) J.g[idx] += g;
+        if (J.tv_slot) {
+            float gh[4] = {0.f, 0.f, 0.f, 0.f}, gw[4] = {0.f, 0.f, 0.f, 0.f};
+            if (y + 1 < J.H) {
+                const float4 n4 = *reinterpret_cast<const float4*>(J.p + idx + rowf);
+                const float n[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float d = n[c] - v[c]; tv += J.h_val * d * d; gh[c] -= d; }
+            }
+            if (y > 0) {
+                const float4 n4 = *reinterpret_cast<const float4*>(J.p + idx - rowf);
+                const float n[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gh[c] += v[c] - n[c];
+            }
+            if (x + 1 < J.W) {
+                const float4 n4 = *reinterpret_cast<const float4*>(J.p + idx + J.C);
+                const float n[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float d = n[c] - v[c]; tv += J.w_val * d * d; gw[c] -= d; }
+            }
+            if (x > 0) {
+                const float4 n4 = *reinterpret_cast<const float4*>(J.p + idx - J.C);
+                const float n[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gw[c] += v[c] - n[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[c] += J.tv_w * 2.f * (J.h_val * gh[c] + J.w_val * gw[c]);
+        }
+        if (J.g) {
+            float4 o = *reinterpret_cast<float4*>(J.g + idx);
+            o.x += g[0]; o.y += g[1]; o.z += g[2]; o.w += g[3];
+            *reinterpret_cast<float4*>(J.g + idx) = o;
+        }
     }
     l1 = wave_sum(l1); tv = wave_sum(tv);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = l1; red[1][threadIdx.x >> 6] = tv; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (J.l1_mode) atomicAdd(jobs.out + 0, J.l1_val * (red[0][0] + red[0][1] + red[0][2] + red[0][3]));
-        if (J.tv_slot) atomicAdd(jobs.out + J.tv_slot, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        float s0 = 0.f, s1 = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { s0 += red[0][w]; s1 += red[1][w]; }
+        if (J.l1_mode) atomicAdd(jobs.out + 0, J.l1_val * s0);
+        if (J.tv_slot) atomicAdd(jobs.out + J.tv_slot, s1);
     }
 }
 
@@ -71,7 +107,9 @@ extern "C" int nvfi_plane_regs(const nvfi_field_desc* f, float w_l1, float w_tv_
         add(f->dpt[i], grads ? grads->dpt[i] : nullptr, f->K, f->G[Cc[i]], f->Cd, 2, f->K > 1 ? 1 : 0, 3.f, w_tv_density);
         add(f->aps[i], grads ? grads->aps[i] : nullptr, f->G[Bx[i]], f->G[A[i]], f->Ca, 0, 2, 1.f, w_tv_app);
     }
-    hipLaunchKernelGGL(k_plane_regs, dim3(1024, jobs.n), dim3(256), 0, st, jobs);
+    if ((f->Cd & 3) || (f->Ca & 3)) return nvfi_fail(2, "nvfi_plane_regs: channel counts must be multiples of 4");
+    // few, fat workgroups: every workgroup ends with two atomics on the same three floats (~11 ns each when contended)
+    hipLaunchKernelGGL(k_plane_regs, dim3(96, jobs.n), dim3(1024), 0, st, jobs);
     LAUNCHCK();
     return 0;
 }
