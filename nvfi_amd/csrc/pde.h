@@ -3,7 +3,7 @@
 #include "common.h"
 
 #define PDE_MAX_CLASS 64           // RK2 step-count buckets
-#define PDE_CHUNK 65536            // kept points processed per pass (bounds the stash)
+#define PDE_CHUNK 131072           // kept points processed per pass (bounds the stash: 42 KB per point -> 5.5 GB; sized for 288 GB of HBM)
 #define PDE_NSLAB 128
 
 // per-tile stash rows (each row = 64 floats)
