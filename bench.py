@@ -111,6 +111,7 @@ class Step:
         self.inplace = True
         from nvfi_amd.dist import PdeGradStage
         self.pde_stage = PdeGradStage(model.nvfi._pde_params()) if world > 1 else None
+        self.tail_off = self.bucket.tail_offset(list(model.nvfi.vel.parameters())) if (world > 1 and model.nvfi.use_vel) else None
         model.nvfi.accumulate_grads_inplace = True   # .grad tensors are views of the GradBucket's flat buffer
 
     def rays(self):
@@ -126,9 +127,8 @@ class Step:
             m.train()
         self.bucket.zero()
         loss = 0
-        # the PDE term goes first: its one host sync (kept count) then overlaps with nothing that is already queued,
-        # and the renders + backward + Adam that follow are launched without any host wait
-        if self.workload == "cfg3":
+
+        def pde_term():
             self.vw *= self.lr_factor
             # same term as `loss += vw * get_vel_loss()`, fused: d(vw * loss_vel) is accumulated by the PDE kernels - straight into
             # .grad on one GPU, through a small staging buffer re-weighted by W*n_r/sum(n_r) (device-side) on several
@@ -136,11 +136,17 @@ class Step:
             if self.world > 1:
                 self.pde_stage.zero()
                 m.vel_grad_targets = self.pde_stage.views
-            lv = m.get_vel_loss(self.n_pts)
+            self.last_lv = m.get_vel_loss(self.n_pts)
             self.pde_counters.append(f.last_pde_counters)
             if self.world > 1:
                 self.pde_stage.commit(f.last_pde_n_kept)
-            self.last_lv = lv
+
+        # One GPU: the PDE term goes first - its one host sync (kept count) then waits on nothing that is already queued, and the
+        # renders + backward + Adam that follow are launched without any host wait.  Several GPUs: it goes LAST, so that the
+        # all-reduce of the plane / render-MLP gradients (38 MB, final after the renders) runs underneath it.
+        overlap = self.world > 1 and self.tail_off is not None
+        if self.workload == "cfg3" and not overlap:
+            pde_term()
         if self.workload == "cfg3":
             i = int(self.rng.integers(0, 46))
             while i % 3 == 0:                       # frame times i/60; keyframes every 0.05 = 3/60
@@ -162,7 +168,13 @@ class Step:
         loss.backward()
         if self.fused_regs:   # same regularisers + their gradients, fused into one pass per plane (nvfi_plane_regs)
             self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
-        self.bucket.all_reduce_mean()
+        if overlap:
+            h = self.bucket.all_reduce_head_start(self.tail_off)
+            if self.workload == "cfg3":
+                pde_term()
+            self.bucket.all_reduce_finish(h, self.tail_off)
+        else:
+            self.bucket.all_reduce_mean()
         self.opt.step()
         for g in self.opt.param_groups:
             g["lr"] = g["lr"] * self.lr_factor

@@ -2,7 +2,8 @@
 
 Every rank holds a full replica of the field, renders its own rays / collocation points, and the only
 exchange is a sum of the flat gradient buffer (RCCL over xGMI through torch.distributed backend "nccl";
-"gloo" on CPU for the tests).  The loss means are formed so that the averaged gradient equals the
+"gloo" on CPU for the tests) - issued in two pieces so that the large one (plane + render-MLP gradients, final once
+the renders are differentiated) travels while the PDE term is still being computed.  The loss means are formed so that the averaged gradient equals the
 single-process gradient of the global batch: the render MSE is a mean over equal-sized shards, and the
 PDE term - whose per-rank kept count differs - is re-weighted by W * n_kept_r / sum_r n_kept_r.
 """
@@ -41,6 +42,34 @@ class GradBucket:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
+
+    def tail_offset(self, tail_params):
+        """Flat offset at which `tail_params` begin, if they are exactly the last parameters of the bucket (else None).
+        The head [0, off) can then be reduced early (all_reduce_head_start) while the tail is still being accumulated."""
+        ids = {id(p) for p in tail_params}
+        off, k = 0, 0
+        while k < len(self.params) and id(self.params[k]) not in ids:
+            off += self.params[k].numel(); k += 1
+        if k == len(self.params) or any(id(p) not in ids for p in self.params[k:]):
+            return None
+        return off
+
+    def all_reduce_head_start(self, off):
+        """Asynchronous sum of flat[:off] (RCCL runs it on its own stream, ordered after the work already queued here); returns
+        a handle for all_reduce_finish.  Used to hide the 38 MB plane-gradient exchange behind the PDE kernels."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return None
+        return dist.all_reduce(self.flat[:off], op=dist.ReduceOp.SUM, async_op=True)
+
+    def all_reduce_finish(self, handle, off):
+        """Sum the tail flat[off:], wait for the head, divide everything by the world size."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        if off < self.flat.numel():
+            dist.all_reduce(self.flat[off:], op=dist.ReduceOp.SUM)
+        if handle is not None:
+            handle.wait()
+        self.flat.div_(dist.get_world_size())
 
 
 def pde_rank_weight(n_kept_local):

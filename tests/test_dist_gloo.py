@@ -25,7 +25,7 @@ def _worker(rank, world, port, out):
     R = o.shape[0]
     lo, hi = shard_range(R, rank, world)
     # parameters as torch tensors, two of them channels_last like the product's planes
-    names = ["density_plane_space.0", "app_plane_time.1", "vel_net.weight_net.3.0.weight", "renderModule.mlp.0.bias"]
+    names = ["density_plane_space.0", "app_plane_time.1", "renderModule.mlp.0.bias", "vel_net.weight_net.3.0.weight"]
     params = []
     for n in names:
         t = torch.from_numpy(fs.p[n].copy())
@@ -46,13 +46,18 @@ def _worker(rank, world, port, out):
     pde = orc.pde_loss(fs, gold["A:pde:points"][plo:phi], gold["A:pde:t"][plo:phi])
     w = pde_rank_weight(pde["n_kept"])
     # the PDE gradients enter through the staging buffer (device-side W*n_r/sum(n_r) weighting), as bench.py does
-    stage = PdeGradStage([params[2]])
+    # ... and the exchange is split as in bench.py: the head (planes, render MLP - final after the renders) starts
+    # asynchronously, the PDE term lands in the tail (velocity nets) meanwhile, then the tail is reduced and everything averaged
+    stage = PdeGradStage([params[3]])
+    off = bucket.tail_offset([params[3]])
+    assert off == sum(p.numel() for p in params[:3]) and bucket.tail_offset([params[0]]) is None
     with torch.no_grad():
-        stage.views[0].copy_(torch.from_numpy(pde["grads"][names[2]]))
+        stage.views[0].copy_(torch.from_numpy(pde["grads"][names[3]]))
         for p, nm in zip(params, names):
             p.grad += torch.from_numpy(g[nm])
+    h = bucket.all_reduce_head_start(off)
     stage.commit(pde["n_kept"])
-    bucket.all_reduce_mean()
+    bucket.all_reduce_finish(h, off)
     if rank == 0:
         np.savez(out, **{nm: p.grad.detach().contiguous().numpy() for nm, p in zip(names, params)}, w=w, nk=pde["n_kept"])
     dist.destroy_process_group()
