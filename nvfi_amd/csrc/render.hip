@@ -807,14 +807,16 @@ __global__ __launch_bounds__(1024) void k_plane_scatter_lds(ScatterArgs a) {
     }
 }
 
-// Side stream for the plane-gradient scatters: they are bound by L2 atomics and leave the MFMA pipes idle, so the backward forks
-// them next to the weight-gradient / RK2-adjoint kernels and joins before returning (NVFI_SIDE_STREAM=0: everything in order).
+// Optional side stream for the plane-gradient scatters (NVFI_SIDE_STREAM=1): they are bound by L2 atomics and leave the MFMA
+// pipes idle, so the backward can fork them next to the weight-gradient / RK2-adjoint kernels and join before returning.
+// Off by default: it gained 2.5 % while those kernels ran two workgroups per CU, but since they own a CU each (one wave per
+// SIMD with the whole register file, engine.h: FragPipe) a scatter wave cannot co-reside with them and the fork only splits CUs.
 struct SideStream {
     hipStream_t s = nullptr; hipEvent_t fork[2] = {nullptr, nullptr}, join = nullptr; int state = -1;
     int get() {
         if (state >= 0) return state;
         const char* e = getenv("NVFI_SIDE_STREAM");
-        state = (e && atoi(e) == 0) ? 0 : 1;
+        state = (e && atoi(e) != 0) ? 1 : 0;
         if (state) {
             if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) state = 0;
             for (int i = 0; i < 2 && state; ++i) if (hipEventCreateWithFlags(&fork[i], hipEventDisableTiming) != hipSuccess) state = 0;
