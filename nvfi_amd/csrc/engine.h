@@ -178,8 +178,12 @@ __device__ __forceinline__ void layer_mfma(const float* lds_w, int lane, const f
 // the 32x32x2 f32 MFMA's dependent latency equals its issue interval), and `epi(m, acc)` - activation, stash stores,
 // derivative loads - of a finished tile is independent work the scheduler overlaps with the next tile's MFMAs.
 // Only 16 accumulator registers are live, which pays for a second activation array (ping-pong x -> xn).
+// `defer` (optional): the last tile's accumulator is handed back instead of being passed to `epi` - the caller runs that
+// epilogue AFTER it has issued the next layer's staging loads.  (vmcnt counts stores too on gfx9/CDNA: staging loads issued
+// behind the last tile's 16 stash stores waited for their L2 acknowledgement - 28 % of the wave cycles of the training forward.)
 template <int MT, int NS, class Epi>
-__device__ __forceinline__ void layer_tiles(const float* lds_w, const float* lds_b, bool bias, int lane, int h, const float* x, Epi epi) {
+__device__ __forceinline__ void layer_tiles(const float* lds_w, const float* lds_b, bool bias, int lane, int h, const float* x, Epi epi,
+                                            f32x16* defer = nullptr) {
     f32x16 prev;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -206,7 +210,7 @@ __device__ __forceinline__ void layer_tiles(const float* lds_w, const float* lds
         __builtin_amdgcn_sched_barrier(0);
         prev = acc;
     }
-    epi(MT - 1, prev);
+    if (defer) *defer = prev; else epi(MT - 1, prev);
 }
 
 // store / load a block of NR stash registers (one 256-B row per register)
@@ -260,30 +264,43 @@ __device__ __forceinline__ void vel_encode_slots(const float4& q, int h, float* 
 // Must be called by all 4 waves of the workgroup (contains barriers).
 // out4: lane h=0 -> w0..w3 ; lane h=1 -> w4,w5,0,0.
 // zst: this (eval,tile)'s z stash (VEL_Z_REGS rows) or NULL; x0st: x0 stash (16 rows) or NULL.
-template <int ACT>
+// DEFER: run each layer's last-tile epilogue (its stash stores) behind the next layer's staging loads - pays only when a stash
+// is written (the 16 accumulator registers it keeps live cost spills in the stash-less kernels).
+template <int ACT, bool DEFER = false>
 __device__ __forceinline__ void velnet_forward(const VelFrags& W, float* lds_w, float* lds_b, int lane,
                                                const float4& q, float* zst, float* x0st, float* out4) {
     const int h = lane >> 5;
     float xa[64], xb[64];
+    f32x16 last;
+    f32x16* const dp = DEFER ? &last : nullptr;
     vel_encode_slots(q, h, xb);
     if (x0st) stash_store<16>(x0st, lane, xb);
     __syncthreads();
     stage_frag(lds_w, lds_b, W.f[0], VEL_F0, W.b[0], 128);
     __syncthreads();
-    layer_tiles<4, 14>(lds_w, lds_b, true, lane, h, xb, [&](int m, const f32x16& acc) {
+    auto epi0 = [&](int m, const f32x16& acc) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (zst) zst[(16 * m + r) * REGF + lane] = acc[r];
             xa[16 * m + r] = act_f<ACT>(acc[r]);
         }
-    });
+    };
+    layer_tiles<4, 14>(lds_w, lds_b, true, lane, h, xb, epi0, dp);
 #pragma unroll 1
     for (int it = 0; it < 2; ++it) {
         const int l = 1 + 2 * it;
+        float* z0 = zst ? zst + (size_t)(l - 1) * 64 * REGF : nullptr;
         float* z1 = zst ? zst + (size_t)l * 64 * REGF : nullptr;
         float* z2 = zst ? zst + (size_t)(l + 1) * 64 * REGF : nullptr;
         __syncthreads();
         stage_frag(lds_w, lds_b, W.f[l], VEL_FH, W.b[l], 128);
+        if (DEFER) {   // deferred epilogue of the previous layer's last tile (layer l-1 wrote xa)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (z0) z0[(48 + r) * REGF + lane] = last[r];
+                xa[48 + r] = act_f<ACT>(last[r]);
+            }
+        }
         __syncthreads();
         layer_tiles<4, 64>(lds_w, lds_b, true, lane, h, xa, [&](int m, const f32x16& acc) {
 #pragma unroll
@@ -291,9 +308,16 @@ __device__ __forceinline__ void velnet_forward(const VelFrags& W, float* lds_w, 
                 if (z1) z1[(16 * m + r) * REGF + lane] = acc[r];
                 xb[16 * m + r] = act_f<ACT>(acc[r]);
             }
-        });
+        }, dp);
         __syncthreads();
         stage_frag(lds_w, lds_b, W.f[l + 1], VEL_FH, W.b[l + 1], 128);
+        if (DEFER) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (z1) z1[(48 + r) * REGF + lane] = last[r];
+                xb[48 + r] = act_f<ACT>(last[r]);
+            }
+        }
         __syncthreads();
         layer_tiles<4, 64>(lds_w, lds_b, true, lane, h, xb, [&](int m, const f32x16& acc) {
 #pragma unroll
@@ -301,10 +325,18 @@ __device__ __forceinline__ void velnet_forward(const VelFrags& W, float* lds_w, 
                 if (z2) z2[(16 * m + r) * REGF + lane] = acc[r];
                 xa[16 * m + r] = act_f<ACT>(acc[r]);
             }
-        });
+        }, dp);
     }
+    float* z4 = zst ? zst + (size_t)4 * 64 * REGF : nullptr;
     __syncthreads();
     stage_frag(lds_w, lds_b, W.f[5], VEL_F5, W.b[5], 32);
+    if (DEFER) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (z4) z4[(48 + r) * REGF + lane] = last[r];
+            xa[48 + r] = act_f<ACT>(last[r]);
+        }
+    }
     __syncthreads();
     layer_tiles<1, 64>(lds_w, lds_b, true, lane, h, xa, [&](int, const f32x16& acc) {
         out4[0] = acc[0]; out4[1] = acc[1]; out4[2] = acc[2]; out4[3] = acc[3];

@@ -376,8 +376,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_fwd(PdeJetArgs a) {
     float4 q = active ? a.qorig[a.klist[a.first + i]] : zero4();
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
     float o4[4], w[6];
-    if (blockIdx.y == 0) velnet_forward<1>(a.Wv, lds_w, lds_b, lane, q, T + PDE_Z * REGF, T + PDE_X0 * REGF, o4);
-    else velnet_forward<0>(a.Wa, lds_w, lds_b, lane, q, T + PDE_ZA * REGF, nullptr, o4);
+    if (blockIdx.y == 0) velnet_forward<1, true>(a.Wv, lds_w, lds_b, lane, q, T + PDE_Z * REGF, T + PDE_X0 * REGF, o4);
+    else velnet_forward<0, true>(a.Wa, lds_w, lds_b, lane, q, T + PDE_ZA * REGF, nullptr, o4);
     gather6(o4, h, w);
     if (h == 0 && i < a.cap) {
         float* o = a.wout + (size_t)(blockIdx.y == 0 ? 0 : 30) * a.cap + i;

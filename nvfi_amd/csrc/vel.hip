@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_fwd(Rk2Args a) {
         }
         float o4[4], w1[6], w2[6], v1[3], v2[3];
         // v1 = vel(x, t)
-        velnet_forward<1>(a.Wv, lds_w, lds_b, lane, make_float4(x, y, z, tcur), zst1, x0s1, o4);
+        velnet_forward<1, STASH>(a.Wv, lds_w, lds_b, lane, make_float4(x, y, z, tcur), zst1, x0s1, o4);
         gather6(o4, h, w1);
         vel_from_w(w1, x, y, z, v1);
         const bool g1 = gated_out(a.f, x, y, z);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_fwd(Rk2Args a) {
         const float hdt = 0.5f * dt;
         const float px = x - hdt * v1[0], py = y - hdt * v1[1], pz = z - hdt * v1[2];
         const float tm = tcur - hdt;
-        velnet_forward<1>(a.Wv, lds_w, lds_b, lane, make_float4(px, py, pz, tm), zst2, x0s2, o4);
+        velnet_forward<1, STASH>(a.Wv, lds_w, lds_b, lane, make_float4(px, py, pz, tm), zst2, x0s2, o4);
         gather6(o4, h, w2);
         vel_from_w(w2, px, py, pz, v2);
         const bool g2 = gated_out(a.f, px, py, pz);
