@@ -71,6 +71,7 @@ class _RenderFn(torch.autograd.Function):
             ctx.field, ctx.t, ctx.flags, ctx.ws = field, t, flags, ws
             ctx.save_for_backward(rays_o, rays_d, weights, *params)
         ctx.mark_non_differentiable(counters)
+        ctx.set_materialize_grads(False)     # unused outputs (depth, acc, the R x S weights) arrive as None, not as zero tensors
         return rgb, depth, acc, weights, counters
 
     @staticmethod
