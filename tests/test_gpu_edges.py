@@ -1,0 +1,109 @@
+"""Edge cases of the hot path on the GPU: ragged and empty inputs, rays that miss the box, a fully transparent field (the PDE
+keeps no point, as at the reference's initialisation), and the largest configuration of the shipped schedule (199^3 grid with
+step_ratio 0.5 -> 686 samples per ray, ~1.4 M samples per 2048-ray chunk)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small():
+    return make_model("A")
+
+
+def _rays(n, seed=0, miss=False):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor([[2.6, -2.2, 2.4]]).expand(n, 3).contiguous()
+    tgt = (torch.rand(n, 3, generator=g) - 0.5) * 3.0
+    if miss:
+        tgt = tgt + torch.tensor([[40.0, 40.0, 0.0]])      # pointing far away from the box
+    d = tgt - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    return o.cuda(), d.contiguous().cuda()
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 63, 65, 129, 2049])
+def test_ragged_ray_counts(small, n):
+    """sizes that are not multiples of the wave / workgroup / chunk granularity: every prefix of a render equals the render"""
+    model, meta = small
+    f = model.nvfi
+    f.eval()
+    o, d = _rays(2049, 1)
+    with torch.no_grad():
+        full = f(0.41, o, d, True)
+        part = f(0.41, o[:n].contiguous(), d[:n].contiguous(), True)
+    assert torch.equal(part[0], full[0][:n]) and torch.equal(part[1], full[1][:n]) and torch.equal(part[3], full[3][:n])
+
+
+def test_rays_that_miss_the_box(small):
+    model, meta = small
+    f = model.nvfi
+    o, d = _rays(256, 2, miss=True)
+    f.train()
+    model.zero_grad(set_to_none=True)
+    out = f(0.41, o, d, True)
+    assert int(f.last_counters[0]) == 0 and int(f.last_counters[2]) == 0          # no valid sample, nothing masked in
+    assert torch.equal(out[2], torch.zeros_like(out[2]))                           # acc = 0
+    assert torch.allclose(out[0], torch.ones_like(out[0]))                         # white background
+    assert torch.allclose(out[1], torch.full_like(out[1], float(meta["far"])))     # depth = far
+    out[0].sum().backward()                                                        # backward with empty sample lists
+    for p in model.parameters():
+        assert p.grad is None or (torch.isfinite(p.grad).all() and float(p.grad.abs().max()) == 0.0)
+
+
+def test_transparent_field_keeps_no_pde_point():
+    """reference behaviour at initialisation (nvfi.py:66-67): get_vel_loss returns the python float 0."""
+    model, meta = make_model("A")
+    f = model.nvfi
+    with torch.no_grad():
+        for p in f.density_plane_space:
+            p.zero_()                                   # sigma = softplus(-10) ~ 4.5e-5 -> alpha < 1e-4 everywhere
+    g = torch.Generator(device="cuda").manual_seed(0)
+    mn, mx = f.aabb
+    pts = torch.rand(4096, 3, device="cuda", generator=g) * (mx - mn) + mn
+    tt = torch.rand(4096, 1, device="cuda", generator=g)
+    lv = model.get_vel_loss(points=pts, t=tt)
+    assert isinstance(lv, float) and lv == 0.0
+    assert int(f.last_pde_n_kept) == 0
+
+
+def test_largest_shipped_configuration():
+    """199^3 grid, step_ratio 0.5, max_n_samples 1024 -> nSamples = 686: train fwd + bwd on a full 2048-ray chunk, finite
+    gradients everywhere, composite identities, and chunking invariance of the eval render."""
+    import bench
+    from nvfi_amd.models import NVFi
+    cfg = bench.bat_cfg(1024, True)
+    torch.manual_seed(233)
+    m = NVFi(cfg, "cpu", torch.tensor([[-2.0, -2.0, -2.0], [2.0, 2.0, 2.0]]), [199, 199, 199], [1.0, 8.0])
+    f = m.nvfi
+    with torch.no_grad():
+        for i in range(3):
+            p = f.density_plane_space[i]
+            H, W = p.shape[-2:]
+            yy = torch.linspace(-1, 1, H)[:, None]; xx = torch.linspace(-1, 1, W)[None, :]
+            p.mul_((3.2 * torch.sqrt(torch.exp(-xx ** 2 / (2 * 0.35 ** 2)) * torch.exp(-yy ** 2 / (2 * 0.35 ** 2))))[None, None])
+    m = m.cuda()
+    assert f.nSamples == 686, f.nSamples
+    o, d = bench.camera_bundle(torch.device("cuda", 0))
+    g = torch.Generator(device="cuda").manual_seed(4)
+    idx = torch.randint(0, o.shape[0], (2048,), device="cuda", generator=g)
+    ro, rd = o[idx].contiguous(), d[idx].contiguous()
+    f.train()
+    out = f(19.0 / 60.0, ro, rd, True)
+    V = int(f.last_counters[0])
+    assert V > 0.3 * 2048 * 686 and out[3].shape == (2048, 686)
+    assert torch.allclose(out[3].sum(-1), out[2], rtol=1e-5, atol=1e-6)
+    (out[0].square().mean() + 0.01 * out[1].mean()).backward()
+    for name, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), name
+    assert float(f.density_plane_space[0].grad.abs().max()) > 0 and float(f.vel_net.weight_net[4][0].weight.grad.abs().max()) > 0
+    f.eval()
+    with torch.no_grad():
+        full = f(0.32, ro, rd, True)
+        a = f(0.32, ro[:700].contiguous(), rd[:700].contiguous(), True)
+    assert torch.equal(a[0], full[0][:700])
