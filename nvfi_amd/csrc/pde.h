@@ -28,7 +28,7 @@ struct PdePrepArgs {
 struct PdeJetArgs {
     VelFrags Wv, Wa;
     const float4* qorig; const int* klist;
-    int64_t first; int count; int64_t cap;
+    int64_t first; int count; int64_t cap; int wgs;
     float* stash; float* seeds; float* wout; double* sums;
     float inv_n, scale;
     float* jac; int64_t n_jac;

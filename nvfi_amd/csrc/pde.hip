@@ -365,22 +365,37 @@ __device__ __forceinline__ void velnet_value_backward_p(const VelFrags& W, FragP
 // ---- column-parallel jet kernels: the value column, the 4 tangent columns and the a_weight_net column of a
 // tile run in DIFFERENT workgroups (blockIdx.y = column) so that a few ten-thousand kept points still fill 256 CUs.
 
+// XCD-aware (tile, column) mapping of the column-parallel kernels.  Workgroups are dealt to the 8 XCDs round-robin by their
+// linear id, and each XCD has its own L2; the NCOL column workgroups of one tile all read that tile's z stash, so they are
+// given linear ids with the same residue mod 8: id = ((tile/8) * NCOL + col) * 8 + tile%8.  The grid is 1-D with
+// ceil(wgs/8) * 8 * NCOL workgroups; returns false for the padding ids.
+#define PDE_GRID(wgs, ncol) dim3((unsigned)((((wgs) + 7) / 8) * 8 * (ncol)))
+__device__ __forceinline__ bool pde_tile_col(int ncol, int wgs, int& wg, int& col) {
+    const int L = blockIdx.x;
+    const int xcd = L & 7, q = L >> 3;
+    col = q % ncol;
+    wg = (q / ncol) * 8 + xcd;
+    return wg < wgs;
+}
+
 // K1: value forward of weight_net (y=0) and a_weight_net (y=1)
 __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_fwd(PdeJetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int tile = blockIdx.x * 4 + wave_id();
+    int wg, ycol;
+    if (!pde_tile_col(2, a.wgs, wg, ycol)) return;
+    const int tile = wg * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     const bool active = i < a.count;
     float4 q = active ? a.qorig[a.klist[a.first + i]] : zero4();
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
     float o4[4], w[6];
-    if (blockIdx.y == 0) velnet_forward<1, true>(a.Wv, lds_w, lds_b, lane, q, T + PDE_Z * REGF, T + PDE_X0 * REGF, o4);
+    if (ycol == 0) velnet_forward<1, true>(a.Wv, lds_w, lds_b, lane, q, T + PDE_Z * REGF, T + PDE_X0 * REGF, o4);
     else velnet_forward<0, true>(a.Wa, lds_w, lds_b, lane, q, T + PDE_ZA * REGF, nullptr, o4);
     gather6(o4, h, w);
     if (h == 0 && i < a.cap) {
-        float* o = a.wout + (size_t)(blockIdx.y == 0 ? 0 : 30) * a.cap + i;
+        float* o = a.wout + (size_t)(ycol == 0 ? 0 : 30) * a.cap + i;
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[(size_t)k * a.cap] = w[k];
     }
@@ -389,8 +404,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_fwd(PdeJetArgs a) {
 __global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_fwd(PdeJetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int j = blockIdx.y;
-    const int tile = blockIdx.x * 4 + wave_id();
+    int wg, j;
+    if (!pde_tile_col(4, a.wgs, wg, j)) return;
+    const int tile = wg * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
     FragPipe pipe; pipe.init(lds);
@@ -499,8 +515,9 @@ __global__ __launch_bounds__(256) void k_pde_seeds(PdeJetArgs a) {
 __global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_bwd(PdeJetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int j = blockIdx.y;
-    const int tile = blockIdx.x * 4 + wave_id();
+    int wg, j;
+    if (!pde_tile_col(5, a.wgs, wg, j)) return;
+    const int tile = wg * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
     const size_t cs = a.cap;
@@ -649,17 +666,18 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
             ja.Wv = VW; ja.Wa = AW; ja.qorig = L.qorig; ja.klist = L.klist; ja.first = first; ja.count = (int)cnt; ja.cap = cap;
             ja.stash = L.stash; ja.seeds = L.seeds; ja.sums = L.sums; ja.inv_n = inv_n; ja.scale = loss_scale; ja.jac = jac_out; ja.n_jac = n_jac;
             const unsigned wgs = (unsigned)(cap / WG_SAMPLES);
+            ja.wgs = (int)wgs;
             ja.wout = L.wout;
             {
                 ProfScope ps(PK_PDE_FWD, st);
-                hipLaunchKernelGGL(k_pde_value_fwd, dim3(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
-                hipLaunchKernelGGL(k_pde_tangent_fwd, dim3(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
+                hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                hipLaunchKernelGGL(k_pde_tangent_fwd, PDE_GRID(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
                 hipLaunchKernelGGL(k_pde_seeds, dim3((unsigned)(cap / 256 + 1)), dim3(256), 0, st, ja);
             }
             if (grads) {
                 {
                     ProfScope ps(PK_PDE_BWD, st);
-                    hipLaunchKernelGGL(k_pde_tangent_bwd, dim3(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
+                    hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
                     hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
                 }
                 LAUNCHCK();
