@@ -6,8 +6,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["engine.hip", "vel.hip", "render.hip", "pde.hip", "regs.hip", "abi.hip"]
-HEADERS = ["engine.h", "common.h", "vel.h", "render.h", "pde.h", os.path.join("..", "..", "include", "nvfi_hip.h")]
+SOURCES = ["engine.hip", "vel.hip", "render.hip", "scatter.hip", "pde.hip", "regs.hip", "abi.hip"]
+HEADERS = ["engine.h", "common.h", "vel.h", "render.h", "scatter.h", "pde.h", os.path.join("..", "..", "include", "nvfi_hip.h")]
 SO = os.environ.get("NVFI_BUILD_SO", os.path.join(CSRC, "libnvfi_hip.so"))   # experiments build a second library elsewhere
 OBJDIR = os.environ.get("NVFI_BUILD_OBJDIR", CSRC)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"] + os.environ.get("NVFI_EXTRA_FLAGS", "").split()

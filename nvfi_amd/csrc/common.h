@@ -79,7 +79,7 @@ struct Bl {
     float w, e, n, s;  // w = x-floor(x), e = 1-w, n = y-floor(y), s = 1-n
     bool m0, m1, m2, m3;
 };
-__device__ __forceinline__ void bl_setup(float gx, float gy, int W, int H, Bl& b) {
+__device__ __forceinline__ void bl_setup_xy(float gx, float gy, int W, int H, Bl& b, int& x0, int& y0) {
     float x = (gx + 1.f) * ((float)(W - 1) / 2.f);
     float y = (gy + 1.f) * ((float)(H - 1) / 2.f);
     float xf = floorf(x), yf = floorf(y);
@@ -89,12 +89,16 @@ __device__ __forceinline__ void bl_setup(float gx, float gy, int W, int H, Bl& b
     yf = fminf(fmaxf(yf, -4.f), (float)H + 2.f);
     if (!(xf == xf)) xf = -4.f;
     if (!(yf == yf)) yf = -4.f;
-    int x0 = (int)xf, y0 = (int)yf;
+    x0 = (int)xf; y0 = (int)yf;
     bool xi0 = x0 >= 0 && x0 < W, xi1 = x0 + 1 >= 0 && x0 + 1 < W;
     bool yi0 = y0 >= 0 && y0 < H, yi1 = y0 + 1 >= 0 && y0 + 1 < H;
     b.m0 = xi0 && yi0; b.m1 = xi1 && yi0; b.m2 = xi0 && yi1; b.m3 = xi1 && yi1;
     b.base = y0 * W + x0;
     b.W = W;
+}
+__device__ __forceinline__ void bl_setup(float gx, float gy, int W, int H, Bl& b) {
+    int x0, y0;
+    bl_setup_xy(gx, gy, W, H, b, x0, y0);
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

@@ -11,6 +11,7 @@
 // loads; per-ray scans/reductions are wave-level; the MLP contractions run on the MFMA engine.
 #include "common.h"
 #include "render.h"
+#include "scatter.h"
 #include <stdlib.h>
 
 // ================================================================ sampling + compaction
@@ -924,6 +925,7 @@ struct RenderPlan {
     float *vel_frag, *render_frag;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     float *slabs;
+    TileWork tw; bool tiles;   // sorted-tile plane scatter (scatter.hip); tiles = false: grid too large, atomic scatter instead
     int64_t total;
 };
 #define NSLAB_MAX 1024
@@ -931,6 +933,7 @@ static int nslab_rt() { static int n = -1; if (n < 0) { const char* e = getenv("
 #define NSLAB (nslab_rt())
 #define SLAB_FLOATS (128 * 128 + 128)
 
+static bool use_tiles() { static int u = -1; if (u < 0) { const char* e = getenv("NVFI_SCATTER_TILES"); u = e ? atoi(e) : 1; } return u != 0; }
 static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nsteps, void* ws, RenderPlan* P) {
     Bump B{(char*)ws, 0, 0};
     const int64_t N = R * f->n_samples;
@@ -956,6 +959,8 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
         P->app_f = B.take<float>(P->cap_tiles * (int64_t)(APP_F_ROWS * REGF));
         P->app_b = B.take<float>(P->cap_tiles * (int64_t)(APP_B_ROWS * REGF));
         P->slabs = B.take<float>((int64_t)NSLAB_MAX * SLAB_FLOATS * 6);
+        P->tiles = tile_geom(f, &P->tw.g) == 0 && use_tiles();
+        if (P->tiles) plan_tile_scatter(B, f, N, &P->tw);
         if (nsteps > 0) {
             const int64_t nev = 2 * (int64_t)nsteps;
             P->zst = B.take<float>(nev * P->cap_tiles * (int64_t)(VEL_Z_REGS * REGF));
@@ -1092,12 +1097,12 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     const int64_t N = P.N;
     const float tn = f->use_vel ? norm_time(*f, base) : norm_time(*f, t);
     const unsigned ray_blocks = (unsigned)((R + 3) / 4);
+    const bool side = g_side.get() != 0 && !P.tiles;   // the tile scatter reuses one og buffer for both branches: same stream
     // fragments were packed by the forward into the same workspace
     VelFrags VW; RenderFrags RW; PackJobs dummy; dummy.n = 0;
     if (f->use_vel && nsteps > 0) pack_vel_frags(f->vW, f->vb, P.vel_frag, &VW, &dummy);
     dummy.n = 0;
     pack_render_frags(f, P.render_frag, &RW, &dummy);
-    const bool side = g_side.get() != 0;
     bool forked = false;
     // appearance branch
     AppArgs aa; memset(&aa, 0, sizeof(aa));
@@ -1112,7 +1117,13 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
         hipStream_t ss = st;
         if (side) { HIPCK(hipEventRecord(g_side.fork[0], st)); HIPCK(hipStreamWaitEvent(g_side.s, g_side.fork[0], 0)); ss = g_side.s; forked = true; }
         ProfScope ps(PK_APP_SCATTER, ss);
-        if (launch_scatter(f, sa, 48, N, tn, ss)) return 1;
+        if (P.tiles) {
+            if (tile_work_init(P.tw, ss)) return 1;
+            OgArgs oa; memset(&oa, 0, sizeof(oa));
+            oa.f = *f; oa.count = P.counters + 1; oa.list = P.mlist; oa.xw = P.xw; oa.tn = tn; oa.gg = P.gg; oa.og = P.tw.og;
+            if (launch_og(f, oa, 48, false, N, ss)) return 1;
+            if (launch_tile_scatter(f, P.tw, P.counters + 1, P.mlist, P.xw, tn, *grads, 48, N, ss)) return 1;
+        } else if (launch_scatter(f, sa, 48, N, tn, ss)) return 1;
     }
     LAUNCHCK();
     // render-MLP weight gradients
@@ -1148,8 +1159,23 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     DensityArgs da; memset(&da, 0, sizeof(da));
     da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn;
     da.gxpre = P.gxpre; memset(&da.g, 0, sizeof(da.g)); da.mflag = P.mflag; da.gxw = P.gxw; da.gxk = nsteps > 0 ? P.gxk : nullptr;
-    if (nsteps > 0) { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
-    if (grads->dps[0] || grads->dpt[0]) {
+    const bool want_dplanes = grads->dps[0] || grads->dpt[0];
+    if (P.tiles) {
+        // one pass over the samples: per-plane value gradients (og) for the tile scatter and, at non-keyframe times, the coordinate gradients
+        if (nsteps > 0 || want_dplanes) {
+            ProfScope ps(PK_DENSITY_BWD, st);
+            OgArgs oa; memset(&oa, 0, sizeof(oa));
+            oa.f = *f; oa.count = P.counters + 0; oa.list = P.vlist; oa.xw = P.xw; oa.tn = tn; oa.gxpre = P.gxpre; oa.og = want_dplanes ? P.tw.og : nullptr;
+            oa.mflag = P.mflag; oa.gxw = P.gxw; oa.gxk = nsteps > 0 ? P.gxk : nullptr;
+            if (launch_og(f, oa, 24, nsteps > 0, N, st)) return 1;
+        }
+        if (want_dplanes) {
+            ProfScope ps(PK_DENSITY_SCATTER, st);
+            if (!(grads->aps[0] || grads->apt[0]) && tile_work_init(P.tw, st)) return 1;
+            if (launch_tile_scatter(f, P.tw, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, st)) return 1;
+        }
+    } else if (nsteps > 0) { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
+    if (!P.tiles && want_dplanes) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
         sa.f = *f; sa.count = P.counters + 0; sa.list = P.vlist; sa.xw = P.xw; sa.tn = tn; sa.gxpre = P.gxpre; sa.g = *grads; sa.plane_mask = scatter_mask();
         hipStream_t ss = st;

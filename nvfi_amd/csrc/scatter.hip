@@ -1,0 +1,411 @@
+// scatter.hip - plane-gradient scatter through sorted plane tiles, and the (sample, channel-quad) gather kernels.
+//
+// Backward of the factor-plane lookups (autograd of models/tensorf_keyframe.py:233-310: F.grid_sample on the six planes of the
+// density / appearance factorisation): every sample adds  w_tap * d(loss)/d(value_p[c])  to 4 texels x C channels of each plane.
+//
+// Measured on MI355X (tools/probes/lds_atomic_probe.hip):
+//   * device-scope fp32 atomics run at ~2.6e11 lane-atomics/s for the whole chip whatever the occupancy (they are executed
+//     past the XCD L2s), so 4.3e7 taps per call are a 0.17 ms floor;
+//   * LDS fp32 atomics (ds_add_f32) take ~190 cycles per 64-lane instruction per CU (one lane every 3 cycles) - 50x slower than
+//     a plain LDS read-add-write;
+//   * thread-per-sample gathers with a loop over channel quads are latency bound (one memory round trip per quad and plane).
+// Hence:
+//   k_og          lanes = (sample, channel quad): the 24 tap loads of a lane are unconditional (clamped addresses, masked by a
+//                 select) and all in flight together; writes og[i][p][c] = d(loss)/d(value_p[c]) and, for the density branch,
+//                 the coordinate gradients (replaces the per-sample loop of k_density_bwd).
+//   k_tile_hist / k_tile_scan / k_tile_fill   counting sort of the samples by TxT-texel tile, once per space plane.
+//   k_tile_scatter   ONE WAVE per (plane, tile, chunk of samples): the tile (+1 texel apron) of the space plane and the matching
+//                 strip of the paired time plane live in LDS and are updated with PLAIN read-add-write - a single wave executes
+//                 its LDS instructions in order and the lanes of one instruction ((channel, x-tap)) never collide - then flushed
+//                 with one contiguous run of global atomics per tile row.  Global atomics drop from 576 per sample to
+//                 (tiles x apron) per chunk.
+// Pairing of time planes: the time plane whose spatial axis is one of the space plane's axes shares that axis' tap index, so its
+// two touched rows restricted to the tile are a (T+1)-texel strip:  plane 0 (x,y) <-> time plane 5 (x), plane 1 (x,z) <-> time
+// plane 3 (z), plane 2 (y,z) <-> time plane 4 (y).
+#include "common.h"
+#include "render.h"
+#include "scatter.h"
+
+#define TT SCATTER_T
+#define TW (TT + 1)
+
+// ---------------------------------------------------------------- branch-free bilinear taps
+struct Tap {
+    int o[4];      // float offsets of the 4 taps (texel * C), 0 when masked
+    float w[4];    // nw, ne, sw, se (un-masked: the loaded value is zeroed instead, as grid_sample's zero padding)
+    bool m[4];
+    float fw, fe, fn, fs;
+};
+__device__ __forceinline__ void tap_setup(const Bl& b, int C, Tap& t) {
+    const int o0 = b.base * C, oW = b.W * C;
+    t.m[0] = b.m0; t.m[1] = b.m1; t.m[2] = b.m2; t.m[3] = b.m3;
+    t.o[0] = b.m0 ? o0 : 0; t.o[1] = b.m1 ? o0 + C : 0; t.o[2] = b.m2 ? o0 + oW : 0; t.o[3] = b.m3 ? o0 + oW + C : 0;
+    t.w[0] = b.e * b.s; t.w[1] = b.w * b.s; t.w[2] = b.e * b.n; t.w[3] = b.w * b.n;
+    t.fw = b.w; t.fe = b.e; t.fn = b.n; t.fs = b.s;
+}
+__device__ __forceinline__ float4 sel4(bool m, const float4& v) { return m ? v : zero4(); }
+
+// ---------------------------------------------------------------- k_og
+// LPS lanes per sample (8 for C=24, 16 for C=48), C/4 of them active.
+template <int C, bool COORD>
+__global__ __launch_bounds__(256) void k_og(OgArgs a) {
+    constexpr int LPS = C == 24 ? 8 : 16, NQ = C / 4, SPW = 256 / LPS;
+    const nvfi_field_desc& f = a.f;
+    const int count = *a.count;
+    const int sub = threadIdx.x % LPS;
+    const int i = blockIdx.x * SPW + threadIdx.x / LPS;
+    if (blockIdx.x * SPW >= count) return;
+    const bool act = i < count && sub < NQ;
+    const int ic = i < count ? i : count - 1;
+    const int n = a.list[ic];
+    const float4 q = a.xw[n];
+    const int qd = sub < NQ ? sub : 0;
+    float4 g4;
+    if (C == 24) { const float g = a.gxpre[n]; g4 = make_float4(g, g, g, g); }
+    else g4 = *reinterpret_cast<const float4*>(a.gg + (size_t)ic * 48 + 4 * qd);
+    Bl b[6];
+    plane_setups(f, q.x, q.y, q.z, a.tn, b);
+    const float* pl[6];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { pl[p] = C == 24 ? f.dps[p] : f.aps[p]; pl[3 + p] = C == 24 ? f.dpt[p] : f.apt[p]; }
+    float4 v[6][4];
+    Tap t[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        tap_setup(b[p], C, t[p]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[p][k] = ld4(pl[p] + t[p].o[k] + 4 * qd);
+    }
+    float4 val[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[p][k] = sel4(t[p].m[k], v[p][k]);
+        val[p].x = v[p][0].x * t[p].w[0] + v[p][1].x * t[p].w[1] + v[p][2].x * t[p].w[2] + v[p][3].x * t[p].w[3];
+        val[p].y = v[p][0].y * t[p].w[0] + v[p][1].y * t[p].w[1] + v[p][2].y * t[p].w[2] + v[p][3].y * t[p].w[3];
+        val[p].z = v[p][0].z * t[p].w[0] + v[p][1].z * t[p].w[1] + v[p][2].z * t[p].w[2] + v[p][3].z * t[p].w[3];
+        val[p].w = v[p][0].w * t[p].w[0] + v[p][1].w * t[p].w[1] + v[p][2].w * t[p].w[2] + v[p][3].w * t[p].w[3];
+    }
+    // o[p] = g * prod_{k != p} val[k]  (prefix / suffix products)
+    float4 L[6], Rr[6], o[6];
+    L[0] = g4;
+#pragma unroll
+    for (int p = 1; p < 6; ++p) L[p] = make_float4(L[p - 1].x * val[p - 1].x, L[p - 1].y * val[p - 1].y, L[p - 1].z * val[p - 1].z, L[p - 1].w * val[p - 1].w);
+    Rr[5] = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int p = 4; p >= 0; --p) Rr[p] = make_float4(Rr[p + 1].x * val[p + 1].x, Rr[p + 1].y * val[p + 1].y, Rr[p + 1].z * val[p + 1].z, Rr[p + 1].w * val[p + 1].w);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        o[p] = make_float4(L[p].x * Rr[p].x, L[p].y * Rr[p].y, L[p].z * Rr[p].z, L[p].w * Rr[p].w);
+        if (act && a.og) *reinterpret_cast<float4*>(a.og + ((size_t)i * 6 + p) * C + 4 * qd) = o[p];
+    }
+    if (COORD) {
+        float g3[3] = {0.f, 0.f, 0.f};
+        if (act) {
+            float gx[6], gy[6];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                const float4 &v0 = v[p][0], &v1 = v[p][1], &v2 = v[p][2], &v3 = v[p][3], &g = o[p];
+                const float s = t[p].fs, nn = t[p].fn, e = t[p].fe, w = t[p].fw;
+                gx[p] = ((v1.x - v0.x) * s + (v3.x - v2.x) * nn) * g.x + ((v1.y - v0.y) * s + (v3.y - v2.y) * nn) * g.y +
+                        ((v1.z - v0.z) * s + (v3.z - v2.z) * nn) * g.z + ((v1.w - v0.w) * s + (v3.w - v2.w) * nn) * g.w;
+                gy[p] = ((v2.x - v0.x) * e + (v3.x - v1.x) * w) * g.x + ((v2.y - v0.y) * e + (v3.y - v1.y) * w) * g.y +
+                        ((v2.z - v0.z) * e + (v3.z - v1.z) * w) * g.z + ((v2.w - v0.w) * e + (v3.w - v1.w) * w) * g.w;
+            }
+            float mx, my;
+            plane_mults(f, 0, mx, my); g3[0] += gx[0] * mx; g3[1] += gy[0] * my;
+            plane_mults(f, 1, mx, my); g3[0] += gx[1] * mx; g3[2] += gy[1] * my;
+            plane_mults(f, 2, mx, my); g3[1] += gx[2] * mx; g3[2] += gy[2] * my;
+            plane_mults(f, 3, mx, my); g3[2] += gx[3] * mx;
+            plane_mults(f, 4, mx, my); g3[1] += gx[4] * mx;
+            plane_mults(f, 5, mx, my); g3[0] += gx[5] * mx;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int d = 1; d < LPS; d <<= 1) g3[c] += __shfl_xor(g3[c], d);
+        if (i < count && sub == 0 && a.gxk) {
+            const float4 ga = (a.mflag && a.mflag[n]) ? a.gxw[n] : zero4();   // appearance-branch part (masked samples only)
+            a.gxk[i] = make_float4(ga.x + g3[0], ga.y + g3[1], ga.z + g3[2], 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- tile sort
+__device__ __forceinline__ int tile_of(float gx, float gy, int W, int H, int ntx) {
+    float x = (gx + 1.f) * ((float)(W - 1) / 2.f), y = (gy + 1.f) * ((float)(H - 1) / 2.f);
+    float xf = floorf(x), yf = floorf(y);
+    xf = fminf(fmaxf(xf, 0.f), (float)(W - 1)); yf = fminf(fmaxf(yf, 0.f), (float)(H - 1));
+    if (!(xf == xf)) xf = 0.f;
+    if (!(yf == yf)) yf = 0.f;
+    return ((int)yf / TT) * ntx + (int)xf / TT;
+}
+__device__ __forceinline__ void bins_of(const TileGeom& g, const float4& q, int* b) {
+    b[0] = tile_of(q.x, q.y, g.G[0], g.G[1], g.ntx[0]);
+    b[1] = g.boff[1] + tile_of(q.x, q.z, g.G[0], g.G[2], g.ntx[1]);
+    b[2] = g.boff[2] + tile_of(q.y, q.z, g.G[1], g.G[2], g.ntx[2]);
+}
+
+__global__ __launch_bounds__(512) void k_tile_hist(TileSortArgs a) {
+    extern __shared__ int h[];
+    const int nb = a.g.nbins;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) h[k] = 0;
+    __syncthreads();
+    const int count = *a.count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const float4 q = a.xw[a.list[i]];
+        int b[3];
+        bins_of(a.g, q, b);
+        atomicAdd(&h[b[0]], 1); atomicAdd(&h[b[1]], 1); atomicAdd(&h[b[2]], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) if (h[k]) atomicAdd(&a.hist[k], h[k]);
+}
+
+// one workgroup: tile starts (exclusive scan of the bin counts), chunk items, cursors; clears the histogram for the next call
+__global__ __launch_bounds__(1024) void k_tile_scan(TileSortArgs a) {
+    __shared__ int wsum[2][16];
+    __shared__ int carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nb = a.g.nbins;
+    if (tid == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int k = base + tid;
+        const int c = k < nb ? a.hist[k] : 0;
+        const int nc = (c + SCATTER_CHUNK - 1) / SCATTER_CHUNK;
+        int i0 = c, i1 = nc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t0 = __shfl_up(i0, o), t1 = __shfl_up(i1, o); if (lane >= o) { i0 += t0; i1 += t1; } }
+        if (lane == 63) { wsum[0][w] = i0; wsum[1][w] = i1; }
+        __syncthreads();
+        int w0 = 0, w1 = 0;
+        for (int j = 0; j < w; ++j) { w0 += wsum[0][j]; w1 += wsum[1][j]; }
+        const int c0 = carry[0], c1 = carry[1];
+        const int start = c0 + w0 + i0 - c, istart = c1 + w1 + i1 - nc;
+        if (k < nb) {
+            a.cursor[k] = start;
+            a.hist[k] = 0;
+            for (int j = 0; j < nc; ++j) {
+                int4 it; it.x = k; it.y = start + j * SCATTER_CHUNK; it.z = min(SCATTER_CHUNK, c - j * SCATTER_CHUNK); it.w = 0;
+                a.items[istart + j] = it;
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) { carry[0] = c0 + w0 + i0; carry[1] = c1 + w1 + i1; }
+        __syncthreads();
+    }
+    if (tid == 0) *a.nitems = carry[1];
+}
+
+__global__ __launch_bounds__(512) void k_tile_fill(TileSortArgs a) {
+    extern __shared__ int sh[];
+    const int nb = a.g.nbins;
+    int* cnt = sh; int* bas = sh + nb;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    const int count = *a.count;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int b[3] = {0, 0, 0}, r[3] = {0, 0, 0};
+    if (i < count) {
+        const float4 q = a.xw[a.list[i]];
+        bins_of(a.g, q, b);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) r[p] = atomicAdd(&cnt[b[p]], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) if (cnt[k]) bas[k] = atomicAdd(&a.cursor[k], cnt[k]);
+    __syncthreads();
+    if (i < count) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a.sorted[bas[b[p]] + r[p]] = i;
+    }
+}
+
+// ---------------------------------------------------------------- tile scatter: one workgroup per item, one private tile per wave
+__device__ __forceinline__ float rl_f(float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k)); }
+
+#define TS_WAVES 8
+#define TS_U 16      // per-sample gradient rows in flight per wave (rolling prefetch)
+#define TS_SP (TW * TW * 24)
+#define TS_TM (2 * TW * 24)
+// A wave's share of an item is at most 64 samples, so lane s first prepares sample s on its own (tap addresses inside the LDS tile,
+// the four bilinear weights, the tap masks) and the sample loop only broadcasts those ten values (v_readlane) - the per-sample
+// instruction count, which every lane of the wave pays, drops ~4x against computing the taps in the loop.  Masked taps are
+// redirected to a per-lane dummy word so the read-add-write stays branch-free.
+template <int CT>
+__global__ __launch_bounds__(64 * TS_WAVES) void k_tile_scatter(TileScatterArgs a) {
+    __shared__ float sp_all[TS_WAVES][TS_SP + TS_TM + 64];
+    if ((int)blockIdx.x >= *a.nitems) return;
+    const nvfi_field_desc& f = a.f;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sp = sp_all[wv];                 // [0, TS_SP) space tile, [TS_SP, TS_SP+TS_TM) time strip, then 64 dummy words
+    const int4 item = a.items[blockIdx.x];
+    const int c0 = blockIdx.y * 24;
+    const int p = item.x >= a.geo.boff[2] ? 2 : (item.x >= a.geo.boff[1] ? 1 : 0);
+    const int tile = item.x - a.geo.boff[p];
+    const int ty = tile / a.geo.ntx[p], tx = tile - ty * a.geo.ntx[p];
+    const int ox = tx * TT, oy = ty * TT;
+    const int ia = p == 2 ? 1 : 0, ib = p == 0 ? 1 : 2;       // matModeSpace axes of plane p
+    const int W = f.G[ia], H = f.G[ib];
+    const int tp = p == 0 ? 5 : (p == 1 ? 3 : 4);              // paired time plane
+    const bool t_on_u = p != 1;                                // the time plane's spatial axis is the u (x-tap) axis of plane p, else v
+    const int Wt = t_on_u ? W : H, ot = t_on_u ? ox : oy;
+    float* gsp = CT == 24 ? a.g.dps[p] : a.g.aps[p];
+    float* gtm = CT == 24 ? a.g.dpt[tp - 3] : a.g.apt[tp - 3];
+    for (int k = lane; k < TS_SP + TS_TM + 64; k += 64) sp[k] = 0.f;
+    const int ch = lane >> 1, dx = lane & 1;
+    const bool lane_on = lane < 48;
+    const int chs = lane_on ? ch : 0;
+    const int dummy = TS_SP + TS_TM + lane;
+    // this wave's share of the item (<= 64 samples): lane s prepares sample s
+    const int per = (((item.z + TS_WAVES - 1) / TS_WAVES) + TS_U - 1) / TS_U * TS_U;
+    const int w_lo = min(item.z, wv * per), nw = min(item.z, w_lo + per) - w_lo;
+    int il = 0, as = 0, at = 0;             // sample index; packed (tile address << 4 | tap masks) for the space tile / time strip
+    float ws[4] = {0.f, 0.f, 0.f, 0.f}, wt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lane < nw) {
+        il = a.sorted[item.y + w_lo + lane];
+        const float4 q = a.xw[a.list[il]];
+        const float uu = ia == 0 ? q.x : q.y, vv = ib == 1 ? q.y : q.z;
+        Bl b, bt;
+        int x0, y0, xt, yt;
+        bl_setup_xy(uu, vv, W, H, b, x0, y0);
+        bl_setup_xy(t_on_u ? uu : vv, a.tn, Wt, f.K, bt, xt, yt);
+        ws[0] = b.e * b.s; ws[1] = b.w * b.s; ws[2] = b.e * b.n; ws[3] = b.w * b.n;
+        wt[0] = bt.e * bt.s; wt[1] = bt.w * bt.s; wt[2] = bt.e * bt.n; wt[3] = bt.w * bt.n;
+        const int ms = (b.m0 ? 1 : 0) | (b.m1 ? 2 : 0) | (b.m2 ? 4 : 0) | (b.m3 ? 8 : 0);
+        const int mt = (bt.m0 ? 1 : 0) | (bt.m1 ? 2 : 0) | (bt.m2 ? 4 : 0) | (bt.m3 ? 8 : 0);
+        // any un-masked tap implies -1 <= x0-ox <= T-1 and -1 <= y0-oy <= T-1 (tile_of clamps the same floor), so the biased
+        // address below is non-negative whenever it is used
+        as = ((((y0 - oy) * TW + (x0 - ox)) * 24 + 1024) << 4) | ms;
+        at = (((xt - ot) * 24 + 1024) << 4) | mt;
+    }
+    float gs[TS_U], gt[TS_U];
+    auto issue = [&](int s, int slot) {
+        const int sc = s < nw ? s : 0;
+        const int i = __builtin_amdgcn_readlane(il, sc);
+        gs[slot] = a.og[((size_t)i * 6 + p) * CT + c0 + chs];
+        gt[slot] = a.og[((size_t)i * 6 + tp) * CT + c0 + chs];
+    };
+    const int loff = dx * 24 + ch - 1024;
+    if (nw > 0) {
+#pragma unroll
+        for (int j = 0; j < TS_U; ++j) issue(j, j);
+#pragma unroll 1
+        for (int s0 = 0; s0 < nw; s0 += TS_U) {
+#pragma unroll
+            for (int j = 0; j < TS_U; ++j) {
+                const int s = s0 + j;
+                const float g_s = gs[j], g_t = gt[j];
+                issue(s + TS_U, j);
+                if (s < nw) {
+                    const int pas = __builtin_amdgcn_readlane(as, s), pat = __builtin_amdgcn_readlane(at, s);
+                    const float w00 = rl_f(ws[0], s), w01 = rl_f(ws[1], s), w10 = rl_f(ws[2], s), w11 = rl_f(ws[3], s);
+                    const float t00 = rl_f(wt[0], s), t01 = rl_f(wt[1], s), t10 = rl_f(wt[2], s), t11 = rl_f(wt[3], s);
+                    const int a0 = (pas >> 4) + loff, b0 = (pat >> 4) + loff + TS_SP;
+                    const bool m0 = lane_on && ((pas >> dx) & 1), m1 = lane_on && ((pas >> (2 + dx)) & 1);
+                    const bool n0 = lane_on && ((pat >> dx) & 1), n1 = lane_on && ((pat >> (2 + dx)) & 1);
+                    const int i0 = m0 ? a0 : dummy, i1 = m1 ? a0 + TW * 24 : dummy;
+                    const int j0 = n0 ? b0 : dummy, j1 = n1 ? b0 + TW * 24 : dummy;
+                    const float r0 = sp[i0], r1 = sp[i1], q0 = sp[j0], q1 = sp[j1];
+                    // (i0 == i1 or j0 == j1 only on the dummy word, whose value is never used)
+                    sp[i0] = r0 + (dx ? w01 : w00) * g_s;
+                    sp[i1] = r1 + (dx ? w11 : w10) * g_s;
+                    sp[j0] = q0 + (dx ? t01 : t00) * g_t;
+                    sp[j1] = q1 + (dx ? t11 : t10) * g_t;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // flush the sum of the waves' private tiles: contiguous runs of (texel, channel) per tile row
+    if (gsp) {
+        for (int k = threadIdx.x; k < TW * TW * 24; k += 64 * TS_WAVES) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < TS_WAVES; ++w) v += sp_all[w][k];
+            if (v != 0.f) {
+                const int c = k % 24, tx2 = (k / 24) % TW, ty2 = k / (24 * TW);
+                const int X = ox + tx2, Y = oy + ty2;
+                if (X < W && Y < H) atomicAdd(gsp + ((size_t)Y * W + X) * CT + c0 + c, v);
+            }
+        }
+    }
+    if (gtm) {
+        for (int k = threadIdx.x; k < 2 * TW * 24; k += 64 * TS_WAVES) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < TS_WAVES; ++w) v += sp_all[w][TS_SP + k];
+            if (v != 0.f) {
+                const int c = k % 24, tx2 = (k / 24) % TW, r = k / (24 * TW);
+                const int X = ot + tx2, Y = a.y0 + r;
+                if (X < Wt && Y >= 0 && Y < f.K) atomicAdd(gtm + ((size_t)Y * Wt + X) * CT + c0 + c, v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host
+int tile_geom(const nvfi_field_desc* f, TileGeom* g) {
+    const int ia[3] = {0, 0, 1}, ib[3] = {1, 2, 2};
+    int off = 0;
+    for (int p = 0; p < 3; ++p) {
+        g->ntx[p] = (f->G[ia[p]] + TT - 1) / TT;
+        const int nty = (f->G[ib[p]] + TT - 1) / TT;
+        g->boff[p] = off;
+        off += g->ntx[p] * nty;
+    }
+    g->nbins = off;
+    for (int c = 0; c < 3; ++c) g->G[c] = f->G[c];
+    return off <= SCATTER_MAX_BINS ? 0 : 1;
+}
+
+int64_t tile_items_cap(const TileGeom& g, int64_t N) { return 3 * ((N + SCATTER_CHUNK - 1) / SCATTER_CHUNK) + g.nbins; }
+
+void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w) {
+    tile_geom(f, &w->g);
+    w->hist = B.take<int>(w->g.nbins); w->cursor = B.take<int>(w->g.nbins); w->nitems = B.take<int>(4);
+    w->items = B.take<int4>(tile_items_cap(w->g, N));
+    w->sorted = B.take<int>(3 * N);
+    w->og = B.take<float>(N * 6 * 48);
+    w->cap_items = tile_items_cap(w->g, N);
+}
+
+// histogram storage must be zero before the first k_tile_hist of a workspace; k_tile_scan re-zeroes it after every use
+int tile_work_init(const TileWork& w, hipStream_t st) {
+    HIPCK(hipMemsetAsync(w.hist, 0, sizeof(int) * w.g.nbins, st));
+    return 0;
+}
+
+int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int64_t N, hipStream_t st) {
+    const int spw = C == 24 ? 32 : 16;
+    const unsigned blocks = (unsigned)((N + spw - 1) / spw);
+    if (C == 24) {
+        if (coord) hipLaunchKernelGGL((k_og<24, true>), dim3(blocks), dim3(256), 0, st, oa);
+        else hipLaunchKernelGGL((k_og<24, false>), dim3(blocks), dim3(256), 0, st, oa);
+    } else hipLaunchKernelGGL((k_og<48, false>), dim3(blocks), dim3(256), 0, st, oa);
+    LAUNCHCK();
+    return 0;
+}
+
+int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* count, const int* list, const float4* xw, float tn,
+                        const nvfi_grads& g, int C, int64_t N, hipStream_t st) {
+    TileSortArgs sa; memset(&sa, 0, sizeof(sa));
+    sa.g = w.g; sa.count = count; sa.list = list; sa.xw = xw; sa.hist = w.hist; sa.cursor = w.cursor; sa.items = w.items; sa.nitems = w.nitems; sa.sorted = w.sorted;
+    const int nb = w.g.nbins;
+    unsigned hb = (unsigned)((N + 511) / 512); if (hb > 512) hb = 512;
+    hipLaunchKernelGGL(k_tile_hist, dim3(hb), dim3(512), sizeof(int) * nb, st, sa);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, sa);
+    hipLaunchKernelGGL(k_tile_fill, dim3((unsigned)((N + 511) / 512)), dim3(512), sizeof(int) * 2 * nb, st, sa);
+    TileScatterArgs ta; memset(&ta, 0, sizeof(ta));
+    ta.f = *f; ta.geo = w.g; ta.items = w.items; ta.nitems = w.nitems; ta.sorted = w.sorted; ta.list = list; ta.xw = xw; ta.og = w.og; ta.tn = tn;
+    ta.g = g;
+    const float y = (tn + 1.f) * ((float)(f->K - 1) / 2.f);
+    float yf = floorf(y);
+    yf = fminf(fmaxf(yf, -4.f), (float)f->K + 2.f);
+    ta.y0 = (int)yf;
+    if (C == 24) hipLaunchKernelGGL(k_tile_scatter<24>, dim3((unsigned)w.cap_items, 1), dim3(64 * TS_WAVES), 0, st, ta);
+    else hipLaunchKernelGGL(k_tile_scatter<48>, dim3((unsigned)w.cap_items, 2), dim3(64 * TS_WAVES), 0, st, ta);
+    LAUNCHCK();
+    return 0;
+}
