@@ -105,11 +105,15 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 
 // 4 consecutive channels (float4 index q4) of the bilinear sample; C = channels per texel
 __device__ __forceinline__ float4 bl_sample4(const float* __restrict__ plane, int C, const Bl& b, int q4) {
+    // unconditional loads (a masked tap reads texel 0 and is zeroed by a select): the four taps - and, in the callers' loops, the
+    // taps of all six planes - are in flight together instead of one exec-masked branch and wait per tap
     const float* p = plane + (size_t)b.base * C + 4 * q4;
-    float4 v0 = b.m0 ? ld4(p) : zero4();
-    float4 v1 = b.m1 ? ld4(p + C) : zero4();
-    float4 v2 = b.m2 ? ld4(p + (size_t)b.W * C) : zero4();
-    float4 v3 = b.m3 ? ld4(p + (size_t)b.W * C + C) : zero4();
+    const float* safe = plane + 4 * q4;
+    float4 v0 = ld4(b.m0 ? p : safe);
+    float4 v1 = ld4(b.m1 ? p + C : safe);
+    float4 v2 = ld4(b.m2 ? p + (size_t)b.W * C : safe);
+    float4 v3 = ld4(b.m3 ? p + (size_t)b.W * C + C : safe);
+    v0 = b.m0 ? v0 : zero4(); v1 = b.m1 ? v1 : zero4(); v2 = b.m2 ? v2 : zero4(); v3 = b.m3 ? v3 : zero4();
     float nw = b.e * b.s, ne = b.w * b.s, sw = b.e * b.n, se = b.w * b.n;
     float4 r;
     r.x = v0.x * nw + v1.x * ne + v2.x * sw + v3.x * se;

@@ -15,6 +15,7 @@
 #include "vel.h"
 #include "render.h"
 #include "pde.h"
+#include "scatter.h"
 
 // ---------------------------------------------------------------- prefilter
 __global__ __launch_bounds__(256) void k_pde_prep(PdePrepArgs a) {
@@ -67,15 +68,12 @@ __global__ __launch_bounds__(256) void k_pde_bucket(int64_t P, const int* cls, c
     perm[p] = (int)i;
     pt_t_perm[p] = pt_t[i]; pt_base_perm[p] = pt_base[i];
 }
-// density at the warped point -> alpha -> keep flag (nvfi.py:56-64); one wave = 64 consecutive points
-__global__ __launch_bounds__(256) void k_pde_keep(nvfi_field_desc f, int64_t P, const float4* xw, uint8_t* flags, int* cnt) {
+// density at the warped point (k_density_q, scatter.hip) -> alpha -> keep flag (nvfi.py:56-64); one wave = 64 consecutive points
+__global__ __launch_bounds__(256) void k_pde_keep(nvfi_field_desc f, int64_t P, const float* sig, uint8_t* flags, int* cnt) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     bool keep = false;
     if (i < P) {
-        const float4 q = xw[i];
-        const float ft = density_feature(f, q.x, q.y, q.z, q.w);
-        const float sigma = softplus_f(ft + f.density_shift);
-        const float alpha = 1.f - expf(-sigma * 0.01f * 25.f);
+        const float alpha = 1.f - expf(-sig[i] * 0.01f * 25.f);
         keep = alpha >= f.alpha_thres;
         flags[i] = keep ? 1 : 0;
     }
@@ -574,6 +572,7 @@ struct PdePlan {
     float *pt_t, *pt_base, *pt_t_perm, *pt_base_perm;
     int *cls, *rank, *cls_count, *perm, *cnt, *off, *klist, *kcount, *dcount;
     uint8_t* flags;
+    float* sig;     // density at the warped points (prefilter)
     double* sums;
     float *vel_frag, *a_frag, *stash, *seeds, *wout, *slabs;
     int64_t chunk, total;
@@ -586,6 +585,7 @@ static void plan_pde(int64_t P, void* ws, PdePlan* L) {
     L->cls = B.take<int>(P); L->rank = B.take<int>(P); L->cls_count = B.take<int>(PDE_MAX_CLASS + 16); L->perm = B.take<int>(P);
     L->cnt = B.take<int>(nw); L->off = B.take<int>(nw + 1); L->klist = B.take<int>(P); L->kcount = L->cls_count + PDE_MAX_CLASS;
     L->flags = B.take<uint8_t>(nw * 64);
+    L->sig = B.take<float>(nw * 64);
     L->sums = B.take<double>(4);
     L->dcount = B.take<int>(16);
     L->vel_frag = B.take<float>(VEL_FRAG_FLOATS); L->a_frag = B.take<float>(VEL_FRAG_FLOATS);
@@ -645,7 +645,12 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
         if (launch_rk2_fwd(ra, P, false, false, st)) return 1;
     }
     const int64_t nw = (P + 63) / 64;
-    hipLaunchKernelGGL(k_pde_keep, dim3(pb), dim3(256), 0, st, *f, P, L.xw, L.flags, L.cnt);
+    {
+        DensityArgs da; memset(&da, 0, sizeof(da));
+        da.f = *f; da.n_direct = P; da.xw = L.xw; da.per_point_t = 1; da.sigma_out = L.sig;
+        if (launch_density_q(da, P, st)) return 1;
+    }
+    hipLaunchKernelGGL(k_pde_keep, dim3(pb), dim3(256), 0, st, *f, P, L.sig, L.flags, L.cnt);
     launch_scan_fill(L.cnt, L.off, nw, L.kcount, L.flags, L.klist, st);
     LAUNCHCK();
     // host needs the kept count (the reference syncs here too: `if xyzt.shape[0] == 0`, nvfi.py:66)

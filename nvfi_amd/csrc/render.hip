@@ -1048,7 +1048,7 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
     // density
     DensityArgs da; memset(&da, 0, sizeof(da));
     da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn;
-    { ProfScope ps(PK_DENSITY_FWD, st); hipLaunchKernelGGL(k_density_fwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
+    { ProfScope ps(PK_DENSITY_FWD, st); if (launch_density_q(da, N, st)) return 1; }
     // weights
     WeightArgs wa; memset(&wa, 0, sizeof(wa));
     wa.R = R; wa.S = S; wa.xpre = P.xpre; wa.xw = P.xw; wa.distance_scale = f->distance_scale; wa.weight_thres = f->weight_thres;
@@ -1239,9 +1239,7 @@ extern "C" int nvfi_density_at(const nvfi_field_desc* f, int64_t N, const float*
     DensityArgs da; memset(&da, 0, sizeof(da));
     da.f = *f; da.count = nullptr; da.n_direct = N; da.list = nullptr; da.xw = reinterpret_cast<const float4*>(xyzt);
     da.per_point_t = 1; da.feat_out = feat; da.sigma_out = sigma; da.xpre = nullptr;
-    hipLaunchKernelGGL(k_density_fwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da);
-    LAUNCHCK();
-    return 0;
+    return launch_density_q(da, N, st);
 }
 
 extern "C" int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, const float* view, float* rgb,

@@ -1,16 +1,20 @@
 // scatter.h - sorted-tile plane-gradient scatter and the (sample, channel-quad) gather kernels (scatter.hip)
 #pragma once
 #include "common.h"
+#include "render.h"
 
 #define SCATTER_T 8            // tile edge in texels (LDS tile = (T+1)^2 x 24 floats + a 2 x (T+1) x 24 strip of the paired time plane)
-#define SCATTER_CHUNK 512      // samples per (plane, tile) work item
+#ifndef SCATTER_CHUNK
+#define SCATTER_CHUNK 256
+#endif
+//     // samples per (plane, tile) work item
 #define SCATTER_MAX_BINS 6144  // 3 planes x tiles; larger grids fall back to the atomic scatter
 
 struct TileGeom { int G[3]; int ntx[3]; int boff[3]; int nbins; };
 
 struct TileWork {              // device buffers inside the caller's workspace
     TileGeom g;
-    int* hist; int* cursor; int* nitems; int4* items; int* sorted; float* og;
+    int* hist; int* cursor; int* nitems; int4* items; float4* sorted; float* og;
     int64_t cap_items;
 };
 
@@ -26,13 +30,13 @@ struct OgArgs {
 struct TileSortArgs {
     TileGeom g;
     const int* count; const int* list; const float4* xw;
-    int* hist; int* cursor; int4* items; int* nitems; int* sorted;
+    int* hist; int* cursor; int4* items; int* nitems; float4* sorted;
 };
 
 struct TileScatterArgs {
     nvfi_field_desc f;
     TileGeom geo;
-    const int4* items; const int* nitems; const int* sorted; const int* list; const float4* xw; const float* og;
+    const int4* items; const int* nitems; const float4* sorted; const int* list; const float4* xw; const float* og;
     float tn; int y0;
     nvfi_grads g;
 };
@@ -43,3 +47,4 @@ int tile_work_init(const TileWork& w, hipStream_t st);
 int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int64_t N, hipStream_t st);
 int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* count, const int* list, const float4* xw, float tn,
                         const nvfi_grads& g, int C, int64_t N, hipStream_t st);
+int launch_density_q(const DensityArgs& da, int64_t N, hipStream_t st);   // Cd == 24 only

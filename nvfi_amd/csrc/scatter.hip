@@ -131,6 +131,62 @@ __global__ __launch_bounds__(256) void k_og(OgArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- k_density_q
+// compute_densityfeature + density_shift (+ softplus) with lanes = (sample, channel quad): 8 lanes per sample, 6 active.
+__global__ __launch_bounds__(256) void k_density_q(DensityArgs a) {
+    const nvfi_field_desc& f = a.f;
+    const int count = a.count ? *a.count : (int)a.n_direct;
+    if (blockIdx.x * 32 >= count) return;
+    const int sub = threadIdx.x & 7;
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool in = i < count;
+    const int ic = in ? i : count - 1;
+    const int n = a.list ? a.list[ic] : ic;
+    const float4 q = a.xw[n];
+    const float tn = a.per_point_t ? q.w : a.tn;
+    const int qd = sub < 6 ? sub : 0;
+    Bl b[6];
+    plane_setups(f, q.x, q.y, q.z, tn, b);
+    const float* pl[6] = {f.dps[0], f.dps[1], f.dps[2], f.dpt[0], f.dpt[1], f.dpt[2]};
+    float4 v[6][4];
+    Tap t[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        tap_setup(b[p], 24, t[p]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[p][k] = ld4(pl[p] + t[p].o[k] + 4 * qd);
+    }
+    float4 val[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[p][k] = sel4(t[p].m[k], v[p][k]);
+        val[p].x = v[p][0].x * t[p].w[0] + v[p][1].x * t[p].w[1] + v[p][2].x * t[p].w[2] + v[p][3].x * t[p].w[3];
+        val[p].y = v[p][0].y * t[p].w[0] + v[p][1].y * t[p].w[1] + v[p][2].y * t[p].w[2] + v[p][3].y * t[p].w[3];
+        val[p].z = v[p][0].z * t[p].w[0] + v[p][1].z * t[p].w[1] + v[p][2].z * t[p].w[2] + v[p][3].z * t[p].w[3];
+        val[p].w = v[p][0].w * t[p].w[0] + v[p][1].w * t[p].w[1] + v[p][2].w * t[p].w[2] + v[p][3].w * t[p].w[3];
+    }
+    float sum = 0.f;
+    if (sub < 6) {
+        sum += ((val[0].x * val[1].x) * val[2].x) * ((val[3].x * val[4].x) * val[5].x);
+        sum += ((val[0].y * val[1].y) * val[2].y) * ((val[3].y * val[4].y) * val[5].y);
+        sum += ((val[0].z * val[1].z) * val[2].z) * ((val[3].z * val[4].z) * val[5].z);
+        sum += ((val[0].w * val[1].w) * val[2].w) * ((val[3].w * val[4].w) * val[5].w);
+    }
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) sum += __shfl_xor(sum, d);
+    if (in && sub == 0) {
+        if (a.feat_out) a.feat_out[n] = sum;
+        if (a.xpre) a.xpre[n] = sum + f.density_shift;
+        if (a.sigma_out) a.sigma_out[n] = softplus_f(sum + f.density_shift);
+    }
+}
+int launch_density_q(const DensityArgs& da, int64_t N, hipStream_t st) {
+    hipLaunchKernelGGL(k_density_q, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, da);
+    LAUNCHCK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- tile sort
 __device__ __forceinline__ int tile_of(float gx, float gy, int W, int H, int ntx) {
     float x = (gx + 1.f) * ((float)(W - 1) / 2.f), y = (gy + 1.f) * ((float)(H - 1) / 2.f);
@@ -207,8 +263,10 @@ __global__ __launch_bounds__(512) void k_tile_fill(TileSortArgs a) {
     const int count = *a.count;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int b[3] = {0, 0, 0}, r[3] = {0, 0, 0};
+    float4 qq = zero4();
     if (i < count) {
         const float4 q = a.xw[a.list[i]];
+        qq = q;
         bins_of(a.g, q, b);
 #pragma unroll
         for (int p = 0; p < 3; ++p) r[p] = atomicAdd(&cnt[b[p]], 1);
@@ -217,16 +275,21 @@ __global__ __launch_bounds__(512) void k_tile_fill(TileSortArgs a) {
     for (int k = threadIdx.x; k < nb; k += blockDim.x) if (cnt[k]) bas[k] = atomicAdd(&a.cursor[k], cnt[k]);
     __syncthreads();
     if (i < count) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) a.sorted[bas[b[p]] + r[p]] = i;
+        // record = (sample index, u, v): the two in-plane coordinates of the pass, so the scatter needs no second and third lookup
+        a.sorted[bas[b[0]] + r[0]] = make_float4(__int_as_float(i), qq.x, qq.y, 0.f);
+        a.sorted[bas[b[1]] + r[1]] = make_float4(__int_as_float(i), qq.x, qq.z, 0.f);
+        a.sorted[bas[b[2]] + r[2]] = make_float4(__int_as_float(i), qq.y, qq.z, 0.f);
     }
 }
 
 // ---------------------------------------------------------------- tile scatter: one workgroup per item, one private tile per wave
 __device__ __forceinline__ float rl_f(float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k)); }
 
-#define TS_WAVES 8
+#ifndef TS_WAVES
+#define TS_WAVES 4
+#endif
 #define TS_U 16      // per-sample gradient rows in flight per wave (rolling prefetch)
+static_assert(SCATTER_CHUNK <= 64 * TS_WAVES, "a wave prepares at most 64 samples");
 #define TS_SP (TW * TW * 24)
 #define TS_TM (2 * TW * 24)
 // A wave's share of an item is at most 64 samples, so lane s first prepares sample s on its own (tap addresses inside the LDS tile,
@@ -264,9 +327,9 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_scatter(TileScatterArgs 
     int il = 0, as = 0, at = 0;             // sample index; packed (tile address << 4 | tap masks) for the space tile / time strip
     float ws[4] = {0.f, 0.f, 0.f, 0.f}, wt[4] = {0.f, 0.f, 0.f, 0.f};
     if (lane < nw) {
-        il = a.sorted[item.y + w_lo + lane];
-        const float4 q = a.xw[a.list[il]];
-        const float uu = ia == 0 ? q.x : q.y, vv = ib == 1 ? q.y : q.z;
+        const float4 rec = a.sorted[item.y + w_lo + lane];
+        il = __float_as_int(rec.x);
+        const float uu = rec.y, vv = rec.z;
         Bl b, bt;
         int x0, y0, xt, yt;
         bl_setup_xy(uu, vv, W, H, b, x0, y0);
@@ -366,7 +429,7 @@ void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w
     tile_geom(f, &w->g);
     w->hist = B.take<int>(w->g.nbins); w->cursor = B.take<int>(w->g.nbins); w->nitems = B.take<int>(4);
     w->items = B.take<int4>(tile_items_cap(w->g, N));
-    w->sorted = B.take<int>(3 * N);
+    w->sorted = B.take<float4>(3 * N);
     w->og = B.take<float>(N * 6 * 48);
     w->cap_items = tile_items_cap(w->g, N);
 }
