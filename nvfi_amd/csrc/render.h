@@ -61,6 +61,7 @@ struct AppArgs {
     const float* g_rgb; const float4* rgb_pre; const float* weight;
     float4* gxw;
     float* gg;           // (M,48) per-sample channel gradients for k_plane_scatter (NULL: scatter in-kernel)
+    int plane_tail;      // 1: coordinate gradients of the plane lookups (+ in-kernel scatter when gg is NULL) are computed here; 0: k_og does it (or nobody needs them)
 };
 
 struct ScatterArgs {

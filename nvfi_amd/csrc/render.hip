@@ -571,6 +571,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
                 make_float4(gg[s0 >> 4][s0 & 15], gg[s0 >> 4][(s0 & 15) + 1], gg[s0 >> 4][(s0 & 15) + 2], gg[s0 >> 4][(s0 & 15) + 3]);
         }
     }
+    if (!a.plane_tail) {   // the plane part of the coordinate gradient is added by k_og<48, true> (scatter.hip) when it is needed at all
+        if (active && h == 0) a.gxw[n] = make_float4(gpts[0], gpts[1], gpts[2], 0.f);
+        return;
+    }
     float4 q = active ? a.xw[n] : zero4();
     Bl b[6];
     plane_setups(f, q.x, q.y, q.z, a.tn, b);
@@ -1109,21 +1113,31 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S;
     aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f; aa.stash_b = P.app_b; aa.g = *grads;
     aa.g_rgb = g_rgb; aa.rgb_pre = P.rgb_pre; aa.weight = weights; aa.gxw = P.gxw; aa.gg = P.gg;
+    aa.plane_tail = P.tiles ? 0 : 1;
     const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
     { ProfScope ps(PK_APP_BWD, st); hipLaunchKernelGGL(k_app_bwd, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa); }
-    if (grads->aps[0] || grads->apt[0]) {
+    const bool want_aplanes = grads->aps[0] || grads->apt[0];
+    if (P.tiles) {
+        if (want_aplanes || nsteps > 0) {
+            // one pass over the masked samples: per-plane value gradients (og) for the tile scatter and, at non-keyframe times,
+            // the plane part of the coordinate gradients (they only feed the RK2 adjoint)
+            ProfScope ps(PK_APP_SCATTER, st);
+            OgArgs oa; memset(&oa, 0, sizeof(oa));
+            oa.f = *f; oa.count = P.counters + 1; oa.list = P.mlist; oa.xw = P.xw; oa.tn = tn; oa.gg = P.gg; oa.og = want_aplanes ? P.tw.og : nullptr;
+            oa.gxw_acc = nsteps > 0 ? P.gxw : nullptr;
+            if (launch_og(f, oa, 48, nsteps > 0, N, st)) return 1;
+            if (want_aplanes) {
+                if (tile_work_init(P.tw, st)) return 1;
+                if (launch_tile_scatter(f, P.tw, P.counters + 1, P.mlist, P.xw, tn, *grads, 48, N, st)) return 1;
+            }
+        }
+    } else if (want_aplanes) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
         sa.f = *f; sa.count = P.counters + 1; sa.list = P.mlist; sa.xw = P.xw; sa.tn = tn; sa.gg = P.gg; sa.g = *grads; sa.plane_mask = scatter_mask();
         hipStream_t ss = st;
         if (side) { HIPCK(hipEventRecord(g_side.fork[0], st)); HIPCK(hipStreamWaitEvent(g_side.s, g_side.fork[0], 0)); ss = g_side.s; forked = true; }
         ProfScope ps(PK_APP_SCATTER, ss);
-        if (P.tiles) {
-            if (tile_work_init(P.tw, ss)) return 1;
-            OgArgs oa; memset(&oa, 0, sizeof(oa));
-            oa.f = *f; oa.count = P.counters + 1; oa.list = P.mlist; oa.xw = P.xw; oa.tn = tn; oa.gg = P.gg; oa.og = P.tw.og;
-            if (launch_og(f, oa, 48, false, N, ss)) return 1;
-            if (launch_tile_scatter(f, P.tw, P.counters + 1, P.mlist, P.xw, tn, *grads, 48, N, ss)) return 1;
-        } else if (launch_scatter(f, sa, 48, N, tn, ss)) return 1;
+        if (launch_scatter(f, sa, 48, N, tn, ss)) return 1;
     }
     LAUNCHCK();
     // render-MLP weight gradients
@@ -1171,7 +1185,7 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
         }
         if (want_dplanes) {
             ProfScope ps(PK_DENSITY_SCATTER, st);
-            if (!(grads->aps[0] || grads->apt[0]) && tile_work_init(P.tw, st)) return 1;
+            if (!want_aplanes && tile_work_init(P.tw, st)) return 1;
             if (launch_tile_scatter(f, P.tw, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, st)) return 1;
         }
     } else if (nsteps > 0) { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }

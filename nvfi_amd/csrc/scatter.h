@@ -25,6 +25,7 @@ struct OgArgs {
     const float* gg;           // appearance: (M,48) per-sample channel gradients (compact)
     float* og;                 // [i][6][C]
     const uint8_t* mflag; const float4* gxw; float4* gxk;   // COORD: coordinate gradients (density branch)
+    float4* gxw_acc;           // COORD, appearance branch: gxw[n] += plane part of the coordinate gradient
 };
 
 struct TileSortArgs {

@@ -124,7 +124,12 @@ __global__ __launch_bounds__(256) void k_og(OgArgs a) {
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int d = 1; d < LPS; d <<= 1) g3[c] += __shfl_xor(g3[c], d);
-        if (i < count && sub == 0 && a.gxk) {
+        if (C == 48) {
+            if (i < count && sub == 0 && a.gxw_acc) {
+                const float4 g0 = a.gxw_acc[n];
+                a.gxw_acc[n] = make_float4(g0.x + g3[0], g0.y + g3[1], g0.z + g3[2], 0.f);
+            }
+        } else if (i < count && sub == 0 && a.gxk) {
             const float4 ga = (a.mflag && a.mflag[n]) ? a.gxw[n] : zero4();   // appearance-branch part (masked samples only)
             a.gxk[i] = make_float4(ga.x + g3[0], ga.y + g3[1], ga.z + g3[2], 0.f);
         }
@@ -446,7 +451,10 @@ int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int
     if (C == 24) {
         if (coord) hipLaunchKernelGGL((k_og<24, true>), dim3(blocks), dim3(256), 0, st, oa);
         else hipLaunchKernelGGL((k_og<24, false>), dim3(blocks), dim3(256), 0, st, oa);
-    } else hipLaunchKernelGGL((k_og<48, false>), dim3(blocks), dim3(256), 0, st, oa);
+    } else {
+        if (coord) hipLaunchKernelGGL((k_og<48, true>), dim3(blocks), dim3(256), 0, st, oa);
+        else hipLaunchKernelGGL((k_og<48, false>), dim3(blocks), dim3(256), 0, st, oa);
+    }
     LAUNCHCK();
     return 0;
 }
