@@ -4,7 +4,9 @@
 
 #define PDE_MAX_CLASS 64           // RK2 step-count buckets
 #define PDE_CHUNK 131072           // kept points processed per pass (bounds the stash: 42 KB per point -> 5.5 GB; sized for 288 GB of HBM)
+#ifndef PDE_NSLAB
 #define PDE_NSLAB 128
+#endif
 
 // per-tile stash rows (each row = 64 floats)
 #define PDE_Z     0                          // weight_net pre-activations        5*64

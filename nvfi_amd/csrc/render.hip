@@ -933,7 +933,7 @@ struct RenderPlan {
     int64_t total;
 };
 #define NSLAB_MAX 1024
-static int nslab_rt() { static int n = -1; if (n < 0) { const char* e = getenv("NVFI_NSLAB"); n = e ? atoi(e) : 512; if (n < 1) n = 1; if (n > NSLAB_MAX) n = NSLAB_MAX; } return n; }
+static int nslab_rt() { static int n = -1; if (n < 0) { const char* e = getenv("NVFI_NSLAB"); n = e ? atoi(e) : 256; if (n < 1) n = 1; if (n > NSLAB_MAX) n = NSLAB_MAX; } return n; }
 #define NSLAB (nslab_rt())
 #define SLAB_FLOATS (128 * 128 + 128)
 
