@@ -1,0 +1,286 @@
+// mask.hip - MaskField (reference models/mask_field.py:34-83 as train_segm.py:97-102 builds it: 3 -> 128 x 4 (ReLU) -> K,
+// softmax) on free points, forward and backward: the per-iteration model of train_segm.py:126-227 (BASELINE config 5).
+//
+// Same fp32 MFMA sample-tile engine as the velocity and render MLPs (engine.h): a wave owns 32 points, activations stay in
+// registers between layers, one layer's weight fragment is staged in LDS per workgroup.  Training stashes the post-ReLU
+// activations (they are the B operands of the weight gradients and carry the ReLU mask of the adjoint pass) and the softmax
+// output; the backward walks the transposed fragments and leaves the adjoints in the MFMA register layout for k_wgrad.
+#include "common.h"
+#include <string.h>
+
+#define MK_F_ROWS (16 + 4 * 64 + 16)   // forward stash per tile: x0 (16) | h1..h4 (64 each) | softmax (16)
+#define MK_B_ROWS (16 + 4 * 64)        // backward stash per tile: g_logits (16) | g_z4, g_z3, g_z2, g_z1 (64 each)
+#define MK_NSLAB 128
+#define MK_SLAB_FLOATS (128 * 128 + 128)
+#define MK_F0 (4 * 2 * 64)
+#define MK_FH (4 * 64 * 64)
+#define MK_F4 (1 * 64 * 64)
+#define MK_T4 (4 * 16 * 64)            // transposed last layer: rows = 128 hidden features, slots = 32 logit rows
+#define MK_FRAG_FLOATS (MK_F0 + 3 * MK_FH + MK_F4 + 5 * 128 + MK_T4 + 3 * MK_FH)
+
+struct MkFrags { const float* f[5]; const float* b[5]; const float* t[5]; };   // t[0] unused (no gradient wrt the points)
+struct MkArgs {
+    MkFrags W; int mask_dim; int64_t N;
+    const float* xyz; float* out;        // (N,3) -> (N,mask_dim)
+    const float* g_out;                  // backward: d loss / d mask (N,mask_dim)
+    float* stash_f; float* stash_b;
+};
+
+template <bool STASH>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_fwd(MkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int tile = blockIdx.x * 4 + wave_id();
+    const int64_t i = (int64_t)tile * TILE + (lane & 31);
+    const bool active = i < a.N;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (active) { px = a.xyz[3 * i]; py = a.xyz[3 * i + 1]; pz = a.xyz[3 * i + 2]; }
+    float* st = STASH ? a.stash_f + (size_t)tile * (MK_F_ROWS * REGF) : nullptr;
+    float xa[64], xb[64];
+    xb[0] = h ? py : px; xb[1] = h ? 0.f : pz;
+    if (STASH) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) st[s * REGF + lane] = s < 2 ? xb[s] : 0.f;
+    }
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f[0], MK_F0, a.W.b[0], 128);
+    __syncthreads();
+    layer_tiles<4, 2>(lds_w, lds_b, true, lane, h, xb, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { xa[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) st[(16 + 16 * m + r) * REGF + lane] = xa[16 * m + r]; }
+    });
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f[1], MK_FH, a.W.b[1], 128);
+    __syncthreads();
+    layer_tiles<4, 64>(lds_w, lds_b, true, lane, h, xa, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { xb[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) st[(80 + 16 * m + r) * REGF + lane] = xb[16 * m + r]; }
+    });
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f[2], MK_FH, a.W.b[2], 128);
+    __syncthreads();
+    layer_tiles<4, 64>(lds_w, lds_b, true, lane, h, xb, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { xa[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) st[(144 + 16 * m + r) * REGF + lane] = xa[16 * m + r]; }
+    });
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f[3], MK_FH, a.W.b[3], 128);
+    __syncthreads();
+    layer_tiles<4, 64>(lds_w, lds_b, true, lane, h, xa, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { xb[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) st[(208 + 16 * m + r) * REGF + lane] = xb[16 * m + r]; }
+    });
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.f[4], MK_F4, a.W.b[4], 32);
+    __syncthreads();
+    float o[16];
+    layer_tiles<1, 64>(lds_w, lds_b, true, lane, h, xb, [&](int, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = acc[r];
+    });
+    // softmax over the mask_dim logits of the point: rows (r&3)+8(r>>2)+4h live in this lane, the rest in lane^32
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int row = (r & 3) + 8 * (r >> 2) + 4 * h; if (row < a.mask_dim) mx = fmaxf(mx, o[r]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int row = (r & 3) + 8 * (r >> 2) + 4 * h; o[r] = row < a.mask_dim ? expf(o[r] - mx) : 0.f; sum += o[r]; }
+    sum += __shfl_xor(sum, 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float p = o[r] / sum;
+        if (STASH) st[(272 + r) * REGF + lane] = p;
+        if (active && row < a.mask_dim) a.out[(size_t)i * a.mask_dim + row] = p;
+    }
+}
+
+// adjoint pass: g_logits = p * (g - sum_k g_k p_k), then g_z_l = (W_{l+1}^T g_z_{l+1}) * [h_l > 0]
+__global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_bwd(MkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int tile = blockIdx.x * 4 + wave_id();
+    const int64_t i = (int64_t)tile * TILE + (lane & 31);
+    const bool active = i < a.N;
+    const float* stf = a.stash_f + (size_t)tile * (MK_F_ROWS * REGF);
+    float* stb = a.stash_b + (size_t)tile * (MK_B_ROWS * REGF);
+    float g[64];
+    {
+        float p[16], go[16], dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            p[r] = stf[(272 + r) * REGF + lane];
+            go[r] = (active && row < a.mask_dim) ? a.g_out[(size_t)i * a.mask_dim + row] : 0.f;
+            dot += go[r] * p[r];
+        }
+        dot += __shfl_xor(dot, 32);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g[r] = p[r] * (go[r] - dot); stb[r * REGF + lane] = g[r]; }
+    }
+    f32x16 acc[4];
+    __syncthreads();
+    stage_frag(lds_w, lds_b, a.W.t[4], MK_T4, nullptr, 0);
+    __syncthreads();
+    acc_init<4>(acc, lds_b, 0, false);
+    layer_mfma<4, 16>(lds_w, lane, g, acc);
+#pragma unroll 1
+    for (int l = 3; l >= 1; --l) {
+        // acc = gradient wrt h_{l+1}: mask with the stashed activation, stash as g_z_{l+1}, push through W_{l+1}^T
+        const float* hh = stf + (size_t)(16 + 64 * l) * REGF;
+        float* gz = stb + (size_t)(16 + 64 * (3 - l)) * REGF;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = hh[(16 * m + r) * REGF + lane] > 0.f ? acc[m][r] : 0.f;
+        stash_store<64>(gz, lane, g);
+        __syncthreads();
+        stage_frag(lds_w, lds_b, a.W.t[l], MK_FH, nullptr, 0);
+        __syncthreads();
+        acc_init<4>(acc, lds_b, 0, false);
+        layer_mfma<4, 64>(lds_w, lane, g, acc);
+    }
+    {   // g_z1 (no further propagation: the points carry no gradient, train_segm.py:137-170 runs them under no_grad)
+        const float* hh = stf + (size_t)16 * REGF;
+        float* gz = stb + (size_t)(16 + 64 * 3) * REGF;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = hh[(16 * m + r) * REGF + lane] > 0.f ? acc[m][r] : 0.f;
+        stash_store<64>(gz, lane, g);
+    }
+}
+
+__global__ void k_set_int(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+
+struct MkPlan { float* frag; float* stash_f; float* stash_b; float* slabs; int* count; int64_t tiles; int64_t total; };
+static void plan_mask(int64_t N, int train, void* ws, MkPlan* P) {
+    Bump B{(char*)ws, 0, 0};
+    P->tiles = (N + WG_SAMPLES - 1) / WG_SAMPLES * 4;
+    P->frag = B.take<float>(MK_FRAG_FLOATS);
+    P->count = B.take<int>(16);
+    P->stash_f = P->stash_b = P->slabs = nullptr;
+    if (train) {
+        P->stash_f = B.take<float>(P->tiles * (int64_t)(MK_F_ROWS * REGF));
+        P->stash_b = B.take<float>(P->tiles * (int64_t)(MK_B_ROWS * REGF));
+        P->slabs = B.take<float>((int64_t)MK_NSLAB * MK_SLAB_FLOATS * 5);
+    }
+    P->total = align_up(B.off, 256);
+}
+
+static int mask_check(const nvfi_mask_desc* m) {
+    if (m->n_layer != 4 || m->n_dim != 128 || m->mask_dim < 1 || m->mask_dim > 32)
+        return nvfi_fail(2, "mask field must be 3->128x4->mask_dim<=32 (train_segm.py:97-102); got n_layer=%d n_dim=%d mask_dim=%d", m->n_layer, m->n_dim, m->mask_dim);
+    for (int l = 0; l < 5; ++l) if (!m->W[l] || !m->b[l]) return nvfi_fail(2, "mask field layer %d has no weight/bias pointer", l);
+    return 0;
+}
+
+static int mask_frags(const nvfi_mask_desc* m, float* frag, MkFrags* W, bool transposed, hipStream_t st) {
+    PackJobs jobs; jobs.n = 0;
+    float* p = frag;
+    for (int l = 0; l < 5; ++l) {
+        PackJob& J = jobs.j[jobs.n++];
+        memset(&J, 0, sizeof(J));
+        const int MT = l < 4 ? 4 : 1, NS = l == 0 ? 2 : 64;
+        J.W = m->W[l]; J.b = m->b[l]; J.frag = p; p += MT * NS * 64; J.bfrag = p; p += 128;
+        J.out = l < 4 ? 128 : m->mask_dim; J.in = l == 0 ? 3 : 128; J.MT = MT; J.NS = NS;
+        J.row_kind = RK_NATURAL; J.slot_kind = l == 0 ? SK_XYZ : SK_HIDDEN; J.transposed = 0;
+        W->f[l] = J.frag; W->b[l] = J.bfrag;
+    }
+    W->t[0] = nullptr;
+    for (int l = 1; l < 5; ++l) {           // dgrad fragments: rows = input features of layer l, slots = its output rows
+        PackJob& J = jobs.j[jobs.n++];
+        memset(&J, 0, sizeof(J));
+        const int NS = l < 4 ? 64 : 16;
+        J.W = m->W[l]; J.b = nullptr; J.frag = p; p += 4 * NS * 64; J.bfrag = nullptr;
+        J.out = l < 4 ? 128 : m->mask_dim; J.in = 128; J.MT = 4; J.NS = NS;
+        J.row_kind = RK_NATURAL; J.slot_kind = SK_HIDDEN; J.transposed = 1;
+        W->t[l] = J.frag;
+    }
+    if (!transposed) jobs.n = 5;
+    return launch_pack(jobs, st);
+}
+
+static int mask_attrs() {
+    static bool done = false;
+    if (done) return 0;
+    HIPCK(hipFuncSetAttribute((const void*)k_maskfield_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_maskfield_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_maskfield_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    done = true;
+    return 0;
+}
+
+extern "C" int nvfi_maskfield_workspace_bytes(const nvfi_mask_desc* m, int64_t N, int train, int64_t* bytes) {
+    if (mask_check(m)) return 2;
+    MkPlan P;
+    plan_mask(N > 0 ? N : 1, train, nullptr, &P);
+    *bytes = P.total;
+    return 0;
+}
+
+extern "C" int nvfi_maskfield_fwd(const nvfi_mask_desc* m, int64_t N, const float* xyz, float* mask_out, int train,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (mask_check(m)) return 2;
+    if (N <= 0) return 0;
+    if (N >= (1ll << 31) - 256) return nvfi_fail(2, "too many points for one call");
+    if (mask_attrs()) return 1;
+    MkPlan P;
+    plan_mask(N, train, workspace, &P);
+    if (P.total > workspace_bytes) return nvfi_fail(4, "workspace too small");
+    MkArgs a; memset(&a, 0, sizeof(a));
+    if (mask_frags(m, P.frag, &a.W, train != 0, st)) return 1;
+    a.mask_dim = m->mask_dim; a.N = N; a.xyz = xyz; a.out = mask_out; a.stash_f = P.stash_f; a.stash_b = P.stash_b;
+    const unsigned wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
+    if (train) hipLaunchKernelGGL(k_maskfield_fwd<true>, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(k_maskfield_fwd<false>, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
+    LAUNCHCK();
+    return 0;
+}
+
+extern "C" int nvfi_maskfield_bwd(const nvfi_mask_desc* m, int64_t N, const float* g_mask, const nvfi_mask_grads* grads,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (mask_check(m)) return 2;
+    if (N <= 0) return 0;
+    if (mask_attrs()) return 1;
+    MkPlan P;
+    plan_mask(N, 1, workspace, &P);
+    if (P.total > workspace_bytes) return nvfi_fail(4, "workspace too small (was the forward run with train != 0?)");
+    MkArgs a; memset(&a, 0, sizeof(a));
+    PackJobs dummy; dummy.n = 0;
+    {   // fragment pointers inside the workspace the forward packed (same layout as mask_frags)
+        float* p = P.frag;
+        for (int l = 0; l < 5; ++l) { const int MT = l < 4 ? 4 : 1, NS = l == 0 ? 2 : 64; a.W.f[l] = p; p += MT * NS * 64; a.W.b[l] = p; p += 128; }
+        for (int l = 1; l < 5; ++l) { const int NS = l < 4 ? 64 : 16; a.W.t[l] = p; p += 4 * NS * 64; }
+    }
+    a.mask_dim = m->mask_dim; a.N = N; a.g_out = g_mask; a.stash_f = P.stash_f; a.stash_b = P.stash_b;
+    const unsigned wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
+    hipLaunchKernelGGL(k_maskfield_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, st, P.count, (int)N);
+    LAUNCHCK();
+    // weight gradients: dW_l = g_z_l^T h_{l-1}, db_l = sum g_z_l  (split-K MFMA over the stashed tiles, engine.hip)
+    WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
+    const size_t fs = MK_F_ROWS * REGF, bs = MK_B_ROWS * REGF;
+    for (int l = 0; l < 5; ++l) {
+        if (!grads->W[l] && !grads->b[l]) continue;
+        WgradJob& J = wj.j[wj.n];
+        memset(&J, 0, sizeof(J));
+        // adjoint rows: l = 4 -> g_logits (16 regs); l = 3..0 -> g_z_{l+1} at 16 + 64*(3-l)
+        J.A = l == 4 ? P.stash_b : P.stash_b + (size_t)(16 + 64 * (3 - l)) * REGF; J.a_regs = l == 4 ? 16 : 64; J.a_tile_stride = bs;
+        // inputs: l = 0 -> the point slots (16 regs); l >= 1 -> h_l at 16 + 64*(l-1)
+        J.B = l == 0 ? P.stash_f : P.stash_f + (size_t)(16 + 64 * (l - 1)) * REGF; J.b_regs = l == 0 ? 16 : 64; J.b_tile_stride = fs;
+        J.bmode = BM_RAW; J.count = P.count; J.cap_tiles = (int)P.tiles; J.nrep = 1;
+        J.slabs = P.slabs + (size_t)wj.n * MK_NSLAB * MK_SLAB_FLOATS; J.nslab = MK_NSLAB;
+        ReduceJob& Q = rj.j[rj.n++];
+        memset(&Q, 0, sizeof(Q));
+        Q.slabs = J.slabs; Q.nslab = MK_NSLAB; Q.MTA = J.a_regs / 16; Q.KTB = J.b_regs / 16; Q.gW = grads->W[l]; Q.gb = grads->b[l];
+        Q.out = l < 4 ? 128 : m->mask_dim; Q.in = l == 0 ? 3 : 128; Q.row_kind = RK_NATURAL; Q.slot_kind = l == 0 ? SK_XYZ : SK_HIDDEN; Q.scale = 1.f;
+        ++wj.n;
+    }
+    return launch_wgrad(wj, rj, st);
+}

@@ -1172,3 +1172,57 @@ float orc_tv_app(const orc_field_t* f) {
     for (int i = 0; i < 3; ++i) tot += tv_plane(f->aps[i], f->Ca, f->G[MS_B[i]], f->G[MS_A[i]], 0) * 1e-2;
     return (float)tot;
 }
+
+/* ---------------------------------------------------------------- MaskField forward / backward (config 5)
+ * models/mask_field.py:68-83 with skips=[] and point_embed=False: h = relu(point_fc[l](h)) for l = 0..3,
+ * mask = softmax(mask_fc(h), dim=1).  Backward: d logits = p * (g - sum_k g_k p_k) (softmax), then Linear / ReLU adjoints. */
+void orc_maskfield(const float* const* W, const float* const* b, int mask_dim, int64_t N, const float* xyz, float* mask,
+                   const float* g_mask, float* const* gW, float* const* gb) {
+    const int H = 128, K = mask_dim;
+    for (int64_t n = 0; n < N; ++n) {
+        float h[5][128], z5[32], p[32];
+        for (int c = 0; c < 3; ++c) h[0][c] = xyz[3 * n + c];
+        for (int l = 0; l < 4; ++l) {
+            const int in = l == 0 ? 3 : H;
+            for (int o = 0; o < H; ++o) {
+                float acc = b[l][o];
+                for (int k = 0; k < in; ++k) acc += W[l][(size_t)o * in + k] * h[l][k];
+                h[l + 1][o] = acc > 0.f ? acc : 0.f;
+            }
+        }
+        float mx = -INFINITY;
+        for (int o = 0; o < K; ++o) {
+            float acc = b[4][o];
+            for (int k = 0; k < H; ++k) acc += W[4][(size_t)o * H + k] * h[4][k];
+            z5[o] = acc; if (acc > mx) mx = acc;
+        }
+        float sum = 0.f;
+        for (int o = 0; o < K; ++o) { p[o] = expf(z5[o] - mx); sum += p[o]; }
+        for (int o = 0; o < K; ++o) { p[o] = p[o] / sum; mask[(size_t)n * K + o] = p[o]; }
+        if (!g_mask) continue;
+        float gz[128], gh[128], dot = 0.f;
+        for (int o = 0; o < K; ++o) dot += g_mask[(size_t)n * K + o] * p[o];
+        for (int o = 0; o < K; ++o) gz[o] = p[o] * (g_mask[(size_t)n * K + o] - dot);
+        for (int k = 0; k < H; ++k) gh[k] = 0.f;
+        for (int o = 0; o < K; ++o) {
+            if (gb && gb[4]) gb[4][o] += gz[o];
+            for (int k = 0; k < H; ++k) {
+                if (gW && gW[4]) gW[4][(size_t)o * H + k] += gz[o] * h[4][k];
+                gh[k] += W[4][(size_t)o * H + k] * gz[o];
+            }
+        }
+        for (int l = 3; l >= 0; --l) {
+            const int in = l == 0 ? 3 : H;
+            for (int o = 0; o < H; ++o) gz[o] = h[l + 1][o] > 0.f ? gh[o] : 0.f;
+            for (int k = 0; k < in; ++k) gh[k] = 0.f;
+            for (int o = 0; o < H; ++o) {
+                if (gz[o] == 0.f) continue;
+                if (gb && gb[l]) gb[l][o] += gz[o];
+                for (int k = 0; k < in; ++k) {
+                    if (gW && gW[l]) gW[l][(size_t)o * in + k] += gz[o] * h[l][k];
+                    gh[k] += W[l][(size_t)o * in + k] * gz[o];
+                }
+            }
+        }
+    }
+}

@@ -99,6 +99,12 @@ float orc_pde_loss(const orc_field_t* f, int64_t P, const float* points, const f
                    uint8_t* kept, int64_t* n_kept_out, int64_t n_jac, float* jac, orc_grads_t* grads,
                    int64_t* rk2_evals_out);
 
+/* a-19 / config 5: MaskField (models/mask_field.py:68-83 built as train_segm.py:97-102: 3 -> 128 x 4 ReLU -> K, softmax).
+ * W[l] (out,in) row-major, l = point_fc.0..3, mask_fc.  mask (N,K).  When g_mask != NULL the gradients of
+ * sum(mask * g_mask) wrt every W[l], b[l] are ACCUMULATED into gW[l], gb[l] (autograd of train_segm.py:195). */
+void orc_maskfield(const float* const* W, const float* const* b, int mask_dim, int64_t N, const float* xyz, float* mask,
+                   const float* g_mask, float* const* gW, float* const* gb);
+
 /* next-row f-1 regularisers */
 float orc_density_L1(const orc_field_t* f);
 float orc_tv_density(const orc_field_t* f);

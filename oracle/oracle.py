@@ -332,3 +332,23 @@ def regs(fs):
     f = fs.c_field()
     L = lib()
     return float(L.orc_density_L1(C.byref(f))), float(L.orc_tv_density(C.byref(f))), float(L.orc_tv_app(C.byref(f)))
+
+
+def maskfield(params, xyz, g_mask=None):
+    """MaskField forward (+ parameter gradients of sum(mask * g_mask)).  params: [W0, b0, ..., W4, b4] (torch Linear layout)."""
+    ps = [_f32(p) for p in params]
+    xyz = _f32(xyz)
+    N, K = xyz.shape[0], ps[8].shape[0]
+    out = np.empty((N, K), np.float32)
+    arr = C.c_void_p * 5
+    W = arr(*[ps[2 * i].ctypes.data for i in range(5)])
+    b = arr(*[ps[2 * i + 1].ctypes.data for i in range(5)])
+    if g_mask is None:
+        lib().orc_maskfield(W, b, C.c_int(K), C.c_int64(N), _p(xyz), _p(out), None, None, None)
+        return out
+    g = _f32(g_mask)
+    grads = [np.zeros_like(p) for p in ps]
+    gW = arr(*[grads[2 * i].ctypes.data for i in range(5)])
+    gb = arr(*[grads[2 * i + 1].ctypes.data for i in range(5)])
+    lib().orc_maskfield(W, b, C.c_int(K), C.c_int64(N), _p(xyz), _p(out), _p(g), gW, gb)
+    return out, grads

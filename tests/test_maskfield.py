@@ -1,0 +1,118 @@
+"""MaskField training path (BASELINE config 5; reference models/mask_field.py:68-83 + train_segm.py:126-198).
+
+CPU: the oracle's plain-C restatement against the golden vectors generated from the reference (tests/golden/make_golden_maskfield.py).
+GPU: the HIP kernels (nvfi_amd/csrc/mask.hip through nvfi_maskfield_fwd / nvfi_maskfield_bwd) against the same goldens, against the
+oracle on larger and ragged point counts, and one train_segm-style iteration (points -> flow -> mask -> loss -> Adam)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, relerr
+
+NAMES = ["point_fc.0", "point_fc.1", "point_fc.2", "point_fc.3", "mask_fc"]
+
+
+@pytest.fixture(scope="module")
+def mgold():
+    return np.load(os.path.join(GOLD, "maskfield.npz"))
+
+
+def _params(g, tag):
+    ps = []
+    for n in NAMES:
+        ps += [g[f"{tag}:sd:{n}.weight"], g[f"{tag}:sd:{n}.bias"]]
+    return ps
+
+
+@pytest.mark.parametrize("tag", ["K8", "K3"])
+def test_oracle_maskfield_matches_reference(mgold, tag):
+    from oracle import oracle as orc
+    out, grads = orc.maskfield(_params(mgold, tag), mgold[f"{tag}:pts"], mgold[f"{tag}:g"])
+    np.testing.assert_allclose(out, mgold[f"{tag}:mask"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(out.sum(1), 1.0, rtol=0, atol=1e-5)
+    for i, n in enumerate(NAMES):
+        for j, s in enumerate(["weight", "bias"]):
+            assert relerr(grads[2 * i + j], mgold[f"{tag}:grad:{n}.{s}"]) < 2e-5, (n, s)
+
+
+def test_oracle_maskfield_forward_only(mgold):
+    from oracle import oracle as orc
+    out = orc.maskfield(_params(mgold, "K8"), mgold["K8:pts"][:7])
+    np.testing.assert_allclose(out, mgold["K8:mask"][:7], rtol=2e-5, atol=1e-6)
+
+
+def _model(g, tag, K):
+    from nvfi_amd.models import MaskField
+    mf = MaskField(n_layer=4, n_dim=128, input_dim=3, skips=[], mask_dim=K, mask_act="softmax")
+    mf.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}:sd:")})
+    return mf.cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,K", [("K8", 8), ("K3", 3)])
+def test_gpu_maskfield_matches_reference(mgold, tag, K):
+    mf = _model(mgold, tag, K)
+    pts = torch.from_numpy(mgold[f"{tag}:pts"]).cuda()
+    g = torch.from_numpy(mgold[f"{tag}:g"]).cuda()
+    mask = mf(pts)
+    np.testing.assert_allclose(mask.detach().cpu().numpy(), mgold[f"{tag}:mask"], rtol=1e-4, atol=1e-6)
+    (mask * g).sum().backward()
+    for n, p in mf.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), mgold[f"{tag}:grad:{n}"]) < 5e-5, n   # fp32 MFMA, different summation order
+    with torch.no_grad():   # inference path (no stash)
+        m2 = mf(pts)
+    assert torch.equal(m2, mask.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 33, 129, 20000])
+def test_gpu_maskfield_vs_oracle_ragged(mgold, N):
+    from oracle import oracle as orc
+    mf = _model(mgold, "K8", 8)
+    rng = np.random.default_rng(N)
+    pts = (rng.random((N, 3), dtype=np.float32) * 2 - 1)
+    g = rng.standard_normal((N, 8)).astype(np.float32)
+    ref, rgrads = orc.maskfield(_params(mgold, "K8"), pts, g)
+    mask = mf(torch.from_numpy(pts).cuda())
+    np.testing.assert_allclose(mask.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-6)
+    (mask * torch.from_numpy(g).cuda()).sum().backward()
+    for i, n in enumerate(NAMES):
+        assert relerr(mf.get_parameter(n + ".weight").grad.cpu().numpy(), rgrads[2 * i]) < 2e-4, n
+        assert relerr(mf.get_parameter(n + ".bias").grad.cpu().numpy(), rgrads[2 * i + 1]) < 2e-4, n
+    # gradient accumulation across two backward calls (+=)
+    mask = mf(torch.from_numpy(pts).cuda())
+    (mask * torch.from_numpy(g).cuda()).sum().backward()
+    assert relerr(mf.mask_fc.weight.grad.cpu().numpy(), 2 * rgrads[8]) < 2e-4
+    assert mf(torch.zeros(0, 3, device="cuda")).shape == (0, 8)
+
+
+@pytest.mark.gpu
+def test_gpu_segm_iteration(mgold):
+    """one train_segm.py:126-198 iteration on the HIP path: occupied points at t=0, flow from the velocity field, MaskField, Adam"""
+    from helpers import make_model
+    from nvfi_amd.utils import segm_points
+    from oracle import oracle as orc
+    model, meta = make_model("A")
+    f = model.nvfi
+    f.eval()
+    torch.manual_seed(3)
+    xyz, flow, t = segm_points(f, n_sample_res=24, min_t=0.1, alpha_scale=1.0)
+    assert xyz.shape[0] > 50 and xyz.shape == flow.shape and torch.isfinite(flow).all()
+    # the advected points are what integrate_pos gives for (x, 0 -> t): the oracle agrees
+    xo = orc.integrate_pos(orc.FieldSpec.from_npz(os.path.join(GOLD, "field_A.npz")), xyz.cpu().numpy(),
+                           np.zeros((xyz.shape[0], 1), np.float32), np.full((xyz.shape[0], 1), t, np.float32))
+    np.testing.assert_allclose((xyz + flow).cpu().numpy(), xo, rtol=1e-4, atol=2e-5)
+    mf = _model(mgold, "K8", 8)
+    opt = torch.optim.Adam(mf.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    target = (flow / (flow.norm(dim=1, keepdim=True) + 1e-9))[:, :1]
+    losses = []
+    for _ in range(5):
+        mask = mf(xyz)
+        loss = ((mask[:, :1] - target) ** 2).mean() - 1e-3 * (mask * torch.log(mask + 1e-8)).sum(1).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0]
