@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 VEL_FLOP = 139776          # 2*(28*128 + 4*128^2 + 128*6)   one VelBasis net evaluation
 APP_FLOP = 64768           # 2*(48*32 + 110*128 + 128^2 + 128*3)
 PEAK_FP32_MFMA = 157.3     # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+PEAK_HBM_GBS = 8000.0      # GB/s, MI355X_MICROARCH.md (HBM3E)
 CLASSES = ["rk2_fwd", "rk2_bwd", "app_fwd", "app_bwd", "wgrad", "pde_fwd", "pde_bwd", "density_fwd", "density_bwd", "pde_prefilter", "density_scatter", "app_scatter", "other"]
 
 
@@ -314,6 +315,20 @@ def main():
         roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=PEAK_FP32_MFMA, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA,
                     traffic=traffic, launches=int(n), avg_launch_ms=ms / max(n, 1), flop_per_launch=flops[dom] / max(n, 1),
                     per_class_ms_per_step={k: times[k][0] / args.steps for k in times})
+
+    if args.workload == "cfg2":
+        # radiance-only: gather / scatter bound: algorithmic bytes per step = 6912 B per valid sample + 13824 B per
+        # appearance-masked sample (forward gathers + read-modify-write of the plane gradients, no reuse credit) + the per-ray
+        # inputs/outputs, over the WHOLE step time (the MLP contractions ride along); peak = 8 TB/s HBM3E
+        V = float(c[0])
+        nbytes = V * 6912.0 + M * 13824.0 + args.steps * renders * args.rays * (24.0 + (5.0 + args.samples) * 4.0)
+        gbs = nbytes / dt / 1e9
+        roof = dict(bound="hbm", kernel="whole step: plane gathers + plane-gradient scatters (k_density_q, k_og, k_tile_scatter, k_app_fwd gather)",
+                    achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=None,
+                    bytes_per_step=nbytes / args.steps, valid_samples_per_step=V / args.steps, masked_samples_per_step=M / args.steps,
+                    mfma=roof, per_class_ms_per_step={k: times[k][0] / args.steps for k in times})
+        if roof["mfma"]:
+            roof["mfma"].pop("per_class_ms_per_step", None)
 
     out = {
         "metric": "training rays/sec (fwd+bwd incl. PDE loss), 'bat' scene", "value": value, "unit": "rays/s",

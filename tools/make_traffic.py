@@ -15,8 +15,10 @@ CLASSES = {
     "pde_fwd": ["k_pde_value_fwd", "k_pde_tangent_fwd"],
     "app_fwd": ["void k_app_fwd<true>"],
     "app_bwd": ["k_app_bwd"],
-    "density_scatter": ["void k_plane_scatter_lds<24>"],
-    "app_scatter": ["void k_plane_scatter_lds<48>"],
+    "density_fwd": ["k_density_q"],
+    "density_bwd": ["void k_og<24, true>"],
+    "density_scatter": ["void k_tile_scatter<24>", "k_tile_hist", "k_tile_scan", "k_tile_fill"],
+    "app_scatter": ["void k_og<48, true>", "void k_tile_scatter<48>", "k_tile_hist", "k_tile_scan", "k_tile_fill"],
 }
 
 
