@@ -96,10 +96,12 @@ class Step:
         self.ren = Renderer(model, 0, 0, n_rays)
         self.tv = TVLoss()
         groups = model.get_optparam_groups(0.02, 1e-3)
-        try:     # one multi-tensor launch per step instead of ~60 small ones (same update rule)
+        if os.environ.get("NVFI_TORCH_ADAM"):    # A/B: PyTorch's own fused Adam
             self.opt = torch.optim.Adam(groups, betas=(0.9, 0.99), fused=True)
-        except Exception:
-            self.opt = torch.optim.Adam(groups, betas=(0.9, 0.99))
+        else:                                    # same update rule in one HIP launch (nvfi_adam_step); also clears the gradients
+            from nvfi_amd.optim import Adam
+            self.opt = Adam(groups, betas=(0.9, 0.99))
+        self.fused_zero = not os.environ.get("NVFI_TORCH_ADAM")
         self.bucket = GradBucket([p for g in self.opt.param_groups for p in g["params"]])
         self.o, self.d = camera_bundle(device)
         self.gen = torch.Generator(device=device); self.gen.manual_seed(233 + rank)
@@ -108,6 +110,7 @@ class Step:
         self.L1w, self.tvd, self.tva, self.vw = 8e-4, 1.0, 1.0, 1.0
         self.counters = []
         self.pde_counters = []
+        self.stepped = False
         self.fused_regs = True
         self.inplace = True
         from nvfi_amd.dist import PdeGradStage
@@ -126,7 +129,8 @@ class Step:
         m, f = self.m, self.m.nvfi
         if not m.training:
             m.train()
-        self.bucket.zero()
+        if not (self.fused_zero and self.stepped):   # after the first step the Adam launch has already cleared the gradients
+            self.bucket.zero()
         loss = 0
 
         def pde_term():
@@ -176,7 +180,10 @@ class Step:
             self.bucket.all_reduce_finish(h, self.tail_off)
         else:
             self.bucket.all_reduce_mean()
-        self.opt.step()
+        if self.fused_zero:
+            self.opt.step(zero_grad=True); self.stepped = True
+        else:
+            self.opt.step()
         for g in self.opt.param_groups:
             g["lr"] = g["lr"] * self.lr_factor
         return loss

@@ -143,6 +143,12 @@ int nvfi_sh_render(int64_t N, const float* view, const float* feat27, float* rgb
 int nvfi_plane_regs(const nvfi_field_desc* f, float w_l1, float w_tv_density, float w_tv_app, float* out3,
                     const nvfi_grads* grads, void* stream);
 
+/* ---- outer optimiser step: torch.optim.Adam(betas, eps) without amsgrad / weight decay (train_nvfi.py:88-96, 243) over n_tensors
+ *      parameter tensors in ONE launch.  `t` is a HOST array; p/g/m/v are device pointers (parameter, gradient, exp_avg, exp_avg_sq),
+ *      n elements each, lr the tensor's learning rate; `step` counts from 1 (bias corrections); zero_grad != 0 clears g in the same pass. */
+typedef struct nvfi_adam_tensor { float* p; float* g; float* m; float* v; int64_t n; float lr; } nvfi_adam_tensor;
+int nvfi_adam_step(const nvfi_adam_tensor* t, int n_tensors, float beta1, float beta2, float eps, int64_t step, int zero_grad, void* stream);
+
 /* ---- building blocks used by train_segm-style callers and by the parity tests */
 /* VelBasis.forward (velocity_field.py:69-75): xt (N,4) -> u (N,6)=(v,a); gated!=0: VelocityAABB[Sur].forward -> (N,3) in u (stride 6) */
 int nvfi_vel_eval(const nvfi_field_desc* f, int64_t N, const float* xt, float* u6, int gated,

@@ -31,6 +31,10 @@ class MaskDesc(C.Structure):
     _fields_ = [("n_layer", C.c_int32), ("n_dim", C.c_int32), ("mask_dim", C.c_int32), ("W", fp * 5), ("b", fp * 5)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("n", C.c_int64), ("lr", C.c_float)]
+
+
 class MaskGrads(C.Structure):
     _fields_ = [("W", fp * 5), ("b", fp * 5)]
 
@@ -46,7 +50,7 @@ class Grads(C.Structure):
 EXPORTS = [
     "nvfi_last_error", "nvfi_abi_version",
     "nvfi_render_workspace_bytes", "nvfi_render_workspace_bytes_t", "nvfi_render_fwd", "nvfi_render_bwd",
-    "nvfi_pde_workspace_bytes", "nvfi_pde_loss", "nvfi_pde_loss_ex", "nvfi_plane_regs", "nvfi_render_mask", "nvfi_maskfield_workspace_bytes", "nvfi_maskfield_fwd", "nvfi_maskfield_bwd", "nvfi_sh_render", "nvfi_compute_alpha", "nvfi_gen_rays",
+    "nvfi_pde_workspace_bytes", "nvfi_pde_loss", "nvfi_pde_loss_ex", "nvfi_plane_regs", "nvfi_adam_step", "nvfi_render_mask", "nvfi_maskfield_workspace_bytes", "nvfi_maskfield_fwd", "nvfi_maskfield_bwd", "nvfi_sh_render", "nvfi_compute_alpha", "nvfi_gen_rays",
     "nvfi_vel_eval", "nvfi_vel_workspace_bytes", "nvfi_integrate_pos", "nvfi_density_at", "nvfi_app_at",
     "nvfi_selftest", "nvfi_prof_enable", "nvfi_prof_collect", "nvfi_prof_nclasses",
 ]

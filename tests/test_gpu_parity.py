@@ -397,3 +397,43 @@ def test_eval_driver_psnr_and_png(fields, models, tmp_path):
     from PIL import Image
     img = np.asarray(Image.open(str(tmp_path / "r_001.png")))
     assert img.shape == (H, W, 3) and np.array_equal(img, res["images"][1])
+
+
+def test_fused_adam_matches_torch():
+    """nvfi_adam_step (one launch, per-group lr, optional gradient clearing) against torch.optim.Adam on mixed layouts / sizes"""
+    from nvfi_amd.optim import Adam
+    torch.manual_seed(0)
+    shapes = [(1, 24, 37, 41), (1, 48, 16, 9), (128, 128), (128,), (6, 128), (3,), (1, 1, 5, 7)]
+    ps_a, ps_b = [], []
+    for s in shapes:
+        t = torch.randn(*s, device="cuda")
+        if len(s) == 4 and s[1] > 1:
+            t = t.contiguous(memory_format=torch.channels_last)
+        ps_a.append(torch.nn.Parameter(t.clone(memory_format=torch.preserve_format)))
+        ps_b.append(torch.nn.Parameter(t.clone(memory_format=torch.preserve_format)))
+    ga = [dict(params=ps_a[:2], lr=0.02), dict(params=ps_a[2:], lr=1e-3)]
+    gb = [dict(params=ps_b[:2], lr=0.02), dict(params=ps_b[2:], lr=1e-3)]
+    oa, ob = Adam(ga, betas=(0.9, 0.99)), torch.optim.Adam(gb, betas=(0.9, 0.99))
+    for it in range(7):
+        for pa, pb in zip(ps_a, ps_b):
+            g = torch.randn_like(pa) * (10.0 ** (it % 3 - 1))
+            pa.grad = g.clone(memory_format=torch.preserve_format); pb.grad = g.clone(memory_format=torch.preserve_format)
+        oa.step(zero_grad=(it % 2 == 0)); ob.step()
+        for grp_a, grp_b in zip(oa.param_groups, ob.param_groups):
+            grp_a["lr"] *= 0.9; grp_b["lr"] *= 0.9
+        for pa, pb in zip(ps_a, ps_b):
+            assert pa.stride() == pb.stride()
+            np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+            if it % 2 == 0:
+                assert not pa.grad.any()
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 7
+        np.testing.assert_allclose(sa["state"][k]["exp_avg_sq"].cpu().numpy(), sb["state"][k]["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=1e-12)
+    ob.load_state_dict(sa)      # our state (python-int step) loads into torch.optim.Adam and vice versa
+    oa.load_state_dict(ob.state_dict())
+    for pa in ps_a:
+        pa.grad = torch.ones_like(pa, memory_format=torch.preserve_format)
+    oa.step()
+    assert oa.state[ps_a[0]]["step"] == 8
