@@ -1,6 +1,7 @@
 // engine.hip - fragment packing, split-K weight-gradient kernel, slab reduce.  See engine.h.
 #include "engine.h"
 #include "common.h"
+#include <stdlib.h>
 
 __global__ void k_pack(PackJobs jobs) {
     const PackJob& J = jobs.j[blockIdx.x];
@@ -42,7 +43,9 @@ __global__ void k_pack(PackJobs jobs) {
 //    non-MFMA work per item is kept minimal: wave-uniform addressing in SGPRs, activations only on the B side.
 // One wave per SIMD with the whole 512-register file: two complete operand sets alternate (explicitly, so the register
 // allocator cannot merge them) - while the 128 MFMAs of one item read one set, the loads of the next item fill the other.
-// (Quarter-tile rolling refills at 2 waves/SIMD were tried: 4x2 tiles spill, 2x2 tiles were 20 % slower overall.)
+// (Quarter-tile rolling refills at 2 waves/SIMD were tried: 4x2 tiles spill, 2x2 tiles were 20 % slower overall.  Half-tile items
+// with four rotating 48-register sets - no AGPR<->VGPR copies left in the loop, three items in flight - measured 6 % slower than
+// this whole-tile loop: neither the copies nor the prefetch depth is what limits it.)
 #ifndef WGRAD_MT
 #define WGRAD_MT 4        // row tiles per worker for 128-row A images
 #endif
@@ -142,24 +145,23 @@ __device__ __forceinline__ void wgrad_worker(const WgradJob& J, int worker, int 
     if (wslot < nitems) {
         // prefetches are unconditional (the last one re-reads a valid item) so that the loop is straight-line code and the
         // compiler's vmcnt bookkeeping leaves exactly the newest set in flight
-        const int last = nitems - 1;
-        int item = wslot;
-        wgrad_load<MT, KTW, tan>(o0, J, item, ntiles, aoff, boff);
+        // single-exit loop: with `break`s inside, the compiler copied all 128 accumulators AGPR -> VGPR in every trip for the exit paths
+        const int last = nitems - 1, stp = J.nslab;
+        const int n_my = (nitems - wslot + stp - 1) / stp;
+        auto it_of = [&](int k) { const int it = wslot + k * stp; return it < last ? it : last; };
+        wgrad_load<MT, KTW, tan>(o0, J, it_of(0), ntiles, aoff, boff);
 #pragma unroll 1
-        while (true) {
-            int ni = item + J.nslab;
-            wgrad_load<MT, KTW, tan>(o1, J, ni < last ? ni : last, ntiles, aoff, boff);
+        for (int k = 0; k < n_my; k += 2) {
+            wgrad_load<MT, KTW, tan>(o1, J, it_of(k + 1), ntiles, aoff, boff);
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (the scheduler would sink it to save registers)
             consume(o0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ni >= nitems) break;
-            item = ni; ni = item + J.nslab;
-            wgrad_load<MT, KTW, tan>(o0, J, ni < last ? ni : last, ntiles, aoff, boff);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(o1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ni >= nitems) break;
-            item = ni;
+            if (k + 1 < n_my) {
+                wgrad_load<MT, KTW, tan>(o0, J, it_of(k + 2), ntiles, aoff, boff);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(o1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     float* S = J.slabs + (size_t)wslot * ((size_t)a_rows * b_rows + a_rows);
