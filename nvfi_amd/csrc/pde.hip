@@ -35,10 +35,13 @@ __global__ __launch_bounds__(256) void k_pde_prep(PdePrepArgs a) {
         for (int c = 0; c < 3; ++c) xn[c] = norm_coord(f, c, a.points[3 * i + c]);
         a.qorig[i] = make_float4(xn[0], xn[1], xn[2], t);
         a.xw[i] = make_float4(xn[0], xn[1], xn[2], norm_time(f, base));
-        a.pt_t[i] = t; a.pt_base[i] = base;
+        // A point outside the velocity gate never moves (velocity_field.py:28-33,46-51: v = 0 there, so x_mid = x and the step leaves
+        // x where it is - it stays outside for every later step): class 0, no network evaluations.  Exact, not an approximation.
+        const bool frozen = gated_out(f, xn[0], xn[1], xn[2]);
+        a.pt_t[i] = t; a.pt_base[i] = frozen ? t : base;
         // number of RK2 steps this point will take (same fp32 recurrence as the integrator)
         const float dtm = dt_max_of(f);
-        float off = t - base;
+        float off = frozen ? 0.f : t - base;
         while (fabsf(off) > 0.f && ns < PDE_MAX_CLASS - 1) {
             float m = fminf(fabsf(off), dtm);
             off = off - (off > 0.f ? m : -m);
