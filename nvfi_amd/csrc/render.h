@@ -11,6 +11,7 @@ struct SampleArgs {
     int train;
     const int* inside;
     float4* xw; float* xpre; uint8_t* valid; int* cnt;
+    uint8_t* rflag; int* cnt_r;   // valid AND inside the velocity gate: the samples the RK2 warp has to touch (NULL: not wanted)
 };
 
 struct DensityArgs {

@@ -73,10 +73,10 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     float d[3] = {a.d[3 * r], a.d[3 * r + 1], a.d[3 * r + 2]};
     const float tmin = ray_tmin(f, *a.inside != 0, o, d);
     const float u = (a.train && a.u) ? a.u[r] : 0.f;
-    int cnt = 0;
+    int cnt = 0, cntr = 0;
     for (int j0 = 0; j0 < S; j0 += 64) {
         const int j = j0 + lane;
-        bool ok = false;
+        bool ok = false, mv = false;
         if (j < S) {
             float rng = (float)j + u;
             float step = f.step_size * rng;
@@ -94,10 +94,14 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
             a.xw[n] = make_float4(xn[0], xn[1], xn[2], z);
             a.xpre[n] = XPRE_INVALID;
             a.valid[n] = ok ? 1 : 0;
+            // a sample outside the velocity gate never moves (v = 0 there, velocity_field.py:28-33,46-51): the warp skips it
+            mv = ok && !gated_out(f, xn[0], xn[1], xn[2]);
+            if (a.rflag) a.rflag[n] = mv ? 1 : 0;
         }
         cnt += __popcll(__ballot(ok));
+        cntr += __popcll(__ballot(mv));
     }
-    if (lane == 0) a.cnt[r] = cnt;
+    if (lane == 0) { a.cnt[r] = cnt; if (a.cnt_r) a.cnt_r[r] = cntr; }
 }
 
 // exclusive scan of n int32 counts (single workgroup), off[n] = total, *total_out = total
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void k_density_bwd(DensityArgs a) {
     }
     if (a.gxk) {
         float4 ga = a.mflag[n] ? a.gxw[n] : zero4();   // appearance-branch part (masked samples only)
-        a.gxk[i] = make_float4(ga.x + g3[0], ga.y + g3[1], ga.z + g3[2], 0.f);
+        a.gxk[n] = make_float4(ga.x + g3[0], ga.y + g3[1], ga.z + g3[2], 0.f);   // dense (per sample): the RK2 adjoint walks its own list
     }
 }
 
@@ -922,8 +926,8 @@ struct RenderPlan {
     int64_t N, cap_tiles;
     int nsteps;
     int* counters;      // [0] V, [1] M, [2] inside flag
-    int *cnt_v, *off_v, *cnt_m, *off_m, *vlist, *mlist;
-    uint8_t *valid, *mflag;
+    int *cnt_v, *off_v, *cnt_m, *off_m, *vlist, *mlist, *cnt_r, *off_r, *rlist;
+    uint8_t *valid, *mflag, *rflag;
     float4 *xw, *rgbs, *rgb_pre, *gxw, *gxk;
     float *xpre, *gxpre;
     float *vel_frag, *render_frag;
@@ -949,6 +953,8 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->cnt_m = B.take<int>(R); P->off_m = B.take<int>(R + 1);
     P->vlist = B.take<int>(N); P->mlist = B.take<int>(N);
     P->valid = B.take<uint8_t>(N); P->mflag = B.take<uint8_t>(N);
+    P->cnt_r = P->off_r = P->rlist = nullptr; P->rflag = nullptr;
+    if (nsteps > 0) { P->cnt_r = B.take<int>(R); P->off_r = B.take<int>(R + 1); P->rlist = B.take<int>(N); P->rflag = B.take<uint8_t>(N); }
     P->xw = B.take<float4>(N + 1); P->rgbs = B.take<float4>(N); P->rgb_pre = B.take<float4>(R);
     P->xpre = B.take<float>(N);
     P->vel_frag = B.take<float>(VEL_FRAG_FLOATS);
@@ -1035,15 +1041,19 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
     // sampling
     hipLaunchKernelGGL(k_any_inside, dim3(64), dim3(256), 0, st, *f, R, rays_o, P.counters + 2);
     SampleArgs sa; sa.f = *f; sa.R = R; sa.o = rays_o; sa.d = rays_d; sa.u = jitter; sa.train = train; sa.inside = P.counters + 2;
-    sa.xw = P.xw; sa.xpre = P.xpre; sa.valid = P.valid; sa.cnt = P.cnt_v;
+    sa.xw = P.xw; sa.xpre = P.xpre; sa.valid = P.valid; sa.cnt = P.cnt_v; sa.rflag = P.rflag; sa.cnt_r = P.cnt_r;
     hipLaunchKernelGGL(k_sample, dim3(ray_blocks), dim3(256), 0, st, sa);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P.cnt_v, P.off_v, R, P.counters + 0);
     hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.valid, P.off_v, P.vlist);
+    if (nsteps > 0) {   // second compact list: the valid samples inside the velocity gate (counters[3])
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P.cnt_r, P.off_r, R, P.counters + 3);
+        hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.rflag, P.off_r, P.rlist);
+    }
     LAUNCHCK();
     // velocity warp back to the keyframe
     if (nsteps > 0) {
         Rk2Args ra; memset(&ra, 0, sizeof(ra));
-        ra.f = *f; ra.Wv = VW; ra.count = P.counters + 0; ra.list = P.vlist; ra.xw = P.xw; ra.xout = nullptr;
+        ra.f = *f; ra.Wv = VW; ra.count = P.counters + 3; ra.list = P.rlist; ra.xw = P.xw; ra.xout = nullptr;
         ra.nsteps = nsteps;
         for (int s = 0; s < nsteps; ++s) { ra.dt[s] = dts[s]; ra.tcur[s] = tcs[s]; }
         ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles;
@@ -1201,12 +1211,12 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     // RK2 adjoint + velocity-net weight gradients
     if (nsteps > 0) {
         Rk2Args ra; memset(&ra, 0, sizeof(ra));
-        ra.f = *f; ra.Wv = VW; ra.count = P.counters + 0; ra.list = P.vlist; ra.xw = P.xw;
+        ra.f = *f; ra.Wv = VW; ra.count = P.counters + 3; ra.list = P.rlist; ra.xw = P.xw;
         ra.nsteps = nsteps;
         for (int s = 0; s < nsteps; ++s) { ra.dt[s] = dts[s]; ra.tcur[s] = tcs[s]; }
         ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles; ra.gxk = P.gxk;
         if (launch_rk2_bwd(ra, N, st)) return 1;
-        if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 0, (int)P.cap_tiles, 2 * nsteps, BM_SILU, P.slabs, NSLAB,
+        if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 3, (int)P.cap_tiles, 2 * nsteps, BM_SILU, P.slabs, NSLAB,
                              grads->vW, grads->vb, 1.f, st)) return 1;
     }
     if (forked) { HIPCK(hipEventRecord(g_side.join, g_side.s)); HIPCK(hipStreamWaitEvent(st, g_side.join, 0)); }
@@ -1238,9 +1248,9 @@ int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, cons
 __global__ void k_counters(const int* c, int nsteps, int64_t* out) {
     if (threadIdx.x == 0) {
         out[0] = c[0];
-        out[1] = nsteps > 0 ? c[0] : 0;
+        out[1] = nsteps > 0 ? c[3] : 0;
         out[2] = c[1];
-        out[3] = (int64_t)c[0] * 2 * nsteps;
+        out[3] = (int64_t)(nsteps > 0 ? c[3] : 0) * 2 * nsteps;
         out[4] = out[5] = out[6] = out[7] = 0;
     }
 }

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_og(OgArgs a) {
             }
         } else if (i < count && sub == 0 && a.gxk) {
             const float4 ga = (a.mflag && a.mflag[n]) ? a.gxw[n] : zero4();   // appearance-branch part (masked samples only)
-            a.gxk[i] = make_float4(ga.x + g3[0], ga.y + g3[1], ga.z + g3[2], 0.f);
+            a.gxk[n] = make_float4(ga.x + g3[0], ga.y + g3[1], ga.z + g3[2], 0.f);   // dense (per sample): the RK2 adjoint walks its own list
         }
     }
 }

@@ -33,7 +33,7 @@ struct Rk2Args {
     float* zst; float* x0st; float* rec; float* gst;
     int64_t cap; int64_t cap_tiles;
     // backward
-    const float4* gxk;     // (count) upstream gradient wrt the warped position
+    const float4* gxk;     // (dense, per sample) upstream gradient wrt the warped position
 };
 
 int launch_vel_eval(const VelEvalArgs& a, hipStream_t st);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_bwd(Rk2Args a) {
     const int tile = blockIdx.x * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     const bool active = i < count;
-    float4 gin = active ? a.gxk[i] : zero4();
+    float4 gin = active ? a.gxk[a.list[i]] : zero4();     // upstream gradient of the warped position, stored per sample
     float g3[3] = {gin.x, gin.y, gin.z};
 #pragma unroll 1
     for (int s = a.nsteps - 1; s >= 0; --s) {
