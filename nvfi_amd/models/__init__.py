@@ -1,5 +1,5 @@
 """Mirror of the reference's `models` package surface for the hot path (models/__init__.py:1-6)."""
-from .camera import Ray, Camera
+from .camera import Ray, Camera, BatchedRays
 from .renderer import Renderer
 from .nvfi import NVFi
 from .tensorf_model_utils import AlphaGridMask

@@ -109,3 +109,21 @@ def test_checkpoint_round_trip(tmp_path):
     for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
     assert m2.nvfi.density_plane_space[0].is_contiguous(memory_format=torch.channels_last)
+
+
+def test_boundary_ray_types():
+    """`from models import *` of the reference exposes Ray, Camera, BatchedRays (models/__init__.py:1): containers behave alike"""
+    import torch
+    from nvfi_amd.models import BatchedRays, Camera, Ray
+    pose = torch.eye(4)
+    img = torch.rand(4, 5, 3)
+    b = BatchedRays([img, img * 0.5], [pose, pose], [0.1, 0.2], 4, 5, 3.0, 1.0, 8.0)
+    assert len(b) == 40 and b.all_rays.shape == (40, 6) and b.all_pixels.shape == (40, 3) and b.all_ts.shape == (40, 1)
+    assert float(b.all_ts[0]) == pytest.approx(0.1) and float(b.all_ts[-1]) == pytest.approx(0.2)
+    cam = Camera(pose, 4, 5, 3.0, img, 1.0, 8.0)
+    assert torch.equal(b.all_rays[:20, 3:], cam.rays.ray_directions.reshape(-1, 3))
+    r = Ray(torch.zeros(7, 3), torch.ones(7, 3), 1.0, 8.0)
+    p = r.points_sampling(6, perturb=False)
+    assert p.shape == (7, 6, 3) and float(p[0, 0, 0]) == pytest.approx(1.0) and float(p[0, -1, 0]) == pytest.approx(8.0)
+    r.update_near_far(2.0, 4.0)
+    assert r.near == 2.0 and r.far == 4.0
