@@ -125,5 +125,5 @@ def test_boundary_ray_types():
     r = Ray(torch.zeros(7, 3), torch.ones(7, 3), 1.0, 8.0)
     p = r.points_sampling(6, perturb=False)
     assert p.shape == (7, 6, 3) and float(p[0, 0, 0]) == pytest.approx(1.0) and float(p[0, -1, 0]) == pytest.approx(8.0)
-    r.update_near_far(2.0, 4.0)
-    assert r.near == 2.0 and r.far == 4.0
+    r.update_near_far(torch.full((7, 1), 2.0), torch.full((7, 1), 4.0))     # buffers: tensors, as in the reference
+    assert float(r.near[0]) == 2.0 and float(r.far[0]) == 4.0
