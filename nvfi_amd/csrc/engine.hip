@@ -191,8 +191,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_wgrad(WgradJobs jobs) {
         case BM_RAW: wgrad_worker<MT_, KT_, BM_RAW>(J, worker, lane); break;              \
         case BM_SILU: wgrad_worker<MT_, KT_, BM_SILU>(J, worker, lane); break;            \
         case BM_RELU: wgrad_worker<MT_, KT_, BM_RELU>(J, worker, lane); break;            \
-        case BM_SILU_TAN: wgrad_worker<(MT_ > 2 ? 2 : MT_), KT_, BM_SILU_TAN>(J, worker, lane); break;    \
-        default: wgrad_worker<(MT_ > 2 ? 2 : MT_), KT_, BM_RELU_TAN>(J, worker, lane); break;             \
+        case BM_SILU_TAN: wgrad_worker<MT_, (MT_ > 2 ? 1 : KT_), BM_SILU_TAN>(J, worker, lane); break;    \
+        default: wgrad_worker<MT_, (MT_ > 2 ? 1 : KT_), BM_RELU_TAN>(J, worker, lane); break;             \
     }
     if (J.a_regs == 64 && J.b_regs == 64) { WGRAD_MODES(WGRAD_MT, 2) }
     else if (J.a_regs == 16 && J.b_regs == 64) { WGRAD_MODES(1, 2) }   // 2 workers per slab
@@ -261,8 +261,10 @@ int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st) {
         const WgradJob& J = bj.j[i];
         const bool ok = (J.a_regs == 64 && J.b_regs == 64) || (J.a_regs == 16 && J.b_regs == 64) || (J.a_regs == 64 && J.b_regs == 16) || (J.a_regs == 16 && J.b_regs == 32);
         if (!ok) return nvfi_fail(5, "k_wgrad: unsupported tile shape a_regs=%d b_regs=%d", J.a_regs, J.b_regs);
-        const bool tanm = J.bmode == BM_SILU_TAN || J.bmode == BM_RELU_TAN;   // tangent jobs carry a second B stream: 2 row tiles per worker
-        const int mt = J.a_regs == 64 ? (tanm ? 2 : WGRAD_MT) : 1, ktw = J.b_regs == 16 ? 1 : 2;
+        // tangent jobs carry a second B stream and ~12 VALU instructions per B value (act'(z) * zd): 4 row tiles x ONE column tile per
+        // worker, so every B tile is activated by exactly one worker (2 x 2 tiles activated each B tile twice; 4 x 2 spills)
+        const bool tanm = J.bmode == BM_SILU_TAN || J.bmode == BM_RELU_TAN;
+        const int mt = J.a_regs == 64 ? WGRAD_MT : 1, ktw = (J.b_regs == 16 || (tanm && J.a_regs == 64)) ? 1 : 2;
         wps[i] = ((J.a_regs >> 4) / mt) * ((J.b_regs >> 4) / ktw);
         cost[i] = (double)(J.nrep > 0 ? J.nrep : 1) * wps[i] * (mt + ktw * (J.B2 ? 2 : 1));
         total += cost[i];
