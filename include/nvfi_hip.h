@@ -124,14 +124,17 @@ typedef struct nvfi_mask_desc {
 int nvfi_render_mask(const nvfi_field_desc* f, const nvfi_mask_desc* m, int64_t R, float t, int flags, const float* weights,
                      float* mask_map, void* workspace, int64_t workspace_bytes, void* stream);
 /* ---- MaskField on free points, forward and backward: the model train_segm.py:126-227 optimises (models/mask_field.py:68-83;
- *      xyz (N,3) -> softmax mask (N,mask_dim)).  train != 0 keeps the activations in `workspace` for nvfi_maskfield_bwd, which
+ *      xyz (N,3) -> softmax mask (N,mask_dim)).  mode & NVFI_MASK_TRAIN keeps the activations in `workspace` for nvfi_maskfield_bwd, which
  *      ACCUMULATES d loss / d W_l, b_l (l = point_fc.0..3, mask_fc) from g_mask = d loss / d mask (N,mask_dim); the points carry
  *      no gradient (the reference computes them under no_grad, train_segm.py:137-170). */
 typedef struct nvfi_mask_grads { float* W[5]; float* b[5]; } nvfi_mask_grads;
 int nvfi_maskfield_workspace_bytes(const nvfi_mask_desc* m, int64_t N, int train, int64_t* bytes);
-int nvfi_maskfield_fwd(const nvfi_mask_desc* m, int64_t N, const float* xyz, float* mask_out, int train,
+#define NVFI_MASK_TRAIN 1   /* keep the activations in `workspace` for nvfi_maskfield_bwd */
+#define NVFI_MASK_FP16  2   /* layer products on the fp16-input MFMA (weights and layer inputs rounded to fp16, fp32 accumulation,
+                               fp32 bias / ReLU / softmax / stashes / weight gradients); default: exact fp32 MFMA */
+int nvfi_maskfield_fwd(const nvfi_mask_desc* m, int64_t N, const float* xyz, float* mask_out, int mode,
                        void* workspace, int64_t workspace_bytes, void* stream);
-int nvfi_maskfield_bwd(const nvfi_mask_desc* m, int64_t N, const float* g_mask, const nvfi_mask_grads* grads,
+int nvfi_maskfield_bwd(const nvfi_mask_desc* m, int64_t N, const float* g_mask, const nvfi_mask_grads* grads, int mode,
                        void* workspace, int64_t workspace_bytes, void* stream);
 /* SHRender (models/tensorf_model_utils.py:292-296 with models/sh.py:87-110, degree 2): view (N,3), feat (N,27) -> rgb (N,3) */
 int nvfi_sh_render(int64_t N, const float* view, const float* feat27, float* rgb, void* stream);

@@ -154,6 +154,196 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_bwd(MkArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- fp16-input MFMA variant (BASELINE config 5: "fp16 MFMA MLP")
+// Same data flow with v_mfma_f32_32x32x16_f16: weights and layer inputs are rounded to fp16, products accumulate in fp32,
+// bias / ReLU / softmax and every stash stay fp32 (the weight gradients still run on the fp32 k_wgrad).  One MFMA covers 16 input
+// features: lane (n, h) supplies k = 8h + j  <->  feature 16 s + 8 (j >> 2) + 4 h + (j & 3), which is exactly registers
+// 8s .. 8s+7 of the previous layer's D-layout output - so, as in the fp32 engine, activations never leave registers and the
+// permutation lives in the packed weight fragments.  32 MFMAs of 32 cycles per 128x128 layer instead of 256 of 64.
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+__host__ __device__ inline int feat16(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+struct Pack16Job { const float* W; h8_t* frag; int out, in, MT, NS, transposed; };
+struct Pack16Jobs { Pack16Job j[12]; int n; };
+__global__ void k_pack16(Pack16Jobs jobs) {
+    const Pack16Job& J = jobs.j[blockIdx.x];
+    const int total = J.MT * J.NS * 64;
+    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += gridDim.y * blockDim.x) {
+        const int lane = idx & 63, ms = idx >> 6, sidx = ms % J.NS, m = ms / J.NS;
+        const int row = 32 * m + (lane & 31), h = lane >> 5;
+        h8_t v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = feat16(sidx, h, j);
+            float w = 0.f;
+            if (!J.transposed) { if (row < J.out && k < J.in) w = J.W[(size_t)row * J.in + k]; }      // rows = outputs, k = inputs
+            else { if (row < J.in && k < J.out) w = J.W[(size_t)k * J.in + row]; }                    // rows = inputs, k = outputs
+            v[j] = (_Float16)w;
+        }
+        J.frag[idx] = v;
+    }
+}
+
+struct Mk16Frags { const h8_t* f[5]; const float* b[5]; const h8_t* t[5]; };
+struct Mk16Args {
+    Mk16Frags W; int mask_dim; int64_t N;
+    const float* xyz; float* out; const float* g_out;
+    float* stash_f; float* stash_b;
+};
+
+__device__ __forceinline__ void stage16(h8_t* lds_w, const h8_t* __restrict__ frag, int n8, float* lds_b, const float* __restrict__ bias, int nb) {
+    const float4* src = reinterpret_cast<const float4*>(frag);
+    float4* dst = reinterpret_cast<float4*>(lds_w);
+    for (int i = threadIdx.x; i < n8; i += WG_THREADS) dst[i] = src[i];
+    if (threadIdx.x < 128) lds_b[threadIdx.x] = (bias && threadIdx.x < nb) ? bias[threadIdx.x] : 0.f;
+}
+template <int NS>
+__device__ __forceinline__ void to_h8(const float* x, h8_t* B) {
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) B[sidx][j] = (_Float16)x[8 * sidx + j];
+}
+// one layer: MT output tiles, NS k-steps; epi(m, acc)
+template <int MT, int NS, class Epi>
+__device__ __forceinline__ void layer16(const h8_t* lds_w, const float* lds_b, bool bias, int lane, int h, const h8_t* B, Epi epi) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias ? lds_b[32 * m + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) acc = MFMA16(lds_w[(m * NS + sidx) * 64 + lane], B[sidx], acc);
+        epi(m, acc);
+    }
+}
+
+template <bool STASH>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_fwd16(Mk16Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    h8_t* lds_w = reinterpret_cast<h8_t*>(lds); float* lds_b = lds + LDS_W_FLOATS;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int tile = blockIdx.x * 4 + wave_id();
+    const int64_t i = (int64_t)tile * TILE + (lane & 31);
+    const bool active = i < a.N;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (active) { px = a.xyz[3 * i]; py = a.xyz[3 * i + 1]; pz = a.xyz[3 * i + 2]; }
+    float* st = STASH ? a.stash_f + (size_t)tile * (MK_F_ROWS * REGF) : nullptr;
+    float xa[64], xb[64];
+    if (STASH) {   // the point slots in the fp32 engine's layout (B operand of the layer-0 weight gradient)
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) st[s2 * REGF + lane] = s2 == 0 ? (h ? py : px) : (s2 == 1 ? (h ? 0.f : pz) : 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xb[k] = 0.f;
+    if (h == 0) { xb[0] = px; xb[1] = py; xb[2] = pz; }     // features 0..2 = k 0..2 of lane half 0
+    h8_t B[8];
+    __syncthreads();
+    stage16(lds_w, a.W.f[0], 4 * 1 * 64, lds_b, a.W.b[0], 128);
+    __syncthreads();
+    to_h8<1>(xb, B);
+    layer16<4, 1>(lds_w, lds_b, true, lane, h, B, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { xa[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) st[(16 + 16 * m + r) * REGF + lane] = xa[16 * m + r]; }
+    });
+#pragma unroll 1
+    for (int l = 1; l < 4; ++l) {
+        __syncthreads();
+        stage16(lds_w, a.W.f[l], 4 * 8 * 64, lds_b, a.W.b[l], 128);
+        __syncthreads();
+        to_h8<8>(xa, B);
+        float* sl = STASH ? st + (size_t)(16 + 64 * l) * REGF : nullptr;
+        layer16<4, 8>(lds_w, lds_b, true, lane, h, B, [&](int m, const f32x16& acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { xb[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) sl[(16 * m + r) * REGF + lane] = xb[16 * m + r]; }
+        });
+#pragma unroll
+        for (int k = 0; k < 64; ++k) xa[k] = xb[k];
+    }
+    __syncthreads();
+    stage16(lds_w, a.W.f[4], 1 * 8 * 64, lds_b, a.W.b[4], a.mask_dim);
+    __syncthreads();
+    to_h8<8>(xa, B);
+    float o[16];
+    layer16<1, 8>(lds_w, lds_b, true, lane, h, B, [&](int, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = acc[r];
+    });
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int row = (r & 3) + 8 * (r >> 2) + 4 * h; if (row < a.mask_dim) mx = fmaxf(mx, o[r]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int row = (r & 3) + 8 * (r >> 2) + 4 * h; o[r] = row < a.mask_dim ? expf(o[r] - mx) : 0.f; sum += o[r]; }
+    sum += __shfl_xor(sum, 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float p = o[r] / sum;
+        if (STASH) st[(272 + r) * REGF + lane] = p;
+        if (active && row < a.mask_dim) a.out[(size_t)i * a.mask_dim + row] = p;
+    }
+}
+
+__global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_bwd16(Mk16Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    h8_t* lds_w = reinterpret_cast<h8_t*>(lds); float* lds_b = lds + LDS_W_FLOATS;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int tile = blockIdx.x * 4 + wave_id();
+    const int64_t i = (int64_t)tile * TILE + (lane & 31);
+    const bool active = i < a.N;
+    const float* stf = a.stash_f + (size_t)tile * (MK_F_ROWS * REGF);
+    float* stb = a.stash_b + (size_t)tile * (MK_B_ROWS * REGF);
+    float g[64], gn[64];
+    {
+        float p[16], go[16], dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            p[r] = stf[(272 + r) * REGF + lane];
+            go[r] = (active && row < a.mask_dim) ? a.g_out[(size_t)i * a.mask_dim + row] : 0.f;
+            dot += go[r] * p[r];
+        }
+        dot += __shfl_xor(dot, 32);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g[r] = p[r] * (go[r] - dot); stb[r * REGF + lane] = g[r]; }
+    }
+    h8_t B[8];
+    __syncthreads();
+    stage16(lds_w, a.W.t[4], 4 * 2 * 64, lds_b, nullptr, 0);
+    __syncthreads();
+    to_h8<2>(g, B);
+    layer16<4, 2>(lds_w, lds_b, false, lane, h, B, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gn[16 * m + r] = acc[r];
+    });
+#pragma unroll 1
+    for (int l = 3; l >= 1; --l) {
+        const float* hh = stf + (size_t)(16 + 64 * l) * REGF;
+        float* gz = stb + (size_t)(16 + 64 * (3 - l)) * REGF;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) g[k] = hh[k * REGF + lane] > 0.f ? gn[k] : 0.f;
+        stash_store<64>(gz, lane, g);
+        __syncthreads();
+        stage16(lds_w, a.W.t[l], 4 * 8 * 64, lds_b, nullptr, 0);
+        __syncthreads();
+        to_h8<8>(g, B);
+        layer16<4, 8>(lds_w, lds_b, false, lane, h, B, [&](int m, const f32x16& acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gn[16 * m + r] = acc[r];
+        });
+    }
+    {
+        const float* hh = stf + (size_t)16 * REGF;
+        float* gz = stb + (size_t)(16 + 64 * 3) * REGF;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) g[k] = hh[k * REGF + lane] > 0.f ? gn[k] : 0.f;
+        stash_store<64>(gz, lane, g);
+    }
+}
+
 __global__ void k_set_int(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 
 struct MkPlan { float* frag; float* stash_f; float* stash_b; float* slabs; int* count; int64_t tiles; int64_t total; };
@@ -204,12 +394,41 @@ static int mask_frags(const nvfi_mask_desc* m, float* frag, MkFrags* W, bool tra
     return launch_pack(jobs, st);
 }
 
+// fp16 fragments inside the same workspace region: forward l=0 (4x1), l=1..3 (4x8), l=4 (1x8); transposed l=1..3 (4x8), l=4 (4x2)
+static void mask_frag16_ptrs(float* frag, Mk16Frags* W, const nvfi_mask_desc* m) {
+    h8_t* p = reinterpret_cast<h8_t*>(frag);
+    for (int l = 0; l < 5; ++l) { const int MT = l < 4 ? 4 : 1, NS = l == 0 ? 1 : 8; W->f[l] = p; p += MT * NS * 64; W->b[l] = m ? m->b[l] : nullptr; }
+    W->t[0] = nullptr;
+    for (int l = 1; l < 5; ++l) { const int NS = l < 4 ? 8 : 2; W->t[l] = p; p += 4 * NS * 64; }
+}
+static int mask_frags16(const nvfi_mask_desc* m, float* frag, Mk16Frags* W, bool transposed, hipStream_t st) {
+    mask_frag16_ptrs(frag, W, m);
+    Pack16Jobs jobs; jobs.n = 0;
+    for (int l = 0; l < 5; ++l) {
+        Pack16Job& J = jobs.j[jobs.n++];
+        J.W = m->W[l]; J.frag = const_cast<h8_t*>(W->f[l]); J.out = l < 4 ? 128 : m->mask_dim; J.in = l == 0 ? 3 : 128;
+        J.MT = l < 4 ? 4 : 1; J.NS = l == 0 ? 1 : 8; J.transposed = 0;
+    }
+    if (transposed)
+        for (int l = 1; l < 5; ++l) {
+            Pack16Job& J = jobs.j[jobs.n++];
+            J.W = m->W[l]; J.frag = const_cast<h8_t*>(W->t[l]); J.out = l < 4 ? 128 : m->mask_dim; J.in = 128;
+            J.MT = 4; J.NS = l < 4 ? 8 : 2; J.transposed = 1;
+        }
+    hipLaunchKernelGGL(k_pack16, dim3(jobs.n, 4), dim3(256), 0, st, jobs);
+    LAUNCHCK();
+    return 0;
+}
+
 static int mask_attrs() {
     static bool done = false;
     if (done) return 0;
     HIPCK(hipFuncSetAttribute((const void*)k_maskfield_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     HIPCK(hipFuncSetAttribute((const void*)k_maskfield_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     HIPCK(hipFuncSetAttribute((const void*)k_maskfield_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_maskfield_fwd16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_maskfield_fwd16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_maskfield_bwd16, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     done = true;
     return 0;
 }
@@ -222,8 +441,9 @@ extern "C" int nvfi_maskfield_workspace_bytes(const nvfi_mask_desc* m, int64_t N
     return 0;
 }
 
-extern "C" int nvfi_maskfield_fwd(const nvfi_mask_desc* m, int64_t N, const float* xyz, float* mask_out, int train,
+extern "C" int nvfi_maskfield_fwd(const nvfi_mask_desc* m, int64_t N, const float* xyz, float* mask_out, int mode,
                                   void* workspace, int64_t workspace_bytes, void* stream) {
+    const int train = mode & NVFI_MASK_TRAIN;
     hipStream_t st = (hipStream_t)stream;
     if (mask_check(m)) return 2;
     if (N <= 0) return 0;
@@ -232,17 +452,26 @@ extern "C" int nvfi_maskfield_fwd(const nvfi_mask_desc* m, int64_t N, const floa
     MkPlan P;
     plan_mask(N, train, workspace, &P);
     if (P.total > workspace_bytes) return nvfi_fail(4, "workspace too small");
+    const unsigned wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
+    if (mode & NVFI_MASK_FP16) {
+        Mk16Args h; memset(&h, 0, sizeof(h));
+        if (mask_frags16(m, P.frag, &h.W, train != 0, st)) return 1;
+        h.mask_dim = m->mask_dim; h.N = N; h.xyz = xyz; h.out = mask_out; h.stash_f = P.stash_f; h.stash_b = P.stash_b;
+        if (train) hipLaunchKernelGGL(k_maskfield_fwd16<true>, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, h);
+        else hipLaunchKernelGGL(k_maskfield_fwd16<false>, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, h);
+        LAUNCHCK();
+        return 0;
+    }
     MkArgs a; memset(&a, 0, sizeof(a));
     if (mask_frags(m, P.frag, &a.W, train != 0, st)) return 1;
     a.mask_dim = m->mask_dim; a.N = N; a.xyz = xyz; a.out = mask_out; a.stash_f = P.stash_f; a.stash_b = P.stash_b;
-    const unsigned wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
     if (train) hipLaunchKernelGGL(k_maskfield_fwd<true>, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
     else hipLaunchKernelGGL(k_maskfield_fwd<false>, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
     LAUNCHCK();
     return 0;
 }
 
-extern "C" int nvfi_maskfield_bwd(const nvfi_mask_desc* m, int64_t N, const float* g_mask, const nvfi_mask_grads* grads,
+extern "C" int nvfi_maskfield_bwd(const nvfi_mask_desc* m, int64_t N, const float* g_mask, const nvfi_mask_grads* grads, int mode,
                                   void* workspace, int64_t workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (mask_check(m)) return 2;
@@ -260,6 +489,12 @@ extern "C" int nvfi_maskfield_bwd(const nvfi_mask_desc* m, int64_t N, const floa
     }
     a.mask_dim = m->mask_dim; a.N = N; a.g_out = g_mask; a.stash_f = P.stash_f; a.stash_b = P.stash_b;
     const unsigned wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
+    if (mode & NVFI_MASK_FP16) {
+        Mk16Args h; memset(&h, 0, sizeof(h));
+        mask_frag16_ptrs(P.frag, &h.W, m);
+        h.mask_dim = m->mask_dim; h.N = N; h.g_out = g_mask; h.stash_f = P.stash_f; h.stash_b = P.stash_b;
+        hipLaunchKernelGGL(k_maskfield_bwd16, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, h);
+    } else
     hipLaunchKernelGGL(k_maskfield_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, st, P.count, (int)N);
     LAUNCHCK();

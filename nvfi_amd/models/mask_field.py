@@ -41,9 +41,10 @@ class _MaskFn(torch.autograd.Function):
         _lib.check(L.nvfi_maskfield_workspace_bytes(C.byref(md), C.c_int64(N), C.c_int(1 if train else 0), C.byref(nbytes)))
         ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=pts.device)
         out = torch.empty(N, mf.mask_dim, device=pts.device, dtype=torch.float32)
-        _lib.check(L.nvfi_maskfield_fwd(C.byref(md), C.c_int64(N), _lib.ptr(pts), _lib.ptr(out), C.c_int(1 if train else 0),
+        mode = (1 if train else 0) | (2 if mf.mfma_fp16 else 0)
+        _lib.check(L.nvfi_maskfield_fwd(C.byref(md), C.c_int64(N), _lib.ptr(pts), _lib.ptr(out), C.c_int(mode),
                                         _lib.ptr(ws), C.c_int64(ws.numel()), _stream_ptr()))
-        ctx.mf, ctx.N, ctx.ws, ctx.params_c, ctx.train = mf, N, ws, params_c, train
+        ctx.mf, ctx.N, ctx.ws, ctx.params_c, ctx.train, ctx.mode = mf, N, ws, params_c, train, mode
         return out
 
     @staticmethod
@@ -58,15 +59,18 @@ class _MaskFn(torch.autograd.Function):
             mg.W[i] = _lib.ptr(grads[2 * i]); mg.b[i] = _lib.ptr(grads[2 * i + 1])
         g = g_out.contiguous().float()
         if ctx.N > 0:
-            _lib.check(L.nvfi_maskfield_bwd(C.byref(md), C.c_int64(ctx.N), _lib.ptr(g), C.byref(mg), _lib.ptr(ctx.ws),
+            _lib.check(L.nvfi_maskfield_bwd(C.byref(md), C.c_int64(ctx.N), _lib.ptr(g), C.byref(mg), C.c_int(ctx.mode), _lib.ptr(ctx.ws),
                                             C.c_int64(ctx.ws.numel()), _stream_ptr()))
         ctx.ws = None
         return (None, None) + tuple(grads)
 
 
 class MaskField(nn.Module):
-    def __init__(self, n_layer=4, n_dim=128, input_dim=3, skips=(), mask_dim=8, mask_act="softmax", point_embed=False):
+    def __init__(self, n_layer=4, n_dim=128, input_dim=3, skips=(), mask_dim=8, mask_act="softmax", point_embed=False, mfma_fp16=False):
         super().__init__()
+        # mfma_fp16 (not a reference argument): layer products on the fp16-input MFMA with fp32 accumulation (BASELINE config 5);
+        # the default is the exact-fp32 MFMA path that matches the reference's fp32 train_segm.py
+        self.mfma_fp16 = bool(mfma_fp16)
         if n_layer != 4 or n_dim != 128 or input_dim != 3 or len(skips) or mask_act != "softmax" or point_embed:
             raise NotImplementedError("only the MaskField of train_segm.py:97-102 (3->128x4->K, softmax) is on the hot path")
         if not 1 <= mask_dim <= 32:

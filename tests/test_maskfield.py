@@ -116,3 +116,24 @@ def test_gpu_segm_iteration(mgold):
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,K", [("K8", 8), ("K3", 3)])
+def test_gpu_maskfield_fp16_mfma_mode(mgold, tag, K):
+    """optional fp16-input MFMA mode (BASELINE config 5): weights / layer inputs rounded to fp16, fp32 accumulation - fp16 tolerance"""
+    mf = _model(mgold, tag, K)
+    mf.mfma_fp16 = True
+    pts = torch.from_numpy(mgold[f"{tag}:pts"]).cuda()
+    g = torch.from_numpy(mgold[f"{tag}:g"]).cuda()
+    mask = mf(pts)
+    ref = mgold[f"{tag}:mask"]
+    assert np.abs(mask.detach().cpu().numpy() - ref).max() < 5e-3          # probabilities, fp16 inputs (eps 4.9e-4) through 5 layers
+    np.testing.assert_allclose(mask.detach().sum(1).cpu().numpy(), 1.0, atol=1e-5)
+    (mask * g).sum().backward()
+    for n, p in mf.named_parameters():      # fp16 rounding flips ReLU gates of near-zero pre-activations: direction, not digits
+        a, b = p.grad.cpu().numpy().ravel().astype(np.float64), mgold[f"{tag}:grad:{n}"].ravel().astype(np.float64)
+        assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.995, n
+        assert relerr(p.grad.cpu().numpy(), mgold[f"{tag}:grad:{n}"]) < 0.2, n
+    mf.mfma_fp16 = False
+    assert np.abs(mf(pts).detach().cpu().numpy() - ref).max() < 1e-5          # and back to the exact path
