@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "common.h"
+#include "scatter.h"
 #include "vel.h"
 
 static thread_local char g_err[512] = "";
@@ -67,12 +68,10 @@ __global__ void k_alpha_prep(nvfi_field_desc f, int64_t N, const float* xyz, flo
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < N) xw[i] = make_float4(norm_coord(f, 0, xyz[3 * i]), norm_coord(f, 1, xyz[3 * i + 1]), norm_coord(f, 2, xyz[3 * i + 2]), tn);
 }
-__global__ void k_alpha_finish(nvfi_field_desc f, int64_t N, const float4* xw, float length, int acc_max, float* out) {
+__global__ void k_alpha_finish(int64_t N, const float* sig, float length, int acc_max, float* out) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const float4 q = xw[i];
-    const float sigma = softplus_f(density_feature(f, q.x, q.y, q.z, q.w) + f.density_shift);
-    const float a = 1.f - expf(-sigma * length);
+    const float a = 1.f - expf(-sig[i] * length);
     out[i] = acc_max ? fmaxf(out[i], a) : a;
 }
 extern "C" int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const float* xyz_world, float t, int transfer, float length,
@@ -83,6 +82,7 @@ extern "C" int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const flo
     Bump B{(char*)workspace, 0, 0};
     float* fv = B.take<float>(VEL_FRAG_FLOATS);
     float4* xw = B.take<float4>(N);
+    float* sig = B.take<float>(N);
     if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
     const float base = transfer ? 0.f : snap_base(*f, t);
     const unsigned nb = (unsigned)((N + 255) / 256);
@@ -105,7 +105,12 @@ extern "C" int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const flo
         a.f = *f; a.count = nullptr; a.n_direct = N; a.list = nullptr; a.xw = xw; a.xout = nullptr; a.nsteps = n;
         if (launch_rk2_fwd(a, N, true, false, st)) return 1;
     }
-    hipLaunchKernelGGL(k_alpha_finish, dim3(nb), dim3(256), 0, st, *f, N, xw, length, accumulate_max, alpha_out);
+    {   // density at the (warped) points with the quad-lane gather kernel (scatter.hip), then alpha = 1 - exp(-sigma * length)
+        DensityArgs da; memset(&da, 0, sizeof(da));
+        da.f = *f; da.n_direct = N; da.xw = xw; da.per_point_t = 1; da.sigma_out = sig;
+        if (launch_density_q(da, N, st)) return 1;
+    }
+    hipLaunchKernelGGL(k_alpha_finish, dim3(nb), dim3(256), 0, st, N, sig, length, accumulate_max, alpha_out);
     LAUNCHCK();
     return 0;
 }

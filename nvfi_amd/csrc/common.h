@@ -161,23 +161,6 @@ __device__ __forceinline__ void plane_mults(const nvfi_field_desc& f, int i, flo
     my = i < 3 ? (float)(f.G[bb[i]] - 1) / 2.f : (float)(f.K - 1) / 2.f;
 }
 
-__device__ __forceinline__ float density_feature(const nvfi_field_desc& f, float x, float y, float z, float tn) {
-    Bl b[6];
-    plane_setups(f, x, y, z, tn, b);
-    float sum = 0.f;
-    const int nq = f.Cd >> 2;
-    for (int q4 = 0; q4 < nq; ++q4) {
-        float4 s0 = bl_sample4(f.dps[0], f.Cd, b[0], q4), s1 = bl_sample4(f.dps[1], f.Cd, b[1], q4), s2 = bl_sample4(f.dps[2], f.Cd, b[2], q4);
-        float4 t0 = bl_sample4(f.dpt[0], f.Cd, b[3], q4), t1 = bl_sample4(f.dpt[1], f.Cd, b[4], q4), t2 = bl_sample4(f.dpt[2], f.Cd, b[5], q4);
-        sum += ((s0.x * s1.x) * s2.x) * ((t0.x * t1.x) * t2.x);
-        sum += ((s0.y * s1.y) * s2.y) * ((t0.y * t1.y) * t2.y);
-        sum += ((s0.z * s1.z) * s2.z) * ((t0.z * t1.z) * t2.z);
-        sum += ((s0.w * s1.w) * s2.w) * ((t0.w * t1.w) * t2.w);
-    }
-    return sum;
-}
-
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

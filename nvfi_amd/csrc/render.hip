@@ -154,18 +154,7 @@ int launch_scan_fill(const int* cnt, int* off, int64_t ngroups, int* total, cons
 }
 
 // ================================================================ density
-__global__ __launch_bounds__(256) void k_density_fwd(DensityArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int count = a.count ? *a.count : (int)a.n_direct;
-    if (i >= count) return;
-    const int n = a.list ? a.list[i] : i;
-    const float4 q = a.xw[n];
-    const float tn = a.per_point_t ? q.w : a.tn;
-    const float ft = density_feature(a.f, q.x, q.y, q.z, tn);
-    if (a.feat_out) a.feat_out[n] = ft;
-    if (a.xpre) a.xpre[n] = ft + a.f.density_shift;
-    if (a.sigma_out) a.sigma_out[n] = softplus_f(ft + a.f.density_shift);
-}
+// (forward: k_density_q in scatter.hip - lanes = sample x channel quad)
 
 // backward: gxpre -> plane grads (atomics) + coordinate grads
 __global__ __launch_bounds__(256) void k_density_bwd(DensityArgs a) {
