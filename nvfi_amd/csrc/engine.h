@@ -145,6 +145,28 @@ template <int ACT> __device__ __forceinline__ void act_d12(float z, float& d1, f
     d2 = s * (1.f - s) * (2.f + z * (1.f - 2.f * s));
 }
 
+// Pairs of values on the packed-fp32 VALU (v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fp32 per instruction slot).  Same
+// operations in the same order as the scalar forms above - bit-identical results - with about half the issue slots for the
+// polynomial part; the two transcendentals per value stay scalar.  Epilogues of the one-wave-per-SIMD kernels are not hidden
+// behind MFMAs, so their VALU count is kernel time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fast_sigmoid2(f32x2 z) {
+    f32x2 s; s.x = fast_sigmoid(z.x); s.y = fast_sigmoid(z.y);
+    return s;
+}
+template <int ACT> __device__ __forceinline__ void act_d12_2(f32x2 z, f32x2& d1, f32x2& d2) {
+    if (ACT == 0) { d1.x = z.x > 0.f ? 1.f : 0.f; d1.y = z.y > 0.f ? 1.f : 0.f; d2 = (f32x2)(0.f); return; }
+    const f32x2 s = fast_sigmoid2(z);
+    const f32x2 oms = 1.f - s;
+    d1 = s * (1.f + z * oms);
+    d2 = s * oms * (2.f + z * (1.f - 2.f * s));
+}
+template <int ACT> __device__ __forceinline__ f32x2 act_d1_2(f32x2 z) {
+    if (ACT == 0) { f32x2 d; d.x = z.x > 0.f ? 1.f : 0.f; d.y = z.y > 0.f ? 1.f : 0.f; return d; }
+    const f32x2 s = fast_sigmoid2(z);
+    return s * (1.f + z * (1.f - s));
+}
+
 // ---------------------------------------------------------------- LDS staging + MFMA layer
 __device__ __forceinline__ void stage_frag(float* lds_w, float* lds_b, const float* __restrict__ frag, int nfloats,
                                            const float* __restrict__ bfrag, int nb) {
@@ -489,7 +511,10 @@ __device__ __forceinline__ void velnet_backward_p(const VelFrags& W, FragPipe& P
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[16 * m + r] = acc[m][r] * act_d1<ACT>(zp[16 * m + r]);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v2 = (f32x2){acc[m][r], acc[m][r + 1]} * act_d1_2<ACT>((f32x2){zp[16 * m + r], zp[16 * m + r + 1]});
+                g[16 * m + r] = v2.x; g[16 * m + r + 1] = v2.y;
+            }
         if (gst) stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
         if (l > 1) P.issue(W.t[l - 1], VEL_FH); else P.issue(W.t[0], VEL_T0);
         stash_load<64>(zst + (size_t)(l - 1) * 64 * REGF, lane, zp);
@@ -501,7 +526,10 @@ __device__ __forceinline__ void velnet_backward_p(const VelFrags& W, FragPipe& P
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[16 * m + r] = acc[m][r] * act_d1<ACT>(zp[16 * m + r]);
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 v2 = (f32x2){acc[m][r], acc[m][r + 1]} * act_d1_2<ACT>((f32x2){zp[16 * m + r], zp[16 * m + r + 1]});
+            g[16 * m + r] = v2.x; g[16 * m + r + 1] = v2.y;
+        }
     if (gst) stash_store<64>(gst, lane, g);
     P.issue(next_frag, next_n);
     __builtin_amdgcn_sched_barrier(0);

@@ -263,12 +263,14 @@ __device__ __forceinline__ void velnet_tangent_backward_p(const VelFrags& W, Fra
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {
                 const int s = 16 * m + r;
-                float d1, d2;
-                act_d12<ACT>(zp[s], d1, d2);
-                cl[s * REGF + lane] = d2 * zdp[s] * acc[m][r];
-                g[s] = d1 * acc[m][r];
+                f32x2 d1, d2;
+                act_d12_2<ACT>((f32x2){zp[s], zp[s + 1]}, d1, d2);
+                const f32x2 a2 = {acc[m][r], acc[m][r + 1]};
+                const f32x2 c2 = d2 * (f32x2){zdp[s], zdp[s + 1]} * a2, g2 = d1 * a2;
+                cl[s * REGF + lane] = c2.x; cl[(s + 1) * REGF + lane] = c2.y;
+                g[s] = g2.x; g[s + 1] = g2.y;
             }
         stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
         if (l >= 1) {
@@ -302,9 +304,11 @@ __device__ __forceinline__ void velnet_tangent_forward_p(const VelFrags& W, Frag
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {
                 zd[(16 * m + r) * REGF + lane] = acc[m][r];
-                x[16 * m + r] = act_d1<ACT>(zp[16 * m + r]) * acc[m][r];
+                zd[(16 * m + r + 1) * REGF + lane] = acc[m][r + 1];
+                const f32x2 v2 = act_d1_2<ACT>((f32x2){zp[16 * m + r], zp[16 * m + r + 1]}) * (f32x2){acc[m][r], acc[m][r + 1]};
+                x[16 * m + r] = v2.x; x[16 * m + r + 1] = v2.y;
             }
         if (l < 3) P.issue(W.f[l + 2], VEL_FH); else P.issue(W.f[5], VEL_F5);
         stash_load<64>(zst + (size_t)(l + 1) * 64 * REGF, lane, zp);
@@ -318,9 +322,11 @@ __device__ __forceinline__ void velnet_tangent_forward_p(const VelFrags& W, Frag
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {
                 zd[(16 * m + r) * REGF + lane] = acc[m][r];
-                x[16 * m + r] = act_d1<ACT>(zp[16 * m + r]) * acc[m][r];
+                zd[(16 * m + r + 1) * REGF + lane] = acc[m][r + 1];
+                const f32x2 v2 = act_d1_2<ACT>((f32x2){zp[16 * m + r], zp[16 * m + r + 1]}) * (f32x2){acc[m][r], acc[m][r + 1]};
+                x[16 * m + r] = v2.x; x[16 * m + r + 1] = v2.y;
             }
     }
     f32x16 o[1];
@@ -350,7 +356,10 @@ __device__ __forceinline__ void velnet_value_backward_p(const VelFrags& W, FragP
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[16 * m + r] = act_d1<ACT>(zp[16 * m + r]) * acc[m][r];
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v2 = act_d1_2<ACT>((f32x2){zp[16 * m + r], zp[16 * m + r + 1]}) * (f32x2){acc[m][r], acc[m][r + 1]};
+                g[16 * m + r] = v2.x; g[16 * m + r + 1] = v2.y;
+            }
         stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
         if (l >= 1) {
             if (l > 1) P.issue(W.t[l - 1], VEL_FH); else P.issue(nullptr, 0);
