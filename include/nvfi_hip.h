@@ -163,6 +163,7 @@ int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const float* x, cons
 /* compute_densityfeature + feature2density (tensorf_keyframe.py:233-272, 312-321): xyzt (N,4) -> feat (N), sigma (N) */
 int nvfi_density_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, float* feat, float* sigma, void* stream);
 /* compute_appfeature + MLPRender_PE (tensorf_keyframe.py:274-310, tensorf_base.py:88-98): xyzt (N,4), view (N,3) -> rgb (N,3) */
+int nvfi_app_workspace_bytes(const nvfi_field_desc* f, int64_t N, int64_t* bytes);
 int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, const float* view, float* rgb,
                 void* workspace, int64_t workspace_bytes, void* stream);
 /* per-kernel-class HIP-event timing for bench.py: enable, run, collect (host arrays of nvfi_prof_nclasses() entries).
@@ -173,6 +174,7 @@ int nvfi_prof_nclasses(void);
 /* compute_alpha (tensorf_keyframe.py:508-537) for a per-call time: xyz (N,3) WORLD coordinates -> normalise, snap to the keyframe
  * (base 0 when transfer), RK2 back-advect, density, alpha = 1-exp(-sigma*length); alpha_out[n] = max(alpha_out[n], alpha) when
  * accumulate_max != 0 (getDenseAlpha's running maximum over the 60 frame times, :476-497), plain store otherwise. */
+int nvfi_alpha_workspace_bytes(const nvfi_field_desc* f, int64_t N, int64_t* bytes);
 int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const float* xyz_world, float t, int transfer, float length,
                        int accumulate_max, float* alpha_out, void* workspace, int64_t workspace_bytes, void* stream);
 /* Camera.get_ray_bundle + pixel selection (models/camera.py:112-138,159-172): pose (device float[12], row-major 3x4 c2w),

@@ -74,15 +74,28 @@ __global__ void k_alpha_finish(int64_t N, const float* sig, float length, int ac
     const float a = 1.f - expf(-sig[i] * length);
     out[i] = acc_max ? fmaxf(out[i], a) : a;
 }
+struct AlphaPlan { float* fv; float4* xw; float* sig; int64_t total; };
+static void plan_alpha(int64_t N, void* ws, AlphaPlan* P) {
+    Bump B{(char*)ws, 0, 0};
+    P->fv = B.take<float>(VEL_FRAG_FLOATS);
+    P->xw = B.take<float4>(N);
+    P->sig = B.take<float>(N);
+    P->total = align_up(B.off, 256);
+}
+extern "C" int nvfi_alpha_workspace_bytes(const nvfi_field_desc* f, int64_t N, int64_t* bytes) {
+    (void)f;
+    AlphaPlan P; plan_alpha(N > 0 ? N : 0, nullptr, &P);
+    *bytes = P.total;
+    return 0;
+}
 extern "C" int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const float* xyz_world, float t, int transfer, float length,
                                   int accumulate_max, float* alpha_out, void* workspace, int64_t workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (N <= 0) return 0;
     if (N >= (1ll << 31) - 256) return nvfi_fail(2, "N too large for one call; chunk the points");
-    Bump B{(char*)workspace, 0, 0};
-    float* fv = B.take<float>(VEL_FRAG_FLOATS);
-    float4* xw = B.take<float4>(N);
-    float* sig = B.take<float>(N);
+    AlphaPlan AP; plan_alpha(N, workspace, &AP);
+    float* fv = AP.fv; float4* xw = AP.xw; float* sig = AP.sig;
+    struct { int64_t off; } B{AP.total};
     if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
     const float base = transfer ? 0.f : snap_base(*f, t);
     const unsigned nb = (unsigned)((N + 255) / 256);

@@ -49,11 +49,12 @@ extern "C" int nvfi_adam_step(const nvfi_adam_tensor* t, int n_tensors, float be
     if (n_tensors <= 0) return 0;
     if (step < 1) return nvfi_fail(2, "nvfi_adam_step: step counts from 1");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    for (int base = 0; base < n_tensors; base += ADAM_MAX_T) {
+    for (int base = 0; base < n_tensors;) {
         AdamArgs a; memset(&a, 0, sizeof(a));
         a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.zero_grad = zero_grad;
         int64_t nmax = 0;
-        for (int k = base; k < n_tensors && a.n < ADAM_MAX_T; ++k) {
+        int k = base;
+        for (; k < n_tensors && a.n < ADAM_MAX_T; ++k) {
             if (!t[k].p || !t[k].g || !t[k].m || !t[k].v) return nvfi_fail(2, "nvfi_adam_step: tensor %d has a NULL pointer", k);
             if (t[k].n <= 0) continue;
             AdamT& T = a.t[a.n++];
@@ -63,6 +64,7 @@ extern "C" int nvfi_adam_step(const nvfi_adam_tensor* t, int n_tensors, float be
             T.vec = ((al & 15) == 0 && (T.n & 3) == 0) ? 1 : 0;
             nmax = T.n > nmax ? T.n : nmax;
         }
+        base = k;      // running index: empty tensors are skipped without being counted against the batch
         if (a.n == 0) continue;
         int64_t bx = (nmax / 4 + 255) / 256;
         if (bx < 1) bx = 1;

@@ -1255,6 +1255,13 @@ extern "C" int nvfi_density_at(const nvfi_field_desc* f, int64_t N, const float*
     return launch_density_q(da, N, st);
 }
 
+extern "C" int nvfi_app_workspace_bytes(const nvfi_field_desc* f, int64_t N, int64_t* bytes) {
+    (void)f;
+    Bump B{nullptr, 0, 0};
+    B.take<float>(RENDER_FRAG_FLOATS); B.take<float4>(N > 0 ? N : 0);
+    *bytes = align_up(B.off, 256);
+    return 0;
+}
 extern "C" int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, const float* view, float* rgb,
                            void* workspace, int64_t workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;

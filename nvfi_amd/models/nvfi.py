@@ -22,8 +22,21 @@ class NVFi(nn.Module):
         return self.nvfi(t, ray_o, ray_d, white_bg, ndc_ray, transfer_vel=True)
 
     def update_nvfi_kwargs(self, kwargs):
+        """models/nvfi.py:33-35 writes every checkpoint kwarg into the field's __dict__.  Same effect here, except that the two
+        entries the C-ABI descriptor caches on the host (aabb, gridSize) go through the buffer / update_stepSize."""
+        f = self.nvfi
         for k, v in kwargs.items():
-            self.nvfi.__dict__[k] = v
+            if k == "aabb":
+                f.aabb.copy_(torch.as_tensor(v).to(f.aabb.device))
+            elif k == "gridSize":
+                continue
+            elif k == "appearance_n_comp":
+                f.app_n_comp = v
+            elif k == "alphaMask_grid":
+                f.__dict__[k] = v
+            else:
+                setattr(f, k, v)
+        f.update_stepSize([int(g) for g in kwargs.get("gridSize", f.gridSize.tolist())])
 
     def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001, lr_init_velocity=0.001):
         return self.nvfi.get_optparam_groups(lr_init_spatialxyz, lr_init_network)

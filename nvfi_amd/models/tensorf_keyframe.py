@@ -467,8 +467,10 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         v = viewdirs.reshape(-1, 3).contiguous().float()
         N = q.shape[0]
         rgb = torch.empty(N, 3, device=q.device)
-        ws = torch.empty(4 * 80000 + 16 * N + 8192, dtype=torch.uint8, device=q.device)
         desc = self._desc()
+        nb = C.c_int64(0)
+        _lib.check(L.nvfi_app_workspace_bytes(C.byref(desc), C.c_int64(N), C.byref(nb)))
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=q.device)
         _lib.check(L.nvfi_app_at(C.byref(desc), C.c_int64(N), _lib.ptr(q), _lib.ptr(v), _lib.ptr(rgb), _lib.ptr(ws),
                                  C.c_int64(ws.numel()), _stream_ptr()))
         return rgb
@@ -517,17 +519,23 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         ov = self.__dict__.get("jitter_override")
         if ov is not None:       # tests: explicit per-ray jitter instead of a draw
             return ov.to(device).reshape(-1).float().contiguous()
-        ring = self.__dict__.setdefault("_jit_ring", [])
+        ring = self.__dict__.setdefault("_jit_ring", [])      # entries: [pinned buffer, event recorded after its last upload]
         idx = self.__dict__.get("_jit_idx", 0)
         if len(ring) < 4:
-            ring.append(torch.empty(max(R, 4096), 1).pin_memory())
-        buf = ring[idx % len(ring)]
-        if buf.shape[0] < R:
-            buf = ring[idx % len(ring)] = torch.empty(R, 1).pin_memory()
+            ring.append([torch.empty(max(R, 4096), 1).pin_memory(), None])
+        slot = ring[idx % len(ring)]
+        if slot[1] is not None:
+            slot[1].synchronize()      # the asynchronous copy that last read this buffer must have executed before it is rewritten
+        if slot[0].shape[0] < R:
+            slot[0] = torch.empty(R, 1).pin_memory()
         self.__dict__["_jit_idx"] = idx + 1
-        view = buf[:R]
+        view = slot[0][:R]
         torch.rand(R, 1, out=view)
-        return view.to(device, non_blocking=True).reshape(-1)
+        out = view.to(device, non_blocking=True).reshape(-1)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return out
 
     def _scratch(self, key, nbytes, device):
         """Reusable workspace for calls whose workspace does not have to outlive the call."""
@@ -628,8 +636,10 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         flat = dense_xyz.reshape(-1, 3).contiguous()
         N = flat.shape[0]
         alpha = torch.zeros(N, device=dev)
-        ws = self._scratch("alpha", 4 * 160000 + 16 * N + 8192, dev)
         desc = self._desc()
+        nb = C.c_int64(0)
+        _lib.check(L.nvfi_alpha_workspace_bytes(C.byref(desc), C.c_int64(N), C.byref(nb)))
+        ws = self._scratch("alpha", nb.value, dev)
         for t in (np.linspace(0, 59, 60) / 60):
             _lib.check(L.nvfi_compute_alpha(C.byref(desc), C.c_int64(N), _lib.ptr(flat), C.c_float(float(np.float32(t))), C.c_int(int(transfer)),
                                             C.c_float(self._step_host), C.c_int(1), _lib.ptr(alpha), _lib.ptr(ws), C.c_int64(ws.numel()), _stream_ptr()))

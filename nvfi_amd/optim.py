@@ -57,7 +57,8 @@ class Adam(torch.optim.Optimizer):
         cache = self.__dict__.setdefault("_tables", {})
         for key, items in batches.items():
             b1, b2, eps, step = key
-            sig = tuple(x for (p, g, st, lr) in items for x in (p.data_ptr(), g.data_ptr()))
+            # every pointer the table holds: a load_state_dict() (or the stride fix above) replaces exp_avg / exp_avg_sq tensors
+            sig = tuple(x for (p, g, st, lr) in items for x in (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
             ent = cache.get(key[:3])
             if ent is None or ent[0] != sig:
                 arr = (_lib.AdamTensor * len(items))()

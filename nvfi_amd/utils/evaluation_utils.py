@@ -29,12 +29,17 @@ def load_checkpoint(logdir, map_location="cpu"):
 
 def load_model_checkpoint(cfg, ckpt, device):
     """Rebuild NVFi at the saved aabb / gridSize / num_keyframes and load the weights (train_nvfi.py:372-392)."""
-    from ..models import NVFi, Renderer
+    from ..models import NVFi, Renderer, AlphaGridMask
     kw = ckpt["nvfi_kwarg"]
     cfg.nvfi.num_keyframes = kw["num_keyframes"]
-    nvfi = NVFi(cfg, device, kw["aabb"].to(device), kw["gridSize"], kw["near_far"])
-    nvfi.load_state_dict(ckpt["model_state_dict"], strict=False)
-    nvfi = nvfi.to(device)
+    # near / far come from the dataset section like the reference (:375); the checkpoint's kwargs then override attributes (:378)
+    near_far = [cfg.dataset.near, cfg.dataset.far] if "dataset" in cfg else kw["near_far"]
+    nvfi = NVFi(cfg, device, kw["aabb"].to(device), kw["gridSize"], near_far).to(device)
+    nvfi.update_nvfi_kwargs(kw)
+    sd = ckpt["model_state_dict"]
+    if "nvfi.alphaMask.alpha_aabb" in sd and "nvfi.alphaMask.alpha_volume" in sd:      # the occupancy mask is rebuilt first (:380-385)
+        nvfi.nvfi.alphaMask = AlphaGridMask(device, sd["nvfi.alphaMask.alpha_aabb"].to(device), sd["nvfi.alphaMask.alpha_volume"].to(device))
+    nvfi.load_state_dict(sd)            # strict: a missing or unexpected key is an error, as in the reference (:386)
     renderer = Renderer(nvfi, cfg.renderer.batch_size, cfg.renderer.test_batch_size, cfg.renderer.n_rays,
                         cfg.renderer.distance_scale, tensorf_sample=cfg.renderer.tensorf_sample, ndc=cfg.renderer.ndc) if "renderer" in cfg else None
     return nvfi, renderer

@@ -88,13 +88,14 @@ class FieldSpec:
         self.amask = None
 
     @staticmethod
-    def from_npz(path, shared=None):
-        z = np.load(path)
-        params = {k[len("sd:nvfi."):]: z[k] for k in z.files if k.startswith("sd:nvfi.")}
+    def from_npz(path, shared=None, prefix=""):
+        z = np.load(path) if isinstance(path, str) else path
+        ps, pm = prefix + "sd:nvfi.", prefix + "meta:"
+        params = {k[len(ps):]: z[k] for k in z.files if k.startswith(ps)}
         if shared is not None:
             for k, v in shared.p.items():
                 params.setdefault(k, v)
-        meta = {k[len("meta:"):]: z[k] for k in z.files if k.startswith("meta:")}
+        meta = {k[len(pm):]: z[k] for k in z.files if k.startswith(pm)}
         meta = {k: (v.item() if v.ndim == 0 else v) for k, v in meta.items()}
         return FieldSpec(params, meta)
 
@@ -144,7 +145,10 @@ class FieldSpec:
         for i, k in enumerate((0, 2, 4)):
             f.rW[i] = _p(self.p[f"renderModule.mlp.{k}.weight"])
             f.rb[i] = _p(self.p[f"renderModule.mlp.{k}.bias"])
-        for i, k in enumerate(VEL_KEYS):
+        has_vel = "vel_net.weight_net.1.weight" in self.p      # radiance-only fields (use_vel: False) carry no velocity nets
+        if not has_vel:
+            f.use_vel = 0
+        for i, k in enumerate(VEL_KEYS if has_vel else []):
             f.vW[i] = _p(self.p[f"vel_net.weight_net.{k}.weight"])
             f.vb[i] = _p(self.p[f"vel_net.weight_net.{k}.bias"])
             f.aW[i] = _p(self.p[f"vel_net.a_weight_net.{k}.weight"])
@@ -171,7 +175,7 @@ class FieldSpec:
         for i, k in enumerate((0, 2, 4)):
             G.rW[i] = _p(g[f"renderModule.mlp.{k}.weight"])
             G.rb[i] = _p(g[f"renderModule.mlp.{k}.bias"])
-        for i, k in enumerate(VEL_KEYS):
+        for i, k in enumerate(VEL_KEYS if "vel_net.weight_net.1.weight" in g else []):
             G.vW[i] = _p(g[f"vel_net.weight_net.{k}.weight"])
             G.vb[i] = _p(g[f"vel_net.weight_net.{k}.bias"])
             G.aW[i] = _p(g[f"vel_net.a_weight_net.{k}.weight"])

@@ -109,6 +109,39 @@ def test_checkpoint_round_trip(tmp_path):
     for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
     assert m2.nvfi.density_plane_space[0].is_contiguous(memory_format=torch.channels_last)
+    # with an occupancy mask: the loader rebuilds AlphaGridMask from the state_dict keys and loads STRICTLY (train_nvfi.py:380-386)
+    from nvfi_amd.models import AlphaGridMask
+    gs = [int(g) for g in meta["gridSize"]]
+    vol = (torch.rand(gs[2], gs[1], gs[0]) > 0.4).float()
+    model.nvfi.alphaMask = AlphaGridMask("cpu", model.nvfi.aabb, vol)
+    save_checkpoint(str(tmp_path), model, opt, epoch=13)
+    ck = load_checkpoint(str(tmp_path))
+    assert "nvfi.alphaMask.alpha_volume" in ck["model_state_dict"] and "alphaMask_grid" in ck["nvfi_kwarg"]
+    m3, _ = load_model_checkpoint(field_cfg(meta), ck, "cpu")
+    assert m3.nvfi.alphaMask is not None and torch.equal(m3.nvfi.alphaMask.alpha_volume.reshape(vol.shape), vol)
+    assert m3.nvfi.nSamples == model.nvfi.nSamples and m3.nvfi._aabb_host == model.nvfi._aabb_host
+    bad = dict(ck); bad["model_state_dict"] = dict(ck["model_state_dict"]); bad["model_state_dict"]["nvfi.bogus"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        load_model_checkpoint(field_cfg(meta), bad, "cpu")
+
+
+def test_camera_rays_match_reference(gold):
+    """f-2: Camera.get_ray_bundle against the reference's rays (models/camera.py:112-138) - the strided centre crop of the 800x800
+    camera that tests/golden/make_golden.py stored as `A:rays_o/d`, `B:rays_o/d` (and `nvfi_gen_rays` is tested against this
+    Camera on the GPU, so the device-side generator inherits the pin)."""
+    import bench
+    from nvfi_amd.models import Camera
+    full, stride, H = 800, 24, 16
+    focal = 0.5 * full / np.tan(0.5 * 0.6911112)
+    for kind, center in (("A", (0.0, 0.0, 0.0)), ("B", (0.0, 0.0, 3.0))):
+        pose = bench.pose_spherical(30.0, -30.0, 4.0)
+        pose[:3, 3] += torch.tensor(center)
+        cam = Camera(pose, full, full, focal, torch.zeros(1, 1, 3), 1.0, 8.0)
+        i0 = full // 2 - (H // 2) * stride
+        sl = slice(i0, i0 + H * stride, stride)
+        o = cam.rays.ray_origins[sl, sl].reshape(-1, 3).numpy()
+        d = cam.rays.ray_directions[sl, sl].reshape(-1, 3).numpy()
+        assert np.array_equal(o, gold[f"{kind}:rays_o"]) and np.array_equal(d, gold[f"{kind}:rays_d"]), kind
 
 
 def test_boundary_ray_types():

@@ -4,14 +4,15 @@ vectors captured from the reference and against the CPU oracle on the same seede
 Tolerances: BASELINE.json's contract is rgb/depth within 1e-4 relative of the PyTorch-CPU reference.
 Discrete decisions (weight > 1e-4 appearance mask, in-box tests) can flip for samples within
 rounding of a threshold; a flip moves a ray's colour by at most ~1e-4 absolute, so composited
-outputs are compared with rtol=1e-4 and atol=1e-4*max|ref| (stated per assert below).
+outputs are compared with a PURE rtol=1e-4 (+ the fp32 rounding floor of the composite); the rays that
+need the absolute threshold-flip band are counted and must stay below 0.5 % (helpers.assert_contract).
 """
 import numpy as np
 import pytest
 import torch
 
 from conftest import relerr
-from helpers import make_model, named_grads
+from helpers import make_model, named_grads, assert_contract
 
 pytestmark = pytest.mark.gpu
 KINDS = ["A", "B"]
@@ -84,10 +85,8 @@ def _render(model, meta, gold, kind, t, mode, white=None, transfer=False):
 def _check_maps(out, gold, key, counts=True):
     rgb, depth, acc, w = (x.detach().cpu().numpy() for x in out[:4])
     for name, got in (("rgb", rgb), ("depth", depth), ("acc", acc)):
-        ref = gold[f"{key}:{name}"]
-        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max(), err_msg=f"{key}:{name}")
-    refw = gold[f"{key}:weight"]
-    np.testing.assert_allclose(w, refw, rtol=2e-4, atol=2e-6, err_msg=f"{key}:weight")
+        assert_contract(got, gold[f"{key}:{name}"], name, label=f"hip {key}")
+    assert_contract(w, gold[f"{key}:weight"], "weight", rtol=2e-4, label=f"hip {key}")
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -171,8 +170,8 @@ def test_render_vs_oracle_bigger(fields, models, kind):
     loss.backward()
     ref = orc.render(fs, o, d, t, u=u, train=True, white_bg=True, keep_ctx=True)
     rgb = out[0].detach().cpu().numpy()
-    np.testing.assert_allclose(rgb, ref.rgb, rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(out[1].detach().cpu().numpy(), ref.depth, rtol=1e-4, atol=1e-4 * ref.depth.max())
+    assert_contract(rgb, ref.rgb, "rgb", label=f"hip vs oracle {kind} R=768")
+    assert_contract(out[1].detach().cpu().numpy(), ref.depth, "depth", label=f"hip vs oracle {kind} R=768")
     cnt = f.last_counters.cpu().numpy()
     assert abs(int(cnt[0]) - int(ref.counters[0])) <= 2 and abs(int(cnt[2]) - int(ref.counters[2])) <= 4
     gref = ref.backward(fs, g_rgb=2 * (ref.rgb - tg.cpu().numpy()) / (R * 3), g_depth=np.full(R, 0.01 / R, np.float32))
@@ -293,7 +292,7 @@ def test_mask_branch(gold, models):
     ref = gold["A:mask:map"]
     assert out[4].shape == ref.shape
     np.testing.assert_allclose(out[4].cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * ref.max())
-    np.testing.assert_allclose(out[0].cpu().numpy(), gold["A:render_nonkey:rgb"], rtol=1e-4, atol=1e-4)
+    assert_contract(out[0].cpu().numpy(), gold["A:render_nonkey:rgb"], "rgb", label="hip A:mask render")
 
 
 def test_sh_render(gold):
