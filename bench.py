@@ -7,8 +7,22 @@ on the synthetic 'bat' scene of BASELINE.md: a 2048-ray render at a random non-k
 collocation points, backward of all of it and the Adam step.  value = rays rendered per second
 (2 x 2048 per step per GPU), whole job.
 
-  python bench.py [--gpus N --steps K --warmup W --workload cfg3|cfg2]
+  python bench.py [--gpus N --steps K --warmup W --workload cfg3|cfg2 --mode fused|dropin --live --scaling weak|strong]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+The workload is STATIONARY by default: the optimiser step is executed in full every iteration, but on a shadow copy of the
+parameters (same tensors, same kernels, same bytes), so the field - and with it the number of valid / appearance-masked
+samples and of PDE points that survive the occupancy prefilter - is the BASELINE.md blob for every step, and a 3-step run
+measures the same thing as a 200-step run.  `--live` applies the updates to the field itself (training on random targets thickens
+the blob: the PDE kept set grows 34k -> 114k points within 20 steps, and the step time with it).
+
+`--mode fused` (default) is this repository's counterpart driver of the loop: gradients accumulated in place into ONE flat
+buffer, the regulariser value+gradient kernels, the one-launch Adam, the PDE term fused with its backward.
+`--mode dropin` is the reference's loop body verbatim on the `models` alias: plain autograd, torch.optim.Adam, torch-op
+regularisers, `if loss_vel > 0`, the `.item()` calls - what train_nvfi.py gets without touching it.
+
+The timed region carries no instrumentation.  The roofline figures come from a second, profiled pass over the same number of
+steps (HIP events around every launch of a kernel class, on the launch stream).
 """
 import argparse
 import ctypes as C
@@ -28,11 +42,11 @@ APP_FLOP = 64768           # 2*(48*32 + 110*128 + 128^2 + 128*3)
 PEAK_FP32_MFMA = 157.3     # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 PEAK_HBM_GBS = 8000.0      # GB/s, MI355X_MICROARCH.md (HBM3E)
 CLASSES = ["rk2_fwd", "rk2_bwd", "app_fwd", "app_bwd", "wgrad", "pde_fwd", "pde_bwd", "density_fwd", "density_bwd", "pde_prefilter", "density_scatter", "app_scatter", "other"]
+PROFILE_TAG = "r02"
 
 
 def bat_cfg(S=128, use_vel=True):
     from nvfi_amd.utils import CfgNode
-    import yaml
     # values of config/InDoorObj/bat.yaml that reach the hot path, restated
     n = dict(model_name="TensorVMKeyframeTimeKplane", density_n_comp=[24, 24, 24], appearance_n_comp=[48, 48, 48], app_dim=32,
              densityMode="Density", shadingMode="MLP_PE", alphaMask_thres=1e-4, rayMarch_weight_thres=1e-4, density_shift=-10,
@@ -77,17 +91,35 @@ def pose_spherical(theta, phi, radius):
     return torch.tensor(flip @ rt @ rp @ tr, dtype=torch.float32)
 
 
-def camera_bundle(device, H=800, W=800, angle_x=0.6911112):
+H_IMG = W_IMG = 800
+ANGLE_X = 0.6911112
+
+
+def camera_bundle(device, H=H_IMG, W=W_IMG, angle_x=ANGLE_X):
     from nvfi_amd.models import Camera
     focal = 0.5 * W / np.tan(0.5 * angle_x)
     cam = Camera(pose_spherical(30.0, -30.0, 4.0).to(device), H, W, focal, torch.zeros(1, 1, 3, device=device), 1.0, 8.0)
     return cam.rays.ray_origins.reshape(-1, 3).contiguous(), cam.rays.ray_directions.reshape(-1, 3).contiguous()
 
 
-class Step:
-    """One training iteration of the hot path (mirrors train_nvfi.py:139-249 with --static_dynamic)."""
+def _shadow_groups(groups):
+    """Optimiser groups over clones of the parameters whose .grad IS the real parameter's .grad tensor: the optimiser step does all
+    of its work (reads p, g, m, v; writes p, m, v) without moving the field that the next step renders."""
+    out, pairs = [], []
+    for g in groups:
+        ps = []
+        for p in g["params"]:
+            s = torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format))
+            pairs.append((p, s))
+            ps.append(s)
+        out.append({"params": ps, "lr": g["lr"]})
+    return out, pairs
 
-    def __init__(self, model, device, n_rays, n_pts, world, rank, workload):
+
+class Step:
+    """One training iteration of the hot path (mirrors train_nvfi.py:139-249 with --static_dynamic), optimised counterpart driver."""
+
+    def __init__(self, model, device, n_rays, n_pts, world, rank, workload, live=False):
         from nvfi_amd.models import Renderer
         from nvfi_amd.utils import TVLoss
         from nvfi_amd.dist import GradBucket
@@ -96,13 +128,19 @@ class Step:
         self.ren = Renderer(model, 0, 0, n_rays)
         self.tv = TVLoss()
         groups = model.get_optparam_groups(0.02, 1e-3)
+        groups = [dict(params=list(g["params"]), lr=g["lr"]) for g in groups]
+        self.bucket = GradBucket([p for g in groups for p in g["params"]])
+        opt_groups = groups
+        if not live:
+            opt_groups, pairs = _shadow_groups(groups)
+            for p, s in pairs:
+                s.grad = p.grad          # (p.grad may be None for parameters outside the bucket: frozen ones)
         if os.environ.get("NVFI_TORCH_ADAM"):    # A/B: PyTorch's own fused Adam
-            self.opt = torch.optim.Adam(groups, betas=(0.9, 0.99), fused=True)
+            self.opt = torch.optim.Adam(opt_groups, betas=(0.9, 0.99), fused=True)
         else:                                    # same update rule in one HIP launch (nvfi_adam_step); also clears the gradients
             from nvfi_amd.optim import Adam
-            self.opt = Adam(groups, betas=(0.9, 0.99))
+            self.opt = Adam(opt_groups, betas=(0.9, 0.99))
         self.fused_zero = not os.environ.get("NVFI_TORCH_ADAM")
-        self.bucket = GradBucket([p for g in self.opt.param_groups for p in g["params"]])
         self.o, self.d = camera_bundle(device)
         self.gen = torch.Generator(device=device); self.gen.manual_seed(233 + rank)
         self.rng = np.random.default_rng(233 + rank)
@@ -112,11 +150,16 @@ class Step:
         self.pde_counters = []
         self.stepped = False
         self.fused_regs = True
-        self.inplace = True
         from nvfi_amd.dist import PdeGradStage
         self.pde_stage = PdeGradStage(model.nvfi._pde_params()) if world > 1 else None
         self.tail_off = self.bucket.tail_offset(list(model.nvfi.vel.parameters())) if (world > 1 and model.nvfi.use_vel) else None
         model.nvfi.accumulate_grads_inplace = True   # .grad tensors are views of the GradBucket's flat buffer
+        # The PDE term and the two renders of an iteration are independent until their gradients meet in the flat buffer (every
+        # accumulation into it is atomic), so they are issued on three HIP streams: each chain's workgroups fill the CUs the others
+        # leave idle in their tails (most engine kernels run one 128-sample workgroup per CU: a grid of 1055 workgroups is 4.1 rounds).
+        self.streams = None
+        if world == 1 and workload == "cfg3" and os.environ.get("NVFI_OVERLAP", "1") != "0":
+            self.streams = [torch.cuda.Stream(device=device) for _ in range(2)]
 
     def rays(self):
         from nvfi_amd.models import Ray
@@ -125,7 +168,6 @@ class Step:
         return Ray(self.o[idx], self.d[idx], 1.0, 8.0), target
 
     def __call__(self):
-        from nvfi_amd.dist import pde_rank_weight
         m, f = self.m, self.m.nvfi
         if not m.training:
             m.train()
@@ -144,12 +186,13 @@ class Step:
             self.last_lv = m.get_vel_loss(self.n_pts)
             self.pde_counters.append(f.last_pde_counters)
             if self.world > 1:
-                self.pde_stage.commit(f.last_pde_n_kept)
+                self.pde_stage.commit_device(f.last_pde_out)
 
-        # One GPU: the PDE term goes first - its one host sync (kept count) then waits on nothing that is already queued, and the
-        # renders + backward + Adam that follow are launched without any host wait.  Several GPUs: it goes LAST, so that the
-        # all-reduce of the plane / render-MLP gradients (38 MB, final after the renders) runs underneath it.
+        # Several GPUs: the PDE term goes LAST, so that the all-reduce of the plane / render-MLP gradients (38 MB, final after the
+        # renders) runs underneath it.  One GPU: first (order is immaterial: no call on this path waits for the device).
         overlap = self.world > 1 and self.tail_off is not None
+        if self.streams is not None:
+            return self._step_streams()
         if self.workload == "cfg3" and not overlap:
             pde_term()
         if self.workload == "cfg3":
@@ -186,6 +229,135 @@ class Step:
             self.opt.step()
         for g in self.opt.param_groups:
             g["lr"] = g["lr"] * self.lr_factor
+        return loss
+
+
+    def _step_streams(self):
+        """Same iteration, three streams: PDE term | non-keyframe render (forward + backward) | keyframe render (forward + backward);
+        the regularisers and the optimiser step follow on the main stream once the three have joined."""
+        m, f = self.m, self.m.nvfi
+        main = torch.cuda.current_stream()
+        s_pde, s_r1 = self.streams
+        start = torch.cuda.Event(); start.record(main)
+        i = int(self.rng.integers(0, 46))
+        while i % 3 == 0:
+            i = int(self.rng.integers(0, 46))
+        t_key = 3 * int(self.rng.integers(0, 16)) / 60.0
+        with torch.cuda.stream(s_pde):
+            s_pde.wait_event(start)
+            self.vw *= self.lr_factor
+            m.vel_loss_weight = self.vw
+            self.last_lv = m.get_vel_loss(self.n_pts)
+            self.pde_counters.append(f.last_pde_counters)
+        with torch.cuda.stream(s_r1):
+            s_r1.wait_event(start)
+            rays, target = self.rays()
+            out = self.ren.render(i / 60.0, rays, white_background=True, mode="train")
+            c1 = f.last_counters
+            torch.nn.functional.mse_loss(out[0], target).backward()
+        rays, target = self.rays()
+        out = self.ren.render(t_key, rays, white_background=True, mode="train")
+        c2 = f.last_counters
+        loss = torch.nn.functional.mse_loss(out[0], target)
+        loss.backward()
+        self.counters += [c1, c2]
+        main.wait_stream(s_pde); main.wait_stream(s_r1)
+        self.L1w *= self.lr_factor; self.tvd *= self.lr_factor; self.tva *= self.lr_factor
+        self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
+        self.opt.step(zero_grad=True); self.stepped = True
+        for g in self.opt.param_groups:
+            g["lr"] = g["lr"] * self.lr_factor
+        return loss
+
+
+class DropinStep:
+    """The reference's loop body (train_nvfi.py:139-249, --static_dynamic) on the `models` alias package, unchanged in structure:
+    plain autograd through `renderer.render`, `nvfi.get_vel_loss` + `if loss_vel > 0`, the torch-op regularisers, torch.optim.Adam with
+    the reference's groups and betas, `optimizer.zero_grad(set_to_none=True)`, the per-iteration `.item()` calls and lr decay.
+    What is NOT mirrored is the dataset: the posed image is the synthetic camera, and the pixel batch is drawn on the device
+    (`Camera.sample_rays_device`, f-2) unless `host_rays` asks for the reference's per-iteration `Camera(...).sample_rays` on the host."""
+
+    def __init__(self, model, device, n_rays, n_pts, world, rank, workload, live=False, host_rays=False):
+        import models                      # the drop-in alias of the reference's package (INTEGRATION.md)
+        self.models = models
+        self.m, self.dev, self.n_rays, self.n_pts, self.world, self.workload = model, device, n_rays, n_pts, world, workload
+        self.ren = models.Renderer(model, 0, 0, n_rays)
+        from nvfi_amd.utils import TVLoss
+        self.tvreg = TVLoss()
+        self.groups = model.get_optparam_groups(0.02, 1e-3, 1e-3)
+        self.live = live
+        if live:
+            self.opt = torch.optim.Adam(self.groups, betas=(0.9, 0.99))
+        else:
+            sg, self.pairs = _shadow_groups([dict(params=list(g["params"]), lr=g["lr"]) for g in self.groups])
+            self.opt = torch.optim.Adam(sg, betas=(0.9, 0.99))
+        self.host_rays = host_rays
+        self.pose = pose_spherical(30.0, -30.0, 4.0).to("cpu" if host_rays else device)
+        self.focal = 0.5 * W_IMG / np.tan(0.5 * ANGLE_X)
+        self.target_img = torch.rand(H_IMG, W_IMG, 3, device="cpu" if host_rays else device)
+        self.gen = torch.Generator(device=device); self.gen.manual_seed(233 + rank)
+        self.rng = np.random.default_rng(233 + rank)
+        np.random.seed(233 + rank)
+        self.lr_factor = 0.1 ** (1 / 30000)
+        self.L1w, self.tvd, self.tva, self.vw = 8e-4, 1.0, 1.0, 1.0
+        self.counters, self.pde_counters = [], []
+        model.nvfi.accumulate_grads_inplace = False
+        model.vel_loss_weight = None
+
+    def batch(self):
+        cam = self.models.Camera(self.pose, H_IMG, W_IMG, self.focal, self.target_img, 1.0, 8.0)
+        if self.host_rays:
+            rays, target = cam.sample_rays(self.n_rays)
+            return rays.to(self.dev), target.to(self.dev)
+        rays, ids = cam.sample_rays_device(self.n_rays, generator=self.gen)
+        return rays, self.target_img.reshape(-1, 3)[ids]
+
+    def __call__(self):
+        nvfi, f = self.m, self.m.nvfi
+        nvfi.train(); self.ren.train()
+        loss = 0
+        if self.workload == "cfg3":
+            i = int(self.rng.integers(0, 46))
+            while i % 3 == 0:
+                i = int(self.rng.integers(0, 46))
+            rays, target = self.batch()
+            rgb_map = self.ren.render(i / 60.0, rays, white_background=True, mode="train")[0]
+            rgb_loss = torch.nn.functional.mse_loss(rgb_map[..., :3], target[..., :3])
+            loss = rgb_loss
+            rgb_loss_t = rgb_loss.item()                                 # train_nvfi.py:161
+            self.counters.append(f.last_counters)
+            t_key = 3 * int(self.rng.integers(0, 16)) / 60.0
+        else:
+            t_key = float(self.rng.integers(0, 46)) / 60.0
+        rays, target = self.batch()
+        rgb_map = self.ren.render(t_key, rays, white_background=True, mode="train")[0]
+        rgb_loss0 = torch.nn.functional.mse_loss(rgb_map[..., :3], target[..., :3])
+        loss = loss + 1.0 * rgb_loss0
+        self.counters.append(f.last_counters)
+        self.L1w *= self.lr_factor
+        loss = loss + self.L1w * f.density_L1()
+        self.tvd *= self.lr_factor
+        loss = loss + f.TV_loss_density(self.tvreg) * self.tvd
+        self.tva *= self.lr_factor
+        loss = loss + f.TV_loss_app(self.tvreg) * self.tva
+        if self.workload == "cfg3":
+            self.vw *= self.lr_factor
+            loss_vel = nvfi.get_vel_loss(self.n_pts)
+            self.pde_counters.append(f.last_pde_counters)
+            if loss_vel > 0:                                             # train_nvfi.py:233 (a device sync on a tensor)
+                loss = loss + self.vw * loss_vel
+        self.opt.zero_grad(set_to_none=True)
+        if not self.live:
+            for p, s in self.pairs:
+                p.grad = None
+        loss.backward()
+        if not self.live:
+            for p, s in self.pairs:
+                s.grad = p.grad
+        self.opt.step()
+        for g in self.opt.param_groups:
+            g["lr"] = g["lr"] * self.lr_factor
+        self.last_psnr = rgb_loss0.item()                                # train_nvfi.py:252
         return loss
 
 
@@ -236,16 +408,28 @@ def cpu_baseline(model, workload, seconds_hint=20):
                        + (f" x2 renders + PDE with P={P}" if workload == "cfg3" else "") + f", fwd+bwd, {n} reps")
 
 
+def _load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--mode", default="fused", choices=["fused", "dropin"])
+    ap.add_argument("--live", action="store_true", help="apply the optimiser updates to the field itself (non-stationary workload)")
+    ap.add_argument("--host-rays", action="store_true", help="dropin mode: rebuild the 800x800 Camera and np.random.choice the batch on the host, as the reference does")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="strong: the GLOBAL batch (rays, collocation points) is fixed and split over the ranks")
     ap.add_argument("--rays", type=int, default=2048)
     ap.add_argument("--pts", type=int, default=262144)
     ap.add_argument("--grid", type=int, default=199)
     ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the separate profiled pass (default: min(steps, 5); 0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -268,10 +452,18 @@ def main():
     from nvfi_amd import _lib
     L = _lib.lib()
 
+    n_rays, n_pts = args.rays, args.pts
+    if args.scaling == "strong":           # 256 rays and P/8 points per GPU at 8 GPUs
+        n_rays, n_pts = max(1, args.rays // world), max(128, args.pts // world)
     model = build_scene(device, args.grid, args.samples, use_vel=True)
     if args.workload == "cfg2":
         model.nvfi.use_vel = False
-    step = Step(model, device, args.rays, args.pts, world, rank, args.workload)
+    if args.mode == "dropin":
+        if world > 1:
+            raise SystemExit("--mode dropin is the single-process reference loop")
+        step = DropinStep(model, device, n_rays, n_pts, world, rank, args.workload, live=args.live, host_rays=args.host_rays)
+    else:
+        step = Step(model, device, n_rays, n_pts, world, rank, args.workload, live=args.live)
 
     def barrier():
         if world > 1:
@@ -280,73 +472,95 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    step.counters.clear(); step.pde_counters.clear()
     barrier()
-    L.nvfi_prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    ncls = L.nvfi_prof_nclasses()
-    tot = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)()
-    _lib.check(L.nvfi_prof_collect(tot, cnt))
-    L.nvfi_prof_enable(0)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
     renders = 2 if args.workload == "cfg3" else 1
-    rays_per_step = args.rays * renders * world
+    rays_per_step = n_rays * renders * world
     value = rays_per_step * args.steps / dt
 
-    # ---- roofline of the dominant kernel class (algorithmic MLP FLOPs / HIP-event time of that class)
-    c = torch.stack(step.counters).sum(0).cpu().numpy() if step.counters else np.zeros(8)
-    pc = torch.stack(step.pde_counters).sum(0).cpu().numpy() if step.pde_counters else np.zeros(8)
-    V_evals, M, kept, pre_evals = float(c[3]), float(c[2]), float(pc[4]), float(pc[3])
-    flops = {"rk2_fwd": V_evals * VEL_FLOP, "rk2_bwd": V_evals * VEL_FLOP, "app_fwd": M * APP_FLOP, "app_bwd": M * APP_FLOP,
-             "wgrad": V_evals * VEL_FLOP + M * APP_FLOP + kept * 6 * VEL_FLOP, "pde_fwd": kept * 6 * VEL_FLOP,
-             "pde_bwd": kept * 6 * VEL_FLOP, "pde_prefilter": pre_evals * VEL_FLOP}
-    times = {CLASSES[i]: (tot[i], cnt[i]) for i in range(min(ncls, len(CLASSES)))}
-    dom = max((k for k in flops if times.get(k, (0, 0))[1] > 0), key=lambda k: times[k][0], default=None)
-    roof = None
-    if dom:
-        ms, n = times[dom]
-        ach = flops[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic = None
-        try:   # HBM bytes per launch of that kernel class from the committed PMC passes (profiles/README.md)
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["bytes_per_launch"].get(dom)
-        except Exception:
-            pass
-        roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=PEAK_FP32_MFMA, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA,
-                    traffic=traffic, launches=int(n), avg_launch_ms=ms / max(n, 1), flop_per_launch=flops[dom] / max(n, 1),
-                    per_class_ms_per_step={k: times[k][0] / args.steps for k in times})
-
-    if args.workload == "cfg2":
-        # radiance-only: gather / scatter bound: algorithmic bytes per step = 6912 B per valid sample + 13824 B per
-        # appearance-masked sample (forward gathers + read-modify-write of the plane gradients, no reuse credit) + the per-ray
-        # inputs/outputs, over the WHOLE step time (the MLP contractions ride along); peak = 8 TB/s HBM3E
-        V = float(c[0])
-        nbytes = V * 6912.0 + M * 13824.0 + args.steps * renders * args.rays * (24.0 + (5.0 + args.samples) * 4.0)
-        gbs = nbytes / dt / 1e9
-        roof = dict(bound="hbm", kernel="whole step: plane gathers + plane-gradient scatters (k_density_q, k_og, k_tile_scatter, k_app_fwd gather)",
-                    achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=None,
-                    bytes_per_step=nbytes / args.steps, valid_samples_per_step=V / args.steps, masked_samples_per_step=M / args.steps,
-                    mfma=roof, per_class_ms_per_step={k: times[k][0] / args.steps for k in times})
-        if roof["mfma"]:
-            roof["mfma"].pop("per_class_ms_per_step", None)
+    # ---- profiled pass (outside the timed region): HIP events around every launch of a kernel class on the launch stream, and the
+    #      device-side work counters of those same steps
+    psteps = min(args.steps, 5) if args.profile_steps < 0 else args.profile_steps
+    roof, work = None, None
+    if psteps > 0:
+        step.counters.clear(); step.pde_counters.clear()
+        streams, step.streams = getattr(step, "streams", None), None     # serial: an event interval then brackets one kernel class only
+        torch.cuda.synchronize()
+        L.nvfi_prof_enable(1)       # (also drops a k_nvfi_prof_marker launch into a rocprofv3 trace: the per-kernel statistics under profiles/ are taken after it)
+        tp0 = time.perf_counter()
+        for _ in range(psteps):
+            step()
+        torch.cuda.synchronize()
+        tprof = (time.perf_counter() - tp0) / psteps
+        ncls = L.nvfi_prof_nclasses()
+        tot = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)()
+        _lib.check(L.nvfi_prof_collect(tot, cnt))
+        L.nvfi_prof_enable(0)
+        step.streams = streams
+        c = torch.stack(step.counters).sum(0).cpu().numpy() if step.counters else np.zeros(8)
+        pc = torch.stack(step.pde_counters).sum(0).cpu().numpy() if step.pde_counters else np.zeros(8)
+        V, Nw, M, E = float(c[0]), float(c[1]), float(c[2]), float(c[3])
+        kept, pre_evals = float(pc[4]), float(pc[3])
+        flops = {"rk2_fwd": E * VEL_FLOP, "rk2_bwd": E * VEL_FLOP, "app_fwd": M * APP_FLOP, "app_bwd": M * APP_FLOP,
+                 "wgrad": E * VEL_FLOP + M * APP_FLOP + kept * 6 * VEL_FLOP, "pde_fwd": kept * 6 * VEL_FLOP,
+                 "pde_bwd": kept * 6 * VEL_FLOP, "pde_prefilter": pre_evals * VEL_FLOP}
+        times = {CLASSES[i]: (tot[i], cnt[i]) for i in range(min(ncls, len(CLASSES)))}
+        # per step: what the kernels counted (V valid samples, N samples warped by RK2, M appearance-masked samples, E velocity-net
+        # evaluations of the render warp, P' collocation points kept by the occupancy prefilter, prefilter net evaluations)
+        work = dict(steps=psteps, V=V / psteps, N=Nw / psteps, M=M / psteps, E=E / psteps, P_kept=kept / psteps, prefilter_evals=pre_evals / psteps,
+                    gflop_per_step={k: v / psteps / 1e9 for k, v in flops.items()}, gflop_per_step_total=sum(flops.values()) / psteps / 1e9,
+                    ms_per_step_profiled_serial=tprof * 1e3,
+                    streams=("3 HIP streams in the timed region (PDE term | non-keyframe render | keyframe render); the profiled pass is issued on one stream"
+                             if streams is not None else "one stream"))
+        traffic_all = (_load_json(f"{PROFILE_TAG}_traffic.json") or {}).get("bytes_per_launch", {})
+        per_class = {}
+        for k, (ms, n) in times.items():
+            e = dict(ms_per_step=ms / psteps, launches_per_step=n / psteps)
+            if k in flops and ms > 0:
+                e["tflops"] = flops[k] / (ms * 1e-3) / 1e12
+                e["frac"] = e["tflops"] / PEAK_FP32_MFMA
+            per_class[k] = e
+        dom = max((k for k in flops if times.get(k, (0, 0))[1] > 0), key=lambda k: times[k][0], default=None)
+        if dom:
+            ms, n = times[dom]
+            ach = flops[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=PEAK_FP32_MFMA, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA,
+                        traffic=traffic_all.get(dom), traffic_source=f"static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/{PROFILE_TAG}_traffic.json (PMC counters cannot be read in-process)",
+                        launches=int(n), avg_launch_ms=ms / max(n, 1), flop_per_launch=flops[dom] / max(n, 1),
+                        whole_step=dict(tflops=sum(flops.values()) / psteps / (dt / args.steps) / 1e12,
+                                        frac=sum(flops.values()) / psteps / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA),
+                        per_class=per_class)
+        if args.workload == "cfg2":
+            # radiance-only: gather / scatter bound: algorithmic bytes per step = 6912 B per valid sample + 13824 B per
+            # appearance-masked sample (forward gathers + read-modify-write of the plane gradients, no reuse credit) + the per-ray
+            # inputs/outputs, over the WHOLE step time (the MLP contractions ride along); peak = 8 TB/s HBM3E
+            nbytes = (V * 6912.0 + M * 13824.0) / psteps + renders * n_rays * (24.0 + (5.0 + args.samples) * 4.0)
+            gbs = nbytes / (dt / args.steps) / 1e9
+            roof = dict(bound="hbm", kernel="whole step: plane gathers + plane-gradient scatters (k_density_q, k_og, k_tile_scatter, k_app_fwd gather)",
+                        achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=None,
+                        bytes_per_step=nbytes, mfma=roof)
 
     out = {
         "metric": "training rays/sec (fwd+bwd incl. PDE loss), 'bat' scene", "value": value, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("bat.yaml + velocity field + PDE divergence loss (configs[2]): 199^3 grid, K=16, 128 samples/ray, "
                                 "2 renders x 2048 rays + PDE on 262144 collocation points + plane regularisers + Adam, per GPU"
                                 if args.workload == "cfg3" else
                                 "bat.yaml radiance-only (configs[1]): 199^3 grid, 128 samples/ray, 2048-ray batches of the 800x800 frame"),
-                   "rays_per_step_per_gpu": args.rays * renders, "pde_points_per_gpu": args.pts if args.workload == "cfg3" else 0,
-                   "grid": args.grid, "samples_per_ray": args.samples, "parallelism": f"ray-sharded x{world}"},
+                   "rays_per_step_per_gpu": n_rays * renders, "pde_points_per_gpu": n_pts if args.workload == "cfg3" else 0,
+                   "grid": args.grid, "samples_per_ray": args.samples, "parallelism": f"ray-sharded x{world}",
+                   "driver": args.mode, "field": "live (updated by the optimiser)" if args.live else "stationary (optimiser steps a shadow copy)"},
+        "work_per_step": work,
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -354,6 +568,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, args.workload)
         except Exception as e:  # the baseline is a report, never a reason to lose the bench line
             out["cpu_baseline"] = {"error": repr(e)}
+        ref = _load_json(f"{PROFILE_TAG}_cpu_bridge.json")
+        if ref and "reference" in ref:      # the reference itself (PyTorch CPU) on that same sample, measured in the build container
+            out["reference_cpu"] = dict(ref["reference"], host=ref.get("host"), oracle_on_that_host=ref.get("oracle", {}).get("value"),
+                                        source=f"profiles/{PROFILE_TAG}_cpu_bridge.json (tools/cpu_bridge.py; /root/reference cannot run on the GPU box)")
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

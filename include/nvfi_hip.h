@@ -6,7 +6,9 @@
  * interface it replaces.  Plain pointers and sizes only: every pointer below is a DEVICE pointer
  * unless stated, `stream` is a hipStream_t passed as void*, the caller owns every buffer, nothing
  * is allocated inside (workspace sizes are queried first).  All calls are asynchronous on
- * `stream`.  Return value: 0 = ok, otherwise an error code; nvfi_last_error() gives the text.
+ * `stream` - none of them waits for the device - with three documented exceptions that hand a value back to the host:
+ * nvfi_pde_loss_ex when `host_info` is non-NULL, nvfi_prof_collect and nvfi_selftest.
+ * Return value: 0 = ok, otherwise an error code; nvfi_last_error() gives the text.
  *
  * Layouts: factor planes are CHANNEL-LAST, [H][W][C] fp32 (the physical layout of a torch
  * (1,C,H,W) tensor in torch.channels_last); Linear weights are (out,in) row-major as in torch.
@@ -104,8 +106,10 @@ int nvfi_pde_loss(const nvfi_field_desc* f, int64_t P, const float* points, cons
                   void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream);
 
 /* same, with optional diagnostics: kept (device uint8[P]), jac (device float[n_jac][6][4], rows 3..5 zero: the loss
- * does not use the acceleration Jacobian) for the first n_jac kept points; host_info (HOST int64[2], optional) receives the kept
- * count and the number of prefilter net evaluations, which the call knows after its one internal synchronisation */
+ * does not use the acceleration Jacobian) for the first n_jac kept points; host_info (HOST int64[2], optional): the kept count and
+ * the number of prefilter net evaluations - asking for it makes the call synchronise `stream` once (the reference's
+ * `if xyzt.shape[0] == 0`, nvfi.py:66, is the same wait); with host_info == NULL the call is asynchronous: the kept count never
+ * leaves the device (out[1], counters[4]) and the Jacobian / adjoint passes size themselves from it. */
 int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float* points, const float* t,
                      float loss_scale, float* out, const nvfi_grads* grads,
                      void* workspace, int64_t workspace_bytes, int64_t* counters,

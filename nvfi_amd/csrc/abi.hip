@@ -227,7 +227,10 @@ void prof_end(int cls, hipStream_t st) {
     (void)hipEventRecord(e, st);
     g_ev[cls].push_back({g_open[cls], e});
 }
+// marks the start of a profiled pass in a rocprofv3 kernel trace (tools/rocpd_stats.py summarises the launches after the last marker)
+__global__ void k_nvfi_prof_marker(int on) { (void)on; }
 extern "C" int nvfi_prof_enable(int on) {
+    if (on) { hipLaunchKernelGGL(k_nvfi_prof_marker, dim3(1), dim3(64), 0, 0, on); (void)hipStreamSynchronize(0); }
     g_prof = on;
     for (int c = 0; c < PK_COUNT; ++c) { for (auto& p : g_ev[c]) { g_pool.push_back(p.first); g_pool.push_back(p.second); } g_ev[c].clear(); }
     return 0;

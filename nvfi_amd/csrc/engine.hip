@@ -229,8 +229,9 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(ReduceJobs jobs) {
             if (o >= 0 && o < J.out) {
                 if (pB >= 0) {
                     const int in = slot_logical(J.slot_kind, pB);
-                    if (in >= 0 && in < J.in && J.gW) J.gW[(size_t)o * J.in + in] += J.scale * s;
-                } else if (J.gb) J.gb[o] += J.scale * s;
+                    // atomic: launches on different streams (the two renders and the PDE term of a step) may accumulate into the same gradient
+                    if (in >= 0 && in < J.in && J.gW) atomicAdd(&J.gW[(size_t)o * J.in + in], J.scale * s);
+                } else if (J.gb) atomicAdd(&J.gb[o], J.scale * s);
             }
         }
     }

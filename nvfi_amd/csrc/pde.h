@@ -3,7 +3,7 @@
 #include "common.h"
 
 #define PDE_MAX_CLASS 64           // RK2 step-count buckets
-#define PDE_CHUNK 131072           // kept points processed per pass (bounds the stash: 42 KB per point -> 5.5 GB; sized for 288 GB of HBM)
+#define PDE_CHUNK 262144           // kept points processed per pass (bounds the stash: 42 KB per point -> 11 GB of address space, touched only up to the kept count; sized for 288 GB of HBM)
 #ifndef PDE_NSLAB
 #define PDE_NSLAB 128
 #endif
@@ -30,9 +30,9 @@ struct PdePrepArgs {
 struct PdeJetArgs {
     VelFrags Wv, Wa;
     const float4* qorig; const int* klist;
-    int64_t first; int count; int64_t cap; int wgs;
+    int64_t first; const int* kcount; int64_t cap; int wgs;     // kcount: DEVICE count of kept points; this pass handles [first, first + cap)
     float* stash; float* seeds; float* wout; double* sums;
-    float inv_n, scale;
+    float scale;
     float* jac; int64_t n_jac;
 };
 

@@ -388,6 +388,12 @@ __device__ __forceinline__ bool pde_tile_col(int ncol, int wgs, int& wg, int& co
     return wg < wgs;
 }
 
+// kept points of this pass: the launch grids are sized for the worst case (every candidate kept) and workgroups beyond the
+// device-side count leave at once - the host never learns the count, so the call needs no synchronisation
+__device__ __forceinline__ int pde_pass_count(const PdeJetArgs& a) {
+    const int64_t c = (int64_t)(*a.kcount) - a.first;
+    return c <= 0 ? 0 : (c > a.cap ? (int)a.cap : (int)c);
+}
 // K1: value forward of weight_net (y=0) and a_weight_net (y=1)
 __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_fwd(PdeJetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -395,9 +401,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_fwd(PdeJetArgs a) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
     int wg, ycol;
     if (!pde_tile_col(2, a.wgs, wg, ycol)) return;
+    const int count = pde_pass_count(a);
+    if (wg * WG_SAMPLES >= count) return;
     const int tile = wg * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
-    const bool active = i < a.count;
+    const bool active = i < count;
     float4 q = active ? a.qorig[a.klist[a.first + i]] : zero4();
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
     float o4[4], w[6];
@@ -416,6 +424,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_fwd(PdeJetArgs a)
     const int lane = threadIdx.x & 63, h = lane >> 5;
     int wg, j;
     if (!pde_tile_col(4, a.wgs, wg, j)) return;
+    if (wg * WG_SAMPLES >= pde_pass_count(a)) return;
     const int tile = wg * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
@@ -439,10 +448,14 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_fwd(PdeJetArgs a)
 __global__ __launch_bounds__(256) void k_pde_seeds(PdeJetArgs a) {
     __shared__ float red[8];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool active = i < a.count;
+    const int count = pde_pass_count(a);
+    if ((int)(blockIdx.x * 256) >= count) return;
+    const bool active = i < count;
     const size_t cs = a.cap;
+    const int capc = (count + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES;   // the jet workgroups cover whole 128-point groups
+    const float inv_n = 1.f / (float)(*a.kcount);
     float sd = 0.f, st = 0.f;
-    if (i < a.cap) {
+    if (i < capc) {
         float w[6], wd[4][6], aw[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -471,10 +484,10 @@ __global__ __launch_bounds__(256) void k_pde_seeds(PdeJetArgs a) {
         float* sp = a.seeds + i;
         if (active) {
             sd = div * div; st = tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2];
-            const float gdiv = a.scale * 10.f * div * a.inv_n;
+            const float gdiv = a.scale * 10.f * div * inv_n;
             float gtr[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) gtr[c] = a.scale * 0.2f * tr[c] * a.inv_n / 3.f;
+            for (int c = 0; c < 3; ++c) gtr[c] = a.scale * 0.2f * tr[c] * inv_n / 3.f;
             float gJ[3][4], gv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -527,6 +540,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_bwd(PdeJetArgs a)
     const int lane = threadIdx.x & 63, h = lane >> 5;
     int wg, j;
     if (!pde_tile_col(5, a.wgs, wg, j)) return;
+    if (wg * WG_SAMPLES >= pde_pass_count(a)) return;
     const int tile = wg * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
@@ -551,6 +565,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_bwd(PdeJetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
     const int lane = threadIdx.x & 63, h = lane >> 5;
+    if ((int)(blockIdx.x * WG_SAMPLES) >= pde_pass_count(a)) return;
     const int tile = blockIdx.x * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
@@ -563,15 +578,26 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_bwd(PdeJetArgs a) {
     velnet_value_backward<1, true>(a.Wv, lds_w, lds_b, lane, r4, T + PDE_Z * REGF, T + PDE_CORR * REGF, T + PDE_GA * REGF);
 }
 
-// tiny helpers that replace host->device copies (no synchronisation on the launch stream)
-__global__ void k_set_i64x8(int64_t* c8, int* i1, int v1, int64_t c0, int64_t c1, int64_t c3, int64_t c4) {
+// tiny helpers that keep the bookkeeping on the device (no synchronisation on the launch stream)
+// per-pass sample count for k_wgrad (whole 128-point groups: the ragged rows of the last group are zero)
+__global__ void k_pde_pass_count(const int* kcount, int64_t first, int64_t cap, int* dcount) {
     if (threadIdx.x == 0) {
-        if (i1) *i1 = v1;
-        if (c8) { c8[0] = c0; c8[1] = c1; c8[2] = 0; c8[3] = c3; c8[4] = c4; c8[5] = c8[6] = c8[7] = 0; }
+        const int64_t c = (int64_t)(*kcount) - first;
+        const int n = c <= 0 ? 0 : (c > cap ? (int)cap : (int)c);
+        *dcount = (n + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES;
     }
 }
-__global__ void k_pde_finish(const double* sums, int64_t nk, float* out) {
+// counters[1] = candidates, [3] = prefilter net evaluations (2 per RK2 step, from the step-class histogram), [4] = kept points
+__global__ void k_pde_counters(const int* cls_count, const int* kcount, int64_t P, int64_t* c8) {
     if (threadIdx.x == 0) {
+        int64_t evals = 0;
+        for (int c = 0; c < PDE_MAX_CLASS; ++c) evals += 2ll * c * cls_count[c];
+        c8[0] = 0; c8[1] = P; c8[2] = 0; c8[3] = evals; c8[4] = *kcount; c8[5] = c8[6] = c8[7] = 0;
+    }
+}
+__global__ void k_pde_finish(const double* sums, const int* kcount, float* out) {
+    if (threadIdx.x == 0) {
+        const int64_t nk = *kcount;
         const double sd = sums[0], st = sums[1];
         out[0] = nk > 0 ? (float)(5.0 * sd / (double)nk + 0.1 * st / (3.0 * (double)nk)) : 0.f;
         out[1] = (float)nk; out[2] = (float)sd; out[3] = (float)st;
@@ -665,48 +691,47 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
     hipLaunchKernelGGL(k_pde_keep, dim3(pb), dim3(256), 0, st, *f, P, L.sig, L.flags, L.cnt);
     launch_scan_fill(L.cnt, L.off, nw, L.kcount, L.flags, L.klist, st);
     LAUNCHCK();
-    // host needs the kept count (the reference syncs here too: `if xyzt.shape[0] == 0`, nvfi.py:66)
-    int hcnt[PDE_MAX_CLASS + 16];
-    HIPCK(hipMemcpyAsync(hcnt, L.cls_count, sizeof(hcnt), hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
-    const int64_t nk = hcnt[PDE_MAX_CLASS];
-    int64_t evals = 0;
-    for (int c = 0; c < PDE_MAX_CLASS; ++c) evals += 2ll * c * hcnt[c];
-    if (host_info) { host_info[0] = nk; host_info[1] = evals; }   // known on the host already: callers need no second sync
+    // The kept count stays on the device (L.kcount): the jet passes are launched with worst-case grids and size themselves from it.
+    // Only a caller that asks for host_info (diagnostics; the Python mirror's `return 0.` decision, nvfi.py:66) pays a synchronisation.
+    if (host_info) {
+        int hcnt[PDE_MAX_CLASS + 16];
+        HIPCK(hipMemcpyAsync(hcnt, L.cls_count, sizeof(hcnt), hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        int64_t evals = 0;
+        for (int c = 0; c < PDE_MAX_CLASS; ++c) evals += 2ll * c * hcnt[c];
+        host_info[0] = hcnt[PDE_MAX_CLASS]; host_info[1] = evals;
+    }
     if (kept_out) HIPCK(hipMemcpyAsync(kept_out, L.flags, (size_t)P, hipMemcpyDeviceToDevice, st));
-    if (nk > 0) {
-        const float inv_n = 1.f / (float)nk;
-        for (int64_t first = 0; first < nk; first += L.chunk) {
-            const int64_t cnt = nk - first < L.chunk ? nk - first : L.chunk;
-            const int64_t cap = (cnt + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES;
-            PdeJetArgs ja; memset(&ja, 0, sizeof(ja));
-            ja.Wv = VW; ja.Wa = AW; ja.qorig = L.qorig; ja.klist = L.klist; ja.first = first; ja.count = (int)cnt; ja.cap = cap;
-            ja.stash = L.stash; ja.seeds = L.seeds; ja.sums = L.sums; ja.inv_n = inv_n; ja.scale = loss_scale; ja.jac = jac_out; ja.n_jac = n_jac;
-            const unsigned wgs = (unsigned)(cap / WG_SAMPLES);
-            ja.wgs = (int)wgs;
-            ja.wout = L.wout;
+    for (int64_t first = 0; first < P; first += L.chunk) {
+        const int64_t cap = P - first < L.chunk ? (P - first + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES : L.chunk;
+        PdeJetArgs ja; memset(&ja, 0, sizeof(ja));
+        ja.Wv = VW; ja.Wa = AW; ja.qorig = L.qorig; ja.klist = L.klist; ja.first = first; ja.kcount = L.kcount; ja.cap = cap;
+        ja.stash = L.stash; ja.seeds = L.seeds; ja.sums = L.sums; ja.scale = loss_scale; ja.jac = jac_out; ja.n_jac = n_jac;
+        const unsigned wgs = (unsigned)(cap / WG_SAMPLES);
+        ja.wgs = (int)wgs;
+        ja.wout = L.wout;
+        {
+            ProfScope ps(PK_PDE_FWD, st);
+            hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+            hipLaunchKernelGGL(k_pde_tangent_fwd, PDE_GRID(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
+            hipLaunchKernelGGL(k_pde_seeds, dim3((unsigned)(cap / 256 + 1)), dim3(256), 0, st, ja);
+        }
+        if (grads) {
             {
-                ProfScope ps(PK_PDE_FWD, st);
-                hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
-                hipLaunchKernelGGL(k_pde_tangent_fwd, PDE_GRID(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
-                hipLaunchKernelGGL(k_pde_seeds, dim3((unsigned)(cap / 256 + 1)), dim3(256), 0, st, ja);
-            }
-            if (grads) {
-                {
-                    ProfScope ps(PK_PDE_BWD, st);
-                    hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
-                    hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
-                }
-                LAUNCHCK();
-                if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, st)) return 1;
+                ProfScope ps(PK_PDE_BWD, st);
+                hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
+                hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
             }
             LAUNCHCK();
+            hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, st, L.kcount, first, cap, L.dcount);
+            if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, st)) return 1;
         }
+        LAUNCHCK();
     }
-    hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, nk, out);
+    hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, L.kcount, out);
     LAUNCHCK();
     if (counters) {
-        hipLaunchKernelGGL(k_set_i64x8, dim3(1), dim3(64), 0, st, counters, (int*)nullptr, 0, (int64_t)0, (int64_t)P, evals, nk);
+        hipLaunchKernelGGL(k_pde_counters, dim3(1), dim3(64), 0, st, L.cls_count, L.kcount, P, counters);
         LAUNCHCK();
     }
     return 0;
@@ -721,8 +746,7 @@ extern "C" int nvfi_pde_loss(const nvfi_field_desc* f, int64_t P, const float* p
 int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st) {
     const size_t ts = (size_t)PDE_TILE_ROWS * REGF;
     const size_t slab = (size_t)PDE_NSLAB * (128 * 128 + 128);
-    // k_wgrad reads the sample count from device memory (set by a one-thread kernel: no host sync)
-    hipLaunchKernelGGL(k_set_i64x8, dim3(1), dim3(64), 0, st, (int64_t*)nullptr, dcount, ntiles * TILE, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0);
+    // k_wgrad reads the sample count from device memory (dcount, set by k_pde_pass_count: no host sync); ntiles is the capacity
     WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
     for (int net = 0; net < 2; ++net)
         for (int l = 0; l < 6; ++l) {

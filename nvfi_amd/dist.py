@@ -108,11 +108,16 @@ class PdeGradStage:
     def zero(self):
         self.flat.zero_()
 
+    def commit_device(self, pde_out):
+        """Same as commit(), with the local kept count taken from the device (pde_out[1] of nvfi_pde_loss): no host value needed."""
+        self.commit(pde_out[1:2].detach())
+
     def commit(self, n_kept_local):
         """p.grad += flat_view * (W * n_r / sum_r n_r)"""
         w = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            n = torch.tensor([float(n_kept_local)], dtype=torch.float32, device=self.flat.device)
+            n = (n_kept_local.to(torch.float32).reshape(1).clone() if isinstance(n_kept_local, torch.Tensor)
+                 else torch.tensor([float(n_kept_local)], dtype=torch.float32, device=self.flat.device))
             tot = n.clone()
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             w = dist.get_world_size() * n / torch.clamp(tot, min=1.0)

@@ -51,9 +51,8 @@ class NVFi(nn.Module):
             t = torch.rand(int(n_pts), 1, device=f.aabb.device)
         if f.accumulate_grads_inplace and torch.is_grad_enabled() and getattr(self, "vel_loss_weight", None) is not None:
             # fused value + backward: gradients of vel_loss_weight * loss go straight into .grad
+            # (sync-free: the value is a 0-dim tensor, 0.0 when no point is occupied - the reference's python `0.` would need the count on the host)
             out = f.pde_loss_backward_(points, t, self.vel_loss_weight, getattr(self, "vel_grad_targets", None))
-            if f.last_pde_n_kept == 0:
-                return 0.
             return out[0]
         loss = f.pde_loss(points, t)
         if f.last_pde_n_kept == 0:   # known on the host from the call's one internal sync (`xyzt.shape[0] == 0` in the reference)

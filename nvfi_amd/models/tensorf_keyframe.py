@@ -505,12 +505,12 @@ class TensorVMKeyframeTimeKplane(nn.Module):
                 grads.append(p.grad)
         G = self._grads_struct_vel(grads)
         counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=points.device)
-        info = (C.c_int64 * 2)()
+        # no host_info: the call does not wait for the device; the kept count is out[1] / counters[4] (device side)
         _lib.check(L.nvfi_pde_loss_ex(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(float(weight)), _lib.ptr(out),
-                                      C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), None, None, C.c_int64(0), info,
+                                      C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), None, None, C.c_int64(0), None,
                                       _stream_ptr()))
         self.last_pde_out, self.last_pde_counters = out, counters
-        self.last_pde_n_kept = int(info[0])     # host value: no extra synchronisation to decide "nothing occupied"
+        self.last_pde_n_kept = None
         return out
 
     def _jitter(self, R, device):
