@@ -184,6 +184,9 @@ int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const float* xyz_wor
 /* Camera.get_ray_bundle + pixel selection (models/camera.py:112-138,159-172): pose (device float[12], row-major 3x4 c2w),
  * pixel ids (device int64[n], row-major y*W+x) -> rays_o (n,3), rays_d (n,3) */
 int nvfi_gen_rays(const float* pose3x4, int H, int W, float focal, int64_t n, const int64_t* pixel_ids, float* rays_o, float* rays_d, void* stream);
+/* The hand-rolled primitives the MLP engine uses instead of libm (engine.h: one-exp2/one-rcp sigmoid, Cody-Waite sin/cos), evaluated
+ * element-wise so that tests can bound their error against float64: kind 0 sigmoid, 1 sin, 2 cos, 3 SiLU, 4 SiLU', 5 SiLU''. */
+int nvfi_debug_act(int kind, int64_t n, const float* x, float* y, void* stream);
 /* MFMA fragment-layout self test: returns max abs error of a 128x128 fp32 layer against a VALU loop (host float*) */
 int nvfi_selftest(float* max_err_host, void* stream);
 

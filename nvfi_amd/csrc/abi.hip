@@ -204,6 +204,31 @@ extern "C" int nvfi_selftest(float* max_err_host, void* stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------- activation / encoding primitives, exposed for the ULP tests
+__global__ void k_debug_act(int kind, int64_t n, const float* __restrict__ x, float* __restrict__ y) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float r = 0.f, d1, d2;
+    switch (kind) {
+        case 0: r = fast_sigmoid(v); break;
+        case 1: r = trig_sel(v, 0); break;
+        case 2: r = trig_sel(v, 1); break;
+        case 3: r = act_f<1>(v); break;
+        case 4: r = act_d1<1>(v); break;
+        case 5: act_d12<1>(v, d1, d2); r = d2; break;
+        default: break;
+    }
+    y[i] = r;
+}
+extern "C" int nvfi_debug_act(int kind, int64_t n, const float* x, float* y, void* stream) {
+    if (n <= 0) return 0;
+    if (kind < 0 || kind > 5) return nvfi_fail(2, "nvfi_debug_act: kind %d outside 0..5", kind);
+    hipLaunchKernelGGL(k_debug_act, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind, n, x, y);
+    LAUNCHCK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- PDE entry points live in pde.hip
 
 // ---------------------------------------------------------------- per-kernel-class event timing

@@ -1,0 +1,118 @@
+"""Multi-process path on REAL kernels without a multi-GPU node: two ranks share the one GPU of the box (gloo carries the
+collectives; on the 8-GPU node the same code runs one rank per GPU over RCCL).  Each rank renders its ray shard and its shard of the
+collocation points with the HIP path, gradients land in the GradBucket / PdeGradStage exactly as in bench.py, and after the split
+all-reduce the averaged gradient must equal the single-process gradient of the union batch."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLD, ROOT
+from helpers import make_model, named_grads
+
+pytestmark = pytest.mark.gpu
+T = 19.0 / 60.0
+W_PDE = 0.7
+
+
+def _local_grads(model, o, d, u, tgt, pts, tt, bucket, stage, world):
+    """bench.Step's gradient path for one rank's shard: in-place accumulation into the bucket, PDE term through the stage."""
+    f = model.nvfi
+    f.train()
+    f.accumulate_grads_inplace = True
+    bucket.zero()
+    f.jitter_override = u
+    try:
+        out = f(T, o, d, True)
+    finally:
+        f.jitter_override = None
+    torch.nn.functional.mse_loss(out[0], tgt).backward()
+    tail = bucket.tail_offset(list(f.vel.parameters()))
+    h = bucket.all_reduce_head_start(tail)
+    stage.zero()
+    model.vel_loss_weight = W_PDE
+    model.vel_grad_targets = stage.views
+    model.get_vel_loss(points=pts, t=tt)
+    stage.commit_device(f.last_pde_out)
+    bucket.all_reduce_finish(h, tail)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nvfi_amd.dist import GradBucket, PdeGradStage, shard_range
+    gold = np.load(os.path.join(GOLD, "hotpath.npz"))
+    model, meta = make_model("A")
+    f = model.nvfi
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    R, P = gold["A:rays_o"].shape[0], gold["A:pde:points"].shape[0]
+    lo, hi = shard_range(R, rank, world)
+    plo, phi = shard_range(P, rank, world)
+    params = [p for g in model.get_optparam_groups() for p in g["params"]]
+    bucket = GradBucket(params)
+    stage = PdeGradStage(f._pde_params())
+    _local_grads(model, cu(gold["A:rays_o"][lo:hi]), cu(gold["A:rays_d"][lo:hi]), torch.from_numpy(gold["A:train_nonkey:u"][lo:hi].copy()),
+                 cu(gold["A:train_nonkey:target"][lo:hi]), cu(gold["A:pde:points"][plo:phi]), cu(gold["A:pde:t"][plo:phi]), bucket, stage, world)
+    torch.cuda.synchronize()
+    if rank == 0:
+        g = named_grads(model)
+        np.savez(out, **{k: v for k, v in g.items() if v is not None}, n_kept=float(f.last_pde_out[1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_union_batch(tmp_path):
+    out = str(tmp_path / "g2.npz")
+    port = 29600 + (os.getpid() % 1500)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    # single process, union batch (same kernels, plain autograd accumulation)
+    gold = np.load(os.path.join(GOLD, "hotpath.npz"))
+    model, meta = make_model("A")
+    f = model.nvfi
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    f.train()
+    f.jitter_override = torch.from_numpy(gold["A:train_nonkey:u"].copy())
+    try:
+        o = f(T, cu(gold["A:rays_o"]), cu(gold["A:rays_d"]), True)
+    finally:
+        f.jitter_override = None
+    loss = torch.nn.functional.mse_loss(o[0], cu(gold["A:train_nonkey:target"]))
+    lv = model.get_vel_loss(points=cu(gold["A:pde:points"]), t=cu(gold["A:pde:t"]))
+    (loss + W_PDE * lv).backward()
+    ref = named_grads(model)
+    n = 0
+    for k, r in ref.items():
+        if r is None or k == "basis_mat_density.weight":
+            continue
+        err = np.abs(got[k] - r).max() / (np.abs(r).max() + 1e-30)
+        assert err < 5e-4, (k, err)        # fp32 sums in a different order (shard-wise, atomics)
+        n += 1
+    assert n >= 40, n
+    assert 0 < float(got["n_kept"]) < int(f.last_pde_n_kept)      # rank 0 kept only its share of the points
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_runs_as_two_ranks(scaling):
+    """bench.py under torch.distributed.run with 2 ranks on the one GPU (NVFI_BENCH_BACKEND=gloo): the multi-rank branch of the step
+    (staged PDE gradients, split all-reduce, MAX-over-ranks timing) executes end to end and rank 0 prints one JSON line."""
+    env = dict(os.environ, NVFI_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = 29700 + (os.getpid() % 1500) + (1 if scaling == "strong" else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "64", "--pts", "16384", "--no-cpu-baseline", "--scaling", scaling]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    per_gpu = 4096 if scaling == "weak" else 2048
+    assert d["config"]["rays_per_step_per_gpu"] == per_gpu
+    assert d["work_per_step"]["P_kept"] > 0

@@ -121,3 +121,49 @@ def test_atomic_scatter_fallback_still_matches_goldens():
                         "-k", "test_render_train_grads or test_inplace_gradient_accumulation"], env=env, cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_fast_activation_and_trig_error_bounds():
+    """engine.h replaces libm on the hot path: `fast_sigmoid` (v_exp_f32 + v_rcp_f32) and `trig_sel` (3-constant Cody-Waite reduction +
+    minimax kernels).  Direct error bounds against float64 over the argument ranges the path produces: pre-activations |z| <= 40;
+    encoder arguments |a| <= 40 (render PE: |coordinate| <= 1.2 times 2^5; velocity encoder: times 2^2), checked out to 400."""
+    import ctypes as C
+    from nvfi_amd import _lib
+    L = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(kind, x):
+        xd = torch.from_numpy(x).cuda()
+        y = torch.empty_like(xd)
+        _lib.check(L.nvfi_debug_act(C.c_int(kind), C.c_int64(xd.numel()), _lib.ptr(xd), _lib.ptr(y), st))
+        return y.cpu().numpy().astype(np.float64)
+
+    rng = np.random.default_rng(0)
+    z = np.concatenate([rng.uniform(-40, 40, 1 << 20), rng.normal(0, 2, 1 << 20), np.linspace(-100, 100, 4001)]).astype(np.float32)
+    z64 = z.astype(np.float64)
+    s = 1.0 / (1.0 + np.exp(-z64))
+    got = run(0, z)
+    inr = np.abs(z64) <= 80.0           # beyond that exp(-z) overflows fp32 in the reference's own `1 / (1 + exp(-z))` as well: both give exactly 0
+    rel = np.abs(got[inr] - s[inr]) / s[inr]
+    print("fast_sigmoid max rel err (|z| <= 80)", rel.max(), "max abs err elsewhere", np.abs(got[~inr] - s[~inr]).max())
+    assert rel.max() < 1e-5             # ~2e-7 + |z| 6e-8 by construction (two ~1-ulp hardware ops); far inside the 1e-4 contract
+    assert np.abs(got[~inr] - s[~inr]).max() < 1e-30
+    for kind, ref in ((3, z64 * s), (4, s * (1 + z64 * (1 - s))), (5, s * (1 - s) * (2 + z64 * (1 - 2 * s)))):
+        got = run(kind, z)
+        # fp32 evaluation of s (1 + z (1 - s)) cancels near the zero of SiLU' (z = -1.28) whatever the sigmoid: the bound is a few ulp of
+        # the O(1) intermediates (absolute) + 1e-5 relative
+        # (and `1 - s` carries an absolute 6e-8 for z >~ 10, which SiLU'' multiplies by |2 - z|)
+        floor = 5e-7 if kind != 5 else 2e-6
+        err = np.abs(got - ref) / (1e-5 * np.abs(ref) + floor)
+        print("act kind", kind, "max err / (1e-5 |ref| + floor)", err.max())
+        assert err.max() < 1.0, (kind, err.max())
+    for lim, tol_ulp in ((40.0, 2.0), (400.0, 2.5)):
+        a = np.concatenate([rng.uniform(-lim, lim, 1 << 20), np.linspace(-lim, lim, 8001)]).astype(np.float32)
+        a64 = a.astype(np.float64)
+        for kind, ref in ((1, np.sin(a64)), (2, np.cos(a64))):
+            got = run(kind, a)
+            ulp = np.abs(got - ref) / np.spacing(np.maximum(np.abs(ref), 2.0 ** -24).astype(np.float32)).astype(np.float64)
+            abs_err = np.abs(got - ref)
+            print(f"trig_sel kind {kind} |a|<={lim}: max abs err {abs_err.max():.3e}, max ulp {ulp.max():.2f}")
+            assert abs_err.max() < 2.5e-7, (kind, lim, abs_err.max())       # absolute: what enters the MLP's first layer
+            assert np.percentile(ulp, 99.9) <= tol_ulp + 1.0, (kind, lim, np.percentile(ulp, 99.9))

@@ -133,3 +133,48 @@ def test_chessboard_pde_slice_matches_oracle(scene):
     gW = f.vel_net.weight_net[4][0].weight.grad.cpu().numpy()
     rW = ref["grads"]["vel_net.weight_net.4.0.weight"]
     assert np.abs(gW - rW).max() <= 2e-3 * np.abs(rW).max() + 1e-9
+
+
+def test_chessboard_final_resolution_slice(scene):
+    """configs[3] at the END of the shipped schedule: the 64^3 field upsampled to 199 x 199 x 200 (N_to_reso of 8e6 voxels in the
+    chessboard box, train_nvfi.py:99-112,343-347) -> 688 samples per ray.  A 64-ray train-mode slice (forward + backward through the
+    surround-box gate) against the oracle, and a 1024-ray eval chunk for the composite identities at 1.4 M samples per chunk."""
+    import copy
+    from oracle import oracle as orc
+    from nvfi_amd.utils import N_to_reso
+    model0, o, d = scene
+    model = copy.deepcopy(model0)
+    f = model.nvfi
+    f.vel_net._owner = __import__("weakref").ref(f)
+    reso = N_to_reso(7999998, f.aabb.cpu())      # last entry of the shipped voxel schedule (SURVEY A.9), evaluated on the host like the reference
+    assert list(reso) == [199, 199, 200], reso
+    f.upsample_volume_grid(reso, 4)
+    assert f.nSamples == 688, f.nSamples
+    fs = _field_spec(model)
+    orc.set_threads(8)
+    ro, rd = o[:64].contiguous(), d[:64].contiguous()
+    t = 22.0 / 60.0
+    f.train()
+    model.zero_grad(set_to_none=True)
+    u = torch.rand(64, 1)
+    f.jitter_override = u
+    try:
+        out = f(t, ro, rd, True)
+    finally:
+        f.jitter_override = None
+    tg = torch.rand(64, 3, device="cuda")
+    (torch.nn.functional.mse_loss(out[0], tg) + 0.01 * out[1].mean()).backward()
+    ref = orc.render(fs, ro.cpu().numpy(), rd.cpu().numpy(), t, u=u.numpy(), train=True, white_bg=True, keep_ctx=True)
+    for i, (nm, r) in enumerate((("rgb", ref.rgb), ("depth", ref.depth), ("acc", ref.acc))):
+        assert_contract(out[i].detach().cpu().numpy(), r, nm, label="hip chessboard 199x199x200 / 688")
+    gref = ref.backward(fs, g_rgb=2 * (ref.rgb - tg.cpu().numpy()) / (64 * 3), g_depth=np.full(64, 0.01 / 64, np.float32))
+    ref.free()
+    for pn, g in (("density_plane_space.0", f.density_plane_space[0].grad), ("app_plane_time.2", f.app_plane_time[2].grad),
+                  ("renderModule.mlp.2.weight", f.renderModule.mlp[2].weight.grad), ("vel_net.weight_net.3.0.weight", f.vel_net.weight_net[3][0].weight.grad)):
+        gr = gref[pn]
+        e = np.abs(g.cpu().numpy() - gr).max() / (np.abs(gr).max() + 1e-30)
+        assert e < 5e-4, (pn, e)
+    f.eval()
+    with torch.no_grad():
+        rgb, depth, acc, w, _ = f(40.0 / 60.0, o[:1024].contiguous(), d[:1024].contiguous(), False)
+    assert w.shape == (1024, 688) and torch.allclose(w.sum(-1), acc, rtol=1e-5, atol=1e-6) and torch.isfinite(depth).all()
