@@ -127,6 +127,12 @@ typedef struct nvfi_mask_desc {
 } nvfi_mask_desc;
 int nvfi_render_mask(const nvfi_field_desc* f, const nvfi_mask_desc* m, int64_t R, float t, int flags, const float* weights,
                      float* mask_map, void* workspace, int64_t workspace_bytes, void* stream);
+/* appearance-masked samples of the nvfi_render_fwd call that filled `workspace` (same f, R, t, flags): warped keyframe positions
+ * xyz_out (cap,3) and dense sample indices idx_out (cap) = ray * n_samples + sample; entries beyond counters[2] are left untouched.
+ * With it the host builds the train-mode (differentiable) mask branch of render_pts (models/tensorf_keyframe.py:749-753) from
+ * nvfi_maskfield_fwd / nvfi_maskfield_bwd: mask_map = sum_j weight_j * MaskField(xyz_j). */
+int nvfi_render_export_masked(const nvfi_field_desc* f, int64_t R, float t, int flags, void* workspace, int64_t workspace_bytes,
+                              int64_t cap, float* xyz_out, int64_t* idx_out, void* stream);
 /* ---- MaskField on free points, forward and backward: the model train_segm.py:126-227 optimises (models/mask_field.py:68-83;
  *      xyz (N,3) -> softmax mask (N,mask_dim)).  mode & NVFI_MASK_TRAIN keeps the activations in `workspace` for nvfi_maskfield_bwd, which
  *      ACCUMULATES d loss / d W_l, b_l (l = point_fc.0..3, mask_fc) from g_mask = d loss / d mask (N,mask_dim); the points carry

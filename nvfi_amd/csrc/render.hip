@@ -1413,6 +1413,32 @@ extern "C" int nvfi_render_mask(const nvfi_field_desc* f, const nvfi_mask_desc* 
     return 0;
 }
 
+// ---- appearance-masked samples of the call that filled `workspace`: warped keyframe position (xyz_out (M,3)) and dense sample index
+//      r * S + j (idx_out (M)); at most `cap` entries are written (the true count is counters[2] of nvfi_render_fwd).  Lets the host
+//      mirror build the DIFFERENTIABLE mask branch (tensorf_keyframe.py:749-753 in train mode) out of MaskField's own fwd/bwd kernels.
+__global__ void k_export_masked(const int* count, int64_t cap, const int* list, const float4* xw, float* xyz, int64_t* idx) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t n = *count < cap ? *count : cap;
+    if (i >= n) return;
+    const int s = list[i];
+    const float4 q = xw[s];
+    xyz[3 * i] = q.x; xyz[3 * i + 1] = q.y; xyz[3 * i + 2] = q.z;
+    idx[i] = s;
+}
+extern "C" int nvfi_render_export_masked(const nvfi_field_desc* f, int64_t R, float t, int flags, void* workspace, int64_t workspace_bytes,
+                                         int64_t cap, float* xyz_out, int64_t* idx_out, void* stream) {
+    if (check_desc(f)) return 2;
+    if (R <= 0 || cap <= 0) return 0;
+    float base, dts[MAX_RK_STEPS], tcs[MAX_RK_STEPS];
+    const int nsteps = rk_schedule(f, t, flags, &base, dts, tcs);
+    RenderPlan P;
+    plan_render(f, R, flags, nsteps < 0 ? 0 : nsteps, workspace, &P);
+    if (P.total > workspace_bytes) return nvfi_fail(4, "workspace too small");
+    hipLaunchKernelGGL(k_export_masked, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P.counters + 1, cap, P.mlist, P.xw, xyz_out, idx_out);
+    LAUNCHCK();
+    return 0;
+}
+
 // ================================================================ a-17 SHRender (degree 2 real SH, relu(sum + 0.5))
 __global__ void k_sh_render(int64_t N, const float* __restrict__ view, const float* __restrict__ ft, float* __restrict__ rgb) {
     const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;

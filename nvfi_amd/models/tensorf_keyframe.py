@@ -67,6 +67,7 @@ class _RenderFn(torch.autograd.Function):
                                      _lib.ptr(weights), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
         field.last_counters = counters
         field._last_ws = ws if (flags & _lib.NVFI_WANT_MASK) else None
+        field._last_call = (desc, R, t, flags)
         if flags & _lib.NVFI_TRAIN:
             ctx.field, ctx.t, ctx.flags, ctx.ws = field, t, flags, ws
             ctx.save_for_backward(rays_o, rays_d, weights, *params)
@@ -371,9 +372,35 @@ class TensorVMKeyframeTimeKplane(nn.Module):
                 rgb, depth, acc, weights, _ = _RenderFn.apply(self, t, ray_o, ray_d, jitter, flags, *params)
         if self.mask_field is None:
             mask_map = torch.zeros(R, 3, device=ray_o.device)
+        elif training and torch.is_grad_enabled():
+            mask_map = self._mask_map_train(R, weights)
         else:
             mask_map = self._mask_map(t, flags, R, weights)
         return rgb, depth, acc, weights, mask_map
+
+    def _mask_map_train(self, R, weights):
+        """Train-mode mask branch (tensorf_keyframe.py:673-676, 749-753), differentiable like the reference's: the appearance-masked
+        samples of the render call are exported (warped keyframe positions), MaskField runs through its own autograd boundary
+        (nvfi_maskfield_fwd / _bwd), and the composite sum_j w_j mask_j is a torch index_add - so gradients reach the MaskField
+        parameters and, through `weights`, the density branch of the field.  (The points themselves carry no gradient: MaskField's
+        kernels do not differentiate their input, as in train_segm.py where they are computed under no_grad.  No reference script
+        differentiates this branch: test_segm_render.py:96 renders in test mode.)"""
+        L = _lib.lib()
+        desc, R_, t, flags = self._last_call
+        M = int(self.last_counters[2])          # host value: sizes the export (the reference syncs here too: `if app_mask.any()`)
+        K = self.mask_field.mask_dim
+        dev = weights.device
+        if M == 0:
+            return weights.sum(-1, keepdim=True) * torch.zeros(1, K, device=dev)
+        xyz = torch.empty(M, 3, device=dev)
+        idx = torch.empty(M, dtype=torch.int64, device=dev)
+        ws = self._last_ws
+        _lib.check(L.nvfi_render_export_masked(C.byref(desc), C.c_int64(R), C.c_float(t), C.c_int(flags), _lib.ptr(ws), C.c_int64(ws.numel()),
+                                               C.c_int64(M), _lib.ptr(xyz), _lib.ptr(idx), _stream_ptr()))
+        mask = self.mask_field(xyz)
+        S = weights.shape[1]
+        w = weights.reshape(-1)[idx]
+        return torch.zeros(R, K, device=dev).index_add(0, idx // S, w[:, None] * mask)
 
     @torch.no_grad()
     def _mask_map(self, t, flags, R, weights):

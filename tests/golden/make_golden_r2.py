@@ -183,6 +183,37 @@ def main():
         for nm, v in zip(("rgb", "depth", "acc"), r[:3]):
             out[pre + f"up:render:{nm}"] = npf(v)
 
+    # ------------------------------------------------------------------ a-19 in TRAIN mode: the mask branch is differentiable
+    # (tensorf_keyframe.py:673-676, 749-753): gradients of a loss on mask_map w.r.t. the MaskField parameters and - through the
+    # weights - the density planes.  (vel_net also receives a gradient through the MaskField's input points in the reference; the
+    # HIP path does not differentiate MaskField inputs, so that family is recorded but not compared.)
+    from make_golden import build_field
+    cfgA, nvA = build_field(R, "A")
+    f = nvA.nvfi
+    torch.manual_seed(41)
+    f.mask_field = R["MaskField"](n_layer=4, n_dim=128, skips=[], mask_dim=8, input_dim=3, mask_act="softmax")
+    for k, v in f.mask_field.state_dict().items():
+        out["A:mask_train:sd:" + k] = npf(v)
+    o, d = camera_rays(R, "A")
+    f.train()
+    nvA.zero_grad(set_to_none=True)
+    g = torch.Generator().manual_seed(43)
+    gm = torch.rand(o.shape[0], 8, generator=g)
+    torch.manual_seed(21)
+    u = torch.rand(o.shape[0], 1)
+    torch.manual_seed(21)
+    r = f(19.0 / 60.0, o, d, True, False)
+    loss = (r[4] * gm).sum() + 0.5 * r[0].mean()
+    loss.backward()
+    out["A:mask_train:u"], out["A:mask_train:gm"] = npf(u), npf(gm)
+    out["A:mask_train:map"], out["A:mask_train:rgb"], out["A:mask_train:loss"] = npf(r[4]), npf(r[0]), npf(loss)
+    for k, p in f.mask_field.named_parameters():
+        out["A:mask_train:grad:mask_field." + k] = npf(p.grad)
+    for k in ("density_plane_space.0", "density_plane_time.1", "app_plane_space.2", "basis_mat.weight"):
+        pp = dict(f.named_parameters())[k]
+        out["A:mask_train:grad:" + k] = npf(pp.grad)
+    f.mask_field = None
+
     np.savez_compressed(os.path.join(HERE, "r2.npz"),
                         **{k: (v.astype(np.float32) if v.dtype == np.float64 and v.ndim > 0 else v) for k, v in out.items()})
     print("wrote", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "r2.npz")), "bytes")

@@ -436,3 +436,42 @@ def test_fused_adam_matches_torch():
         pa.grad = torch.ones_like(pa, memory_format=torch.preserve_format)
     oa.step()
     assert oa.state[ps_a[0]]["step"] == 8
+
+
+def test_mask_branch_train_gradients(gold, models):
+    """a-19 in train mode (tensorf_keyframe.py:673-676, 749-753): mask_map is differentiable.  Against reference goldens
+    (tests/golden/make_golden_r2.py): mask_map, and the gradients of  sum(mask_map * gm) + 0.5 mean(rgb)  w.r.t. every MaskField
+    parameter and - through the weights - the density / appearance planes."""
+    import os
+    from conftest import GOLD
+    from nvfi_amd.models import MaskField
+    g2 = np.load(os.path.join(GOLD, "r2.npz"))
+    model, meta = models["A"]
+    f = model.nvfi
+    mf = MaskField(n_layer=4, n_dim=128, skips=[], mask_dim=8).cuda()
+    mf.load_state_dict({k[len("A:mask_train:sd:"):]: torch.from_numpy(g2[k]) for k in g2.files if k.startswith("A:mask_train:sd:")})
+    f.mask_field = mf
+    f.train()
+    model.zero_grad(set_to_none=True)
+    try:
+        torch.manual_seed(21)
+        out = f(19.0 / 60.0, _cuda(gold["A:rays_o"]), _cuda(gold["A:rays_d"]), True, False)
+        loss = (out[4] * _cuda(g2["A:mask_train:gm"])).sum() + 0.5 * out[0].mean()
+        loss.backward()
+    finally:
+        f.mask_field = None
+    ref = g2["A:mask_train:map"]
+    np.testing.assert_allclose(out[4].detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * ref.max())
+    assert_contract(out[0].detach().cpu().numpy(), g2["A:mask_train:rgb"], "rgb", label="hip A:mask_train")
+    np.testing.assert_allclose(loss.item(), g2["A:mask_train:loss"].reshape(-1)[0], rtol=1e-4)
+    n = 0
+    for k, p in mf.named_parameters():
+        e = relerr(p.grad.cpu().numpy(), g2["A:mask_train:grad:mask_field." + k])
+        assert e < 5e-4, (k, e)
+        n += 1
+    assert n == 10
+    g = named_grads(model)
+    for k in ("density_plane_space.0", "density_plane_time.1", "app_plane_space.2", "basis_mat.weight"):
+        e = relerr(g[k], g2["A:mask_train:grad:" + k])
+        assert e < 5e-4, (k, e)
+    model.zero_grad(set_to_none=True)
