@@ -154,6 +154,11 @@ class Step:
         self.pde_stage = PdeGradStage(model.nvfi._pde_params()) if world > 1 else None
         self.tail_off = self.bucket.tail_offset(list(model.nvfi.vel.parameters())) if (world > 1 and model.nvfi.use_vel) else None
         model.nvfi.accumulate_grads_inplace = True   # .grad tensors are views of the GradBucket's flat buffer
+        # NVFI_ALLREDUCE=abi: the gradient exchange through nvfi_allreduce_grads (RCCL behind the C ABI) instead of torch.distributed
+        self.comm = None
+        if world > 1 and os.environ.get("NVFI_ALLREDUCE") == "abi":
+            from nvfi_amd.dist import RcclComm
+            self.comm = RcclComm()
         # The PDE term and the two renders of an iteration are independent until their gradients meet in the flat buffer (every
         # accumulation into it is atomic), so they are issued on three HIP streams: each chain's workgroups fill the CUs the others
         # leave idle in their tails (most engine kernels run one 128-sample workgroup per CU: a grid of 1055 workgroups is 4.1 rounds).
@@ -190,7 +195,7 @@ class Step:
 
         # Several GPUs: the PDE term goes LAST, so that the all-reduce of the plane / render-MLP gradients (38 MB, final after the
         # renders) runs underneath it.  One GPU: first (order is immaterial: no call on this path waits for the device).
-        overlap = self.world > 1 and self.tail_off is not None
+        overlap = self.world > 1 and self.tail_off is not None and self.comm is None
         if self.streams is not None:
             return self._step_streams()
         if self.workload == "cfg3" and not overlap:
@@ -222,7 +227,7 @@ class Step:
                 pde_term()
             self.bucket.all_reduce_finish(h, self.tail_off)
         else:
-            self.bucket.all_reduce_mean()
+            self.bucket.all_reduce_mean(self.comm)
         if self.fused_zero:
             self.opt.step(zero_grad=True); self.stepped = True
         else:

@@ -176,6 +176,16 @@ int nvfi_density_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, floa
 int nvfi_app_workspace_bytes(const nvfi_field_desc* f, int64_t N, int64_t* bytes);
 int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, const float* view, float* rgb,
                 void* workspace, int64_t workspace_bytes, void* stream);
+/* ---- multi-GPU: rays and collocation points shard over one process per GPU; the ONLY data-path exchange is the sum of the
+ *      flat fp32 gradient buffer (the reference has no distributed code: models/ is single-device).  RCCL over xGMI,
+ *      loaded lazily with dlopen.  Bootstrap: rank 0 gets a 128-byte id, the host program distributes it, every rank inits.
+ *      nvfi_allreduce_grads is in place and asynchronous on `stream`; average != 0 divides by the world size. */
+#define NVFI_UNIQUE_ID_BYTES 128
+typedef struct nvfi_comm nvfi_comm;
+int nvfi_comm_unique_id(void* id128_host);
+int nvfi_comm_init(nvfi_comm** comm, int world, int rank, const void* id128_host);
+int nvfi_allreduce_grads(nvfi_comm* comm, float* flat_grads, int64_t count, int average, void* stream);
+int nvfi_comm_destroy(nvfi_comm* comm);
 /* per-kernel-class HIP-event timing for bench.py: enable, run, collect (host arrays of nvfi_prof_nclasses() entries).
  * classes: 0 rk2_fwd 1 rk2_bwd 2 app_fwd 3 app_bwd 4 wgrad 5 pde_fwd 6 pde_bwd 7 density_fwd 8 density_bwd 9 pde_prefilter */
 int nvfi_prof_enable(int on);

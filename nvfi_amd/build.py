@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["engine.hip", "vel.hip", "render.hip", "scatter.hip", "mask.hip", "pde.hip", "regs.hip", "optim.hip", "abi.hip"]
+SOURCES = ["engine.hip", "vel.hip", "render.hip", "scatter.hip", "mask.hip", "pde.hip", "regs.hip", "optim.hip", "abi.hip", "comm.hip"]
 HEADERS = ["engine.h", "common.h", "vel.h", "render.h", "scatter.h", "pde.h", os.path.join("..", "..", "include", "nvfi_hip.h")]
 SO = os.environ.get("NVFI_BUILD_SO", os.path.join(CSRC, "libnvfi_hip.so"))   # experiments build a second library elsewhere
 OBJDIR = os.environ.get("NVFI_BUILD_OBJDIR", CSRC)
@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=4) as ex:
             list(ex.map(cc, todo))
     if todo or not os.path.exists(SO):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

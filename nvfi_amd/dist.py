@@ -11,6 +11,47 @@ import torch
 import torch.distributed as dist
 
 
+class RcclComm:
+    """RCCL communicator behind the C ABI (nvfi_comm_* / nvfi_allreduce_grads, include/nvfi_hip.h): the data-path collective without
+    torch.distributed in the loop.  Bootstrap only needs a way to ship 128 bytes from rank 0 to the others; here that is
+    torch.distributed's object broadcast when a process group exists (any backend), or a single process.
+
+    bench.py keeps torch.distributed's all_reduce (the same RCCL underneath) as its default exchange - the launcher contract hands the
+    rendezvous to torch.distributed anyway, and that path is the one exercised on the 8-GPU node; `NVFI_ALLREDUCE=abi` switches the
+    GradBucket to this communicator."""
+
+    def __init__(self, world=None, rank=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        L = _lib.lib()
+        have_pg = dist.is_available() and dist.is_initialized()
+        self.world = world if world is not None else (dist.get_world_size() if have_pg else 1)
+        self.rank = rank if rank is not None else (dist.get_rank() if have_pg else 0)
+        ident = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(L.nvfi_comm_unique_id(ident))
+        if self.world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_char * 128).from_buffer_copy(box[0])
+        self.handle = C.c_void_p()
+        _lib.check(L.nvfi_comm_init(C.byref(self.handle), C.c_int(self.world), C.c_int(self.rank), ident))
+
+    def all_reduce_(self, flat, average=True):
+        """in place, asynchronous on the current stream"""
+        C = self._C
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        self._lib.check(self._lib.lib().nvfi_allreduce_grads(self.handle, self._lib.ptr(flat), C.c_int64(flat.numel()), C.c_int(1 if average else 0),
+                                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return flat
+
+    def close(self):
+        if self.handle:
+            self._lib.lib().nvfi_comm_destroy(self.handle)
+            self.handle = None
+
+
 class GradBucket:
     """One flat fp32 buffer that backs every parameter's .grad (so the step has a single collective)."""
 
@@ -38,7 +79,10 @@ class GradBucket:
     def zero(self):
         self.flat.zero_()
 
-    def all_reduce_mean(self):
+    def all_reduce_mean(self, comm=None):
+        if comm is not None:        # RCCL through the C ABI (RcclComm)
+            comm.all_reduce_(self.flat, average=True)
+            return
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())

@@ -116,3 +116,25 @@ def test_bench_runs_as_two_ranks(scaling):
     per_gpu = 4096 if scaling == "weak" else 2048
     assert d["config"]["rays_per_step_per_gpu"] == per_gpu
     assert d["work_per_step"]["P_kept"] > 0
+
+
+def test_rccl_abi_allreduce_single_rank():
+    """nvfi_allreduce_grads over RCCL behind the C ABI.  A one-rank communicator on the one GPU of the box: unique id, init,
+    in-place sum and mean (identity for one rank), on a side stream, then destroy.  (Two ranks cannot share one device in a RCCL
+    communicator; N > 1 is the driver's 8-GPU run.)"""
+    from nvfi_amd.dist import RcclComm, GradBucket
+    comm = RcclComm(world=1, rank=0)
+    ps = [torch.nn.Parameter(torch.randn(1, 24, 9, 11, device="cuda").contiguous(memory_format=torch.channels_last)), torch.nn.Parameter(torch.randn(128, 28, device="cuda"))]
+    b = GradBucket(ps)
+    b.flat.copy_(torch.arange(b.flat.numel(), device="cuda", dtype=torch.float32))
+    ref = b.flat.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        b.all_reduce_mean(comm)
+        comm.all_reduce_(b.flat, average=False)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    assert torch.equal(b.flat, ref)
+    assert ps[1].grad.data_ptr() == b.flat[ps[0].numel():].data_ptr()
+    comm.close()
