@@ -155,6 +155,9 @@ int nvfi_sh_render(int64_t N, const float* view, const float* feat27, float* rgb
  *      gradient of  w_l1*L1 + w_tv_density*TVd + w_tv_app*TVa  is accumulated into grads->dps/dpt/aps. */
 int nvfi_plane_regs(const nvfi_field_desc* f, float w_l1, float w_tv_density, float w_tv_app, float* out3,
                     const nvfi_grads* grads, void* stream);
+/* same with the three weights read from DEVICE memory (float[3]): the autograd backward of `weight * field.density_L1()` receives its
+ * upstream gradient as a device scalar */
+int nvfi_plane_regs_dev(const nvfi_field_desc* f, const float* w3_dev, float* out3, const nvfi_grads* grads, void* stream);
 
 /* ---- outer optimiser step: torch.optim.Adam(betas, eps) without amsgrad / weight decay (train_nvfi.py:88-96, 243) over n_tensors
  *      parameter tensors in ONE launch.  `t` is a HOST array; p/g/m/v are device pointers (parameter, gradient, exp_avg, exp_avg_sq),

@@ -17,7 +17,7 @@ struct RegJob {
     float tv_w;         // TV weight (gradient scale multiplies the value scales)
     int tv_slot;        // 1: TV density, 2: TV app, 0: no TV
 };
-struct RegJobs { RegJob j[12]; int n; float* out; };
+struct RegJobs { RegJob j[12]; int n; float* out; const float* wdev; };   // wdev (optional): device float[3] multipliers of the (L1, TV density, TV app) gradients
 
 // One thread handles 4 consecutive channels of a texel (C is a multiple of 4, so they share x and y): 16-byte loads of the
 // texel and its four neighbours, 32-bit index arithmetic (the largest plane has 1.9 M elements).
@@ -27,6 +27,7 @@ __global__ __launch_bounds__(1024) void k_plane_regs(RegJobs jobs) {
     const int total4 = (J.H * J.W * J.C) >> 2;
     const int rowf = J.W * J.C;
     float l1 = 0.f, tv = 0.f;
+    const float m_l1 = jobs.wdev ? jobs.wdev[0] : 1.f, m_tv = (jobs.wdev && J.tv_slot) ? jobs.wdev[J.tv_slot] : 1.f;
     for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += gridDim.x * blockDim.x) {
         const int idx = i4 << 2;
         const int y = idx / rowf;
@@ -36,10 +37,10 @@ __global__ __launch_bounds__(1024) void k_plane_regs(RegJobs jobs) {
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         if (J.l1_mode == 1) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { l1 += fabsf(v[c]); g[c] += J.l1_grad * (v[c] > 0.f ? 1.f : (v[c] < 0.f ? -1.f : 0.f)); }
+            for (int c = 0; c < 4; ++c) { l1 += fabsf(v[c]); g[c] += m_l1 * J.l1_grad * (v[c] > 0.f ? 1.f : (v[c] < 0.f ? -1.f : 0.f)); }
         } else if (J.l1_mode == 2) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const float u = 1.f - v[c]; l1 += fabsf(u); g[c] -= J.l1_grad * (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)); }
+            for (int c = 0; c < 4; ++c) { const float u = 1.f - v[c]; l1 += fabsf(u); g[c] -= m_l1 * J.l1_grad * (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)); }
         }
         if (J.tv_slot) {
             float gh[4] = {0.f, 0.f, 0.f, 0.f}, gw[4] = {0.f, 0.f, 0.f, 0.f};
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(1024) void k_plane_regs(RegJobs jobs) {
                 for (int c = 0; c < 4; ++c) gw[c] += v[c] - n[c];
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) g[c] += J.tv_w * 2.f * (J.h_val * gh[c] + J.w_val * gw[c]);
+            for (int c = 0; c < 4; ++c) g[c] += m_tv * J.tv_w * 2.f * (J.h_val * gh[c] + J.w_val * gw[c]);
         }
         if (J.g) {
             float4 o = *reinterpret_cast<float4*>(J.g + idx);
@@ -87,10 +88,22 @@ __global__ __launch_bounds__(1024) void k_plane_regs(RegJobs jobs) {
     }
 }
 
+static int plane_regs(const nvfi_field_desc* f, float w_l1, float w_tv_density, float w_tv_app, const float* wdev, float* out3,
+                      const nvfi_grads* grads, void* stream);
 extern "C" int nvfi_plane_regs(const nvfi_field_desc* f, float w_l1, float w_tv_density, float w_tv_app, float* out3,
                                const nvfi_grads* grads, void* stream) {
+    return plane_regs(f, w_l1, w_tv_density, w_tv_app, nullptr, out3, grads, stream);
+}
+// weights in DEVICE memory (w3_dev: float[3]): the backward of `w * density_L1()` etc. under autograd hands over its upstream
+// gradient as a device scalar; reading it here avoids a host synchronisation
+extern "C" int nvfi_plane_regs_dev(const nvfi_field_desc* f, const float* w3_dev, float* out3, const nvfi_grads* grads, void* stream) {
+    if (!w3_dev) return nvfi_fail(2, "nvfi_plane_regs_dev: w3_dev is NULL");
+    return plane_regs(f, 1.f, 1.f, 1.f, w3_dev, out3, grads, stream);
+}
+static int plane_regs(const nvfi_field_desc* f, float w_l1, float w_tv_density, float w_tv_app, const float* wdev, float* out3,
+                      const nvfi_grads* grads, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    RegJobs jobs; jobs.n = 0; jobs.out = out3;
+    RegJobs jobs; jobs.n = 0; jobs.out = out3; jobs.wdev = wdev;
     HIPCK(hipMemsetAsync(out3, 0, 3 * sizeof(float), st));
     const int A[3] = {0, 0, 1}, Bx[3] = {1, 2, 2}, Cc[3] = {2, 1, 0};
     auto add = [&](const float* p, float* g, int H, int W, int C, int l1_mode, int tv_slot, float hmul, float tvw) {

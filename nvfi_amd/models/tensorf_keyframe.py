@@ -143,6 +143,49 @@ class _PdeFn(torch.autograd.Function):
         return (None, None, None) + tuple(g * gr for gr in ctx.saved_tensors)
 
 
+class _RegFn(torch.autograd.Function):
+    """`density_L1()` / `TV_loss_density(reg)` / `TV_loss_app(reg)` of the reference (tensorf_keyframe.py:188-231) as ONE pass over the
+    planes each (nvfi_plane_regs, regs.hip) instead of ~230 torch launches: forward = the value, backward = the gradient pass with the
+    upstream gradient taken from device memory (no host sync)."""
+
+    @staticmethod
+    def forward(ctx, field, which, *planes):
+        L = _lib.lib()
+        out = torch.empty(3, device=planes[0].device)
+        desc = field._desc()
+        _lib.check(L.nvfi_plane_regs(C.byref(desc), C.c_float(0.0), C.c_float(0.0), C.c_float(0.0), _lib.ptr(out), None, _stream_ptr()))
+        ctx.field, ctx.which = field, which
+        ctx.save_for_backward(*planes)
+        return out[which].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        field, which = ctx.field, ctx.which
+        planes = ctx.saved_tensors                      # the 9 regularised planes: dps[3], dpt[3], aps[3]
+        touched = (0, 1, 2, 3, 4, 5) if which < 2 else (6, 7, 8)
+        inplace = field.accumulate_grads_inplace
+        grads = [None] * 9
+        cur = field._render_params()[:9]
+        cur = cur[:3] + cur[3:6] + cur[6:9]
+        for k in touched:
+            if inplace:
+                if cur[k].grad is None:
+                    cur[k].grad = torch.zeros_like(cur[k])
+                grads[k] = cur[k].grad
+            else:
+                grads[k] = torch.zeros_like(planes[k])
+        G = field._grads_struct(grads + [None] * 22)
+        w3 = torch.zeros(3, device=g.device)
+        w3[which] = g
+        out = torch.empty(3, device=g.device)
+        desc = field._desc(list(planes) + field._render_params()[9:])
+        _lib.check(L.nvfi_plane_regs_dev(C.byref(desc), _lib.ptr(w3), _lib.ptr(out), C.byref(G), _stream_ptr()))
+        if inplace:
+            return (None, None) + (None,) * 9
+        return (None, None) + tuple(grads)
+
+
 class TensorVMKeyframeTimeKplane(nn.Module):
     def __init__(self, aabb, gridSize, device, near_far, cfg):
         super().__init__()
@@ -574,19 +617,32 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         return buf
 
     # ------------------------------------------------------------------ per-iteration regularisers (next-row f-1; torch ops)
+    def _reg_planes(self):
+        return list(self.density_plane_space) + list(self.density_plane_time) + list(self.app_plane_space)
+
+    def _reg_on_device(self, reg=None):
+        from ..utils.tensorf_utils import TVLoss
+        return self.aabb.is_cuda and not self.__dict__.get("regs_torch_ops", False) and self.density_n_comp[0] % 4 == 0 and self.app_n_comp[0] % 4 == 0 and (reg is None or type(reg) is TVLoss)
+
     def density_L1(self):
+        if self._reg_on_device():
+            return _RegFn.apply(self, 0, *self._reg_planes())
         total = 0
         for i in range(3):
             total = total + torch.mean(torch.abs(self.density_plane_space[i])) + torch.mean(torch.abs(1 - self.density_plane_time[i]))
         return total
 
     def TV_loss_density(self, reg):
+        if self._reg_on_device(reg):
+            return _RegFn.apply(self, 1, *self._reg_planes()) * reg.TVLoss_weight
         total = 0
         for i in range(3):
             total = total + reg(self.density_plane_space[i]) * 1e-2 + ((reg(self.density_plane_time[i], t=True) * 1e-2) if self.num_keyframes > 1 else 0)
         return total
 
     def TV_loss_app(self, reg):
+        if self._reg_on_device(reg):
+            return _RegFn.apply(self, 2, *self._reg_planes()) * reg.TVLoss_weight
         total = 0
         for i in range(3):
             total = total + reg(self.app_plane_space[i]) * 1e-2

@@ -221,9 +221,24 @@ def test_plane_regularisers(gold, models, kind):
     model.zero_grad(set_to_none=True)
     tv = TVLoss()
     w = (8e-4, 0.7, 1.3)
-    loss = w[0] * f.density_L1() + w[1] * f.TV_loss_density(tv) + w[2] * f.TV_loss_app(tv)
-    loss.backward()
+    f.regs_torch_ops = True        # the mirrored reference formulas as torch ops (independent of the kernel)
+    try:
+        vals_t = [f.density_L1(), f.TV_loss_density(tv), f.TV_loss_app(tv)]
+        (w[0] * vals_t[0] + w[1] * vals_t[1] + w[2] * vals_t[2]).backward()
+    finally:
+        f.regs_torch_ops = False
     ref = {k: v.copy() for k, v in named_grads(model).items() if v is not None}
+    model.zero_grad(set_to_none=True)
+    # the reference-signature methods run the same kernel behind autograd (value forward, gradient pass with a device-side weight)
+    vals = [f.density_L1(), f.TV_loss_density(tv), f.TV_loss_app(tv)]
+    assert all(v.requires_grad for v in vals)
+    (w[0] * vals[0] + w[1] * vals[1] + w[2] * vals[2]).backward()
+    for a, b in zip(vals, vals_t):
+        np.testing.assert_allclose(a.item(), b.item(), rtol=1e-5)
+    g = named_grads(model)
+    for k, r in ref.items():
+        if "plane" in k:
+            assert relerr(g[k], r) < 1e-5, k
     model.zero_grad(set_to_none=True)
     out = f.regularizers_backward_(*w).cpu().numpy()
     np.testing.assert_allclose(out[0], gold[f"{kind}:regs:L1"][0], rtol=1e-5)
