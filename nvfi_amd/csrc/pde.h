@@ -27,8 +27,16 @@ struct PdePrepArgs {
     int* cls; int* rank; int* cls_count;
 };
 
+// x4 fragment repack jobs (pde_jet.hip): four consecutive K steps of a lane side by side, so one 16-byte load feeds four MFMA steps
+struct X4Jobs { const float* src[12]; float* dst[12]; int MT[12]; int NS[12]; int n; };
+#define X4_FLOATS(MT, NS) ((MT) * (((NS) + 3) / 4) * 256)
+// v-net fragments in x4 order: forward f[0] (4 tiles x 14 steps), f[1..4] (4 x 64), f[5] (1 x 64); transposed t[1..4], t[5] (4 x 4)
+#define VEL_X4_FLOATS (X4_FLOATS(4, 14) + 4 * X4_FLOATS(4, 64) + X4_FLOATS(1, 64) + 4 * X4_FLOATS(4, 64) + X4_FLOATS(4, 4))
+
 struct PdeJetArgs {
     VelFrags Wv, Wa;
+    const float4* f4[6]; const float4* t4[6]; const float* bv[6];   // x4 fragments / bias fragments of weight_net (fused jet kernels)
+    int only_col;              // column kernels of pde.hip: >= 0 runs that single column (the acceleration net beside the fused kernels)
     const float4* qorig; const int* klist;
     int64_t first; const int* kcount; int64_t cap; int wgs;     // kcount: DEVICE count of kept points; this pass handles [first, first + cap)
     float* stash; float* seeds; float* wout; double* sums;
@@ -36,4 +44,13 @@ struct PdeJetArgs {
     float* jac; int64_t n_jac;
 };
 
+// kept points of this pass: the launch grids are sized for the worst case (every candidate kept) and workgroups beyond the
+// device-side count leave at once - the host never learns the count, so the call needs no synchronisation
+__device__ __forceinline__ int pde_pass_count_of(const PdeJetArgs& a) {
+    const int64_t c = (int64_t)(*a.kcount) - a.first;
+    return c <= 0 ? 0 : (c > a.cap ? (int)a.cap : (int)c);
+}
+int launch_frag_x4(const X4Jobs& jobs, hipStream_t st);
+int launch_pde_jet_fwd(const PdeJetArgs& a, unsigned tiles, hipStream_t st);
+int launch_pde_jet_bwd(const PdeJetArgs& a, unsigned tiles, hipStream_t st);
 int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st);

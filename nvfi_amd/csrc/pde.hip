@@ -11,6 +11,7 @@
 // tangent program (4 tangent-adjoint passes feeding a second-derivative correction into the
 // value-adjoint pass), and weight gradients are split-K MFMA over the stashed tiles (k_wgrad).
 // Points are bucketed by RK2 step count so workgroups of the prefilter are homogeneous.
+#include <stdlib.h>
 #include "common.h"
 #include "vel.h"
 #include "render.h"
@@ -388,19 +389,15 @@ __device__ __forceinline__ bool pde_tile_col(int ncol, int wgs, int& wg, int& co
     return wg < wgs;
 }
 
-// kept points of this pass: the launch grids are sized for the worst case (every candidate kept) and workgroups beyond the
-// device-side count leave at once - the host never learns the count, so the call needs no synchronisation
-__device__ __forceinline__ int pde_pass_count(const PdeJetArgs& a) {
-    const int64_t c = (int64_t)(*a.kcount) - a.first;
-    return c <= 0 ? 0 : (c > a.cap ? (int)a.cap : (int)c);
-}
+#define pde_pass_count pde_pass_count_of
 // K1: value forward of weight_net (y=0) and a_weight_net (y=1)
 __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_fwd(PdeJetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     int wg, ycol;
-    if (!pde_tile_col(2, a.wgs, wg, ycol)) return;
+    if (a.only_col >= 0) { if (!pde_tile_col(1, a.wgs, wg, ycol)) return; ycol = a.only_col; }
+    else if (!pde_tile_col(2, a.wgs, wg, ycol)) return;
     const int count = pde_pass_count(a);
     if (wg * WG_SAMPLES >= count) return;
     const int tile = wg * 4 + wave_id();
@@ -539,7 +536,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_bwd(PdeJetArgs a)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, h = lane >> 5;
     int wg, j;
-    if (!pde_tile_col(5, a.wgs, wg, j)) return;
+    if (a.only_col >= 0) { if (!pde_tile_col(1, a.wgs, wg, j)) return; j = a.only_col; }
+    else if (!pde_tile_col(5, a.wgs, wg, j)) return;
     if (wg * WG_SAMPLES >= pde_pass_count(a)) return;
     const int tile = wg * 4 + wave_id();
     const int i = tile * TILE + (lane & 31);
@@ -612,7 +610,7 @@ struct PdePlan {
     uint8_t* flags;
     float* sig;     // density at the warped points (prefilter)
     double* sums;
-    float *vel_frag, *a_frag, *stash, *seeds, *wout, *slabs;
+    float *vel_frag, *a_frag, *vel_x4, *stash, *seeds, *wout, *slabs;
     int64_t chunk, total;
 };
 static void plan_pde(int64_t P, void* ws, PdePlan* L) {
@@ -627,6 +625,7 @@ static void plan_pde(int64_t P, void* ws, PdePlan* L) {
     L->sums = B.take<double>(4);
     L->dcount = B.take<int>(16);
     L->vel_frag = B.take<float>(VEL_FRAG_FLOATS); L->a_frag = B.take<float>(VEL_FRAG_FLOATS);
+    L->vel_x4 = B.take<float>(VEL_X4_FLOATS);
     L->chunk = P < PDE_CHUNK ? (P + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES : PDE_CHUNK;
     L->stash = B.take<float>(L->chunk / TILE * (int64_t)PDE_TILE_ROWS * REGF);
     L->seeds = B.take<float>(36 * L->chunk);
@@ -669,6 +668,25 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
     if (pack_vel_frags(f->vW, f->vb, L.vel_frag, &VW, &jobs)) return 3;
     if (pack_vel_frags(f->aW, f->ab, L.a_frag, &AW, &jobs)) return 3;
     if (launch_pack(jobs, st)) return 1;
+    // fused jet kernels (pde_jet.hip; NVFI_PDE_JET=0 keeps the column kernels for every column): x4 copies of the v-net fragments
+    static int use_jet = -1;
+    if (use_jet < 0) { const char* e = getenv("NVFI_PDE_JET"); use_jet = e ? atoi(e) : 1; }
+    const float4* f4[6] = {nullptr}; const float4* t4[6] = {nullptr};
+    if (use_jet) {
+        X4Jobs xj; xj.n = 0;
+        float* p = L.vel_x4;
+        auto add = [&](const float* src, int MT, int NS, const float4** slot) {
+            xj.src[xj.n] = src; xj.dst[xj.n] = p; xj.MT[xj.n] = MT; xj.NS[xj.n] = NS; ++xj.n;
+            *slot = reinterpret_cast<const float4*>(p);
+            p += X4_FLOATS(MT, NS);
+        };
+        add(VW.f[0], 4, 14, &f4[0]);
+        for (int l = 1; l <= 4; ++l) add(VW.f[l], 4, 64, &f4[l]);
+        add(VW.f[5], 1, 64, &f4[5]);
+        for (int l = 1; l <= 4; ++l) add(VW.t[l], 4, 64, &t4[l]);
+        add(VW.t[5], 4, 4, &t4[5]);
+        if (launch_frag_x4(xj, st)) return 1;
+    }
     const unsigned pb = (unsigned)((P + 255) / 256);
     PdePrepArgs pa; pa.f = *f; pa.P = P; pa.points = points; pa.t = t; pa.qorig = L.qorig; pa.xw = L.xw; pa.pt_t = L.pt_t; pa.pt_base = L.pt_base;
     pa.cls = L.cls; pa.rank = L.rank; pa.cls_count = L.cls_count;
@@ -710,17 +728,34 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
         const unsigned wgs = (unsigned)(cap / WG_SAMPLES);
         ja.wgs = (int)wgs;
         ja.wout = L.wout;
+        ja.only_col = -1;
+        for (int l = 0; l < 6; ++l) { ja.f4[l] = f4[l]; ja.t4[l] = t4[l]; ja.bv[l] = VW.b[l]; }
         {
             ProfScope ps(PK_PDE_FWD, st);
-            hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
-            hipLaunchKernelGGL(k_pde_tangent_fwd, PDE_GRID(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
+            if (use_jet) {
+                // all five weight_net columns of a tile in one workgroup; the ReLU acceleration net keeps its column kernel
+                if (launch_pde_jet_fwd(ja, (unsigned)(cap / TILE), st)) return 1;
+                ja.only_col = 1;
+                hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 1), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                ja.only_col = -1;
+            } else {
+                hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                hipLaunchKernelGGL(k_pde_tangent_fwd, PDE_GRID(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
+            }
             hipLaunchKernelGGL(k_pde_seeds, dim3((unsigned)(cap / 256 + 1)), dim3(256), 0, st, ja);
         }
         if (grads) {
             {
                 ProfScope ps(PK_PDE_BWD, st);
-                hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
-                hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                if (use_jet) {
+                    if (launch_pde_jet_bwd(ja, (unsigned)(cap / TILE), st)) return 1;
+                    ja.only_col = 4;
+                    hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 1), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
+                    ja.only_col = -1;
+                } else {
+                    hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
+                    hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                }
             }
             LAUNCHCK();
             hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, st, L.kcount, first, cap, L.dcount);

@@ -67,7 +67,7 @@ class _RenderFn(torch.autograd.Function):
                                      _lib.ptr(weights), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
         field.last_counters = counters
         field._last_ws = ws if (flags & _lib.NVFI_WANT_MASK) else None
-        field._last_call = (desc, R, t, flags)
+        field._last_call = (R, t, flags)
         if flags & _lib.NVFI_TRAIN:
             ctx.field, ctx.t, ctx.flags, ctx.ws = field, t, flags, ws
             ctx.save_for_backward(rays_o, rays_d, weights, *params)
@@ -429,7 +429,8 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         kernels do not differentiate their input, as in train_segm.py where they are computed under no_grad.  No reference script
         differentiates this branch: test_segm_render.py:96 renders in test mode.)"""
         L = _lib.lib()
-        desc, R_, t, flags = self._last_call
+        R_, t, flags = self._last_call
+        desc = self._desc()
         M = int(self.last_counters[2])          # host value: sizes the export (the reference syncs here too: `if app_mask.any()`)
         K = self.mask_field.mask_dim
         dev = weights.device

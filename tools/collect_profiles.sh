@@ -1,25 +1,36 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 passes of bench.py, summarised into gpurun_out/<tag>_*.
-# usage: tools/collect_profiles.sh <tag>      (e.g. r01)
+# usage: tools/collect_profiles.sh <tag>      (e.g. r02)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_k /tmp/prof_f /tmp/prof_w /tmp/prof_s
-# 1. kernel trace of the default bench run (side stream as shipped)
+# 0. plain bench lines (no profiler attached): default (with the CPU baseline), other drivers / workloads
+python $REPO/bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_line.err
+python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_line_3steps.json 2>/dev/null
+python $REPO/bench.py --steps 100 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_line_100steps.json 2>/dev/null
+NVFI_OVERLAP=0 python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_line_one_stream.json 2>/dev/null
+python $REPO/bench.py --live --no-cpu-baseline > $OUT/${TAG}_bench_line_live.json 2>/dev/null
+python $REPO/bench.py --mode dropin --no-cpu-baseline > $OUT/${TAG}_bench_line_dropin.json 2>/dev/null
+python $REPO/bench.py --workload cfg2 --no-cpu-baseline > $OUT/${TAG}_bench_line_cfg2.json 2>/dev/null
+# 1. kernel trace of the default bench command: per-kernel statistics of the whole run and of the profiled pass (after the marker)
 rocprofv3 --kernel-trace -d /tmp/prof_k -- python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1
 grep -a "^{" $OUT/${TAG}_prof.log > $OUT/${TAG}_bench_line_rocprof.json
 DB=$(find /tmp/prof_k -name "*.db" | head -1)
-python $REPO/tools/rocpd_stats.py $DB $OUT/${TAG}_kernel_stats.csv > /dev/null
+python $REPO/tools/rocpd_stats.py $DB $OUT/${TAG}_kernel_stats_whole_run.csv > /dev/null
+python $REPO/tools/rocpd_stats.py $DB $OUT/${TAG}_kernel_stats.csv --after-marker > /dev/null
 python $REPO/tools/timeline.py $DB $OUT/${TAG}_timeline.csv > /dev/null
-# 2./3. HBM traffic: separate counter passes (kernel trace only)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+# 2./3. HBM traffic: separate counter passes (kernel trace only); counter collection serialises the dispatches
+B="python $REPO/bench.py --steps 3 --warmup 1 --prime 1 --profile-steps 0 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -- $B > /dev/null 2>&1
 python $REPO/tools/pmc_summary.py $(find /tmp/prof_f -name "*.db" | head -1) $OUT/${TAG}_pmc_fetch_size.csv > /dev/null
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -- $B > /dev/null 2>&1
 python $REPO/tools/pmc_summary.py $(find /tmp/prof_w -name "*.db" | head -1) $OUT/${TAG}_pmc_write_size.csv > /dev/null
 # 4. SQ counters (MFMA utilisation, waits)
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -d /tmp/prof_s -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -d /tmp/prof_s -- $B > /dev/null 2>&1
 python $REPO/tools/pmc_summary.py $(find /tmp/prof_s -name "*.db" | head -1) $OUT/${TAG}_pmc_sq.csv > /dev/null
+python $REPO/tools/make_traffic.py $OUT/${TAG}_pmc_fetch_size.csv $OUT/${TAG}_pmc_write_size.csv $OUT/${TAG}_traffic.json "bench.py --steps 3 --warmup 1" > /dev/null
 ls -la $OUT | grep ${TAG}_

@@ -5,7 +5,7 @@ sample of the bench step - the synthetic bat scene of bench.py (199^3, K=16, 128
 and t=0.30, train mode, fwd+bwd) + get_vel_loss on P=32768 collocation points (fwd+bwd) - so that the `cpu_baseline` the
 bench reports from the GPU box's host (oracle) can be related to the reference itself.
 
-    python tools/cpu_bridge.py            # prints one JSON object; copy it into BASELINE notes / DESIGN.md
+    python tools/cpu_bridge.py profiles/r02_cpu_bridge.json      # prints one JSON object and writes it (bench.py quotes it as "reference_cpu")
 """
 import json
 import os
@@ -24,7 +24,12 @@ def main():
     threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
     model = bench.build_scene("cpu")                       # our module is only a parameter container here
-    out = {"host_threads": threads}
+    cpu = "unknown"
+    try:
+        cpu = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except Exception:
+        pass
+    out = {"host_threads": threads, "host": f"build container: {threads} vCPU, {cpu}, torch {torch.__version__} (CPU kernels)"}
     # --- oracle (same function bench.py uses on the GPU box)
     out["oracle"] = bench.cpu_baseline(model, "cfg3", seconds_hint=40)
     # --- the reference itself on the same field
@@ -37,7 +42,9 @@ def main():
     cfg.nvfi.max_n_samples = 128
     cfg.nvfi.step_ratio = float(model.nvfi.step_ratio)
     aabb = torch.tensor([[-2.0, -2.0, -2.0], [2.0, 2.0, 2.0]])
-    ref = R["NVFi"](cfg, "cpu", aabb, [199, 199, 199], [1.0, 8.0])
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):      # the reference prints its configuration
+        ref = R["NVFi"](cfg, "cpu", aabb, [199, 199, 199], [1.0, 8.0])
     sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
     missing = ref.load_state_dict(sd, strict=False)
     assert ref.nvfi.nSamples == 128, ref.nvfi.nSamples
@@ -67,7 +74,10 @@ def main():
                             sample=f"vLAR-group/NVFi on torch {torch.__version__} CPU x{threads}: {Rr} rays per render x2 renders + get_vel_loss(P={P}), fwd+bwd, {n} reps",
                             state_dict_missing=len(missing.missing_keys), state_dict_unexpected=len(missing.unexpected_keys))
     out["oracle_over_reference"] = out["oracle"]["value"] / out["reference"]["value"]
-    print(json.dumps(out, indent=1))
+    txt = json.dumps(out, indent=1)
+    if len(sys.argv) > 1:
+        open(sys.argv[1], "w").write(txt + "\n")
+    print(txt)
 
 
 if __name__ == "__main__":
