@@ -435,7 +435,7 @@ def main():
     ap.add_argument("--grid", type=int, default=199)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the separate profiled pass (default: min(steps, 5); 0: none)")
-    ap.add_argument("--prime", type=int, default=4, help="setup iterations before the W warm-up steps (first-touch of the workspaces, allocator pools of the three streams, clocks): the first ~5 iterations of a process run 5-10 %% slower than steady state")
+    ap.add_argument("--prime", type=int, default=8, help="setup iterations before the W warm-up steps (first-touch of the workspaces, allocator pools of the three streams, clocks): the first ~5 iterations of a process run 5-10 %% slower than steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

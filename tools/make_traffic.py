@@ -11,8 +11,8 @@ CLASSES = {
     "pde_prefilter": ["void k_rk2_fwd<false, false>"],
     "rk2_fwd": ["void k_rk2_fwd<true, true>"],
     "rk2_bwd": ["k_rk2_bwd"],
-    "pde_bwd": ["k_pde_tangent_bwd", "k_pde_value_bwd"],
-    "pde_fwd": ["k_pde_value_fwd", "k_pde_tangent_fwd"],
+    "pde_bwd": ["k_pde_jet_bwd", "k_pde_tangent_bwd", "k_pde_value_bwd"],
+    "pde_fwd": ["k_pde_jet_fwd", "k_pde_value_fwd", "k_pde_tangent_fwd"],
     "app_fwd": ["void k_app_fwd<true>"],
     "app_bwd": ["k_app_bwd"],
     "density_fwd": ["k_density_q"],
