@@ -36,6 +36,7 @@ struct X4Jobs { const float* src[12]; float* dst[12]; int MT[12]; int NS[12]; in
 struct PdeJetArgs {
     VelFrags Wv, Wa;
     const float4* f4[6]; const float4* t4[6]; const float* bv[6];   // x4 fragments / bias fragments of weight_net (fused jet kernels)
+    int jet_tiles;             // fused jet launches: workgroups [0, jet_tiles) are jet tiles, the rest the acceleration net's column
     int only_col;              // column kernels of pde.hip: >= 0 runs that single column (the acceleration net beside the fused kernels)
     const float4* qorig; const int* klist;
     int64_t first; const int* kcount; int64_t cap; int wgs;     // kcount: DEVICE count of kept points; this pass handles [first, first + cap)
@@ -51,6 +52,52 @@ __device__ __forceinline__ int pde_pass_count_of(const PdeJetArgs& a) {
     return c <= 0 ? 0 : (c > a.cap ? (int)a.cap : (int)c);
 }
 int launch_frag_x4(const X4Jobs& jobs, hipStream_t st);
-int launch_pde_jet_fwd(const PdeJetArgs& a, unsigned tiles, hipStream_t st);
-int launch_pde_jet_bwd(const PdeJetArgs& a, unsigned tiles, hipStream_t st);
+// tiles: capacity in 32-point tiles (five weight_net columns each); anet_wgs: capacity in 128-point workgroups of the acceleration net
+int launch_pde_jet_fwd(const PdeJetArgs& a, unsigned tiles, unsigned anet_wgs, hipStream_t st);
+int launch_pde_jet_bwd(const PdeJetArgs& a, unsigned tiles, unsigned anet_wgs, hipStream_t st);
+
+// value adjoint with the correction term; no input gradient needed
+template <int ACT, bool CORR>
+__device__ __forceinline__ void velnet_value_backward(const VelFrags& W, float* lds_w, float* lds_b, int lane, const float* seed4,
+                                                      const float* zst, const float* corr, float* gst) {
+    float g[64];
+    f32x16 acc[4];
+    g[0] = seed4[0]; g[1] = seed4[1]; g[2] = seed4[2]; g[3] = seed4[3];
+    {
+        float* gw_rows = gst + (size_t)5 * 64 * REGF;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
+    }
+    __syncthreads();
+    stage_frag(lds_w, lds_b, W.t[5], VEL_T5, nullptr, 0);
+    __syncthreads();
+    acc_init<4>(acc, lds_b, 0, false);
+    layer_mfma<4, 4>(lds_w, lane, g, acc);
+#pragma unroll 1
+    for (int l = 4; l >= 0; --l) {
+        const float* zl = zst + (size_t)l * 64 * REGF;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int s = 16 * m + r;
+                float v = act_d1<ACT>(zl[s * REGF + lane]) * acc[m][r];
+                if (CORR) {
+                    const float* c0 = corr + (size_t)l * 64 * REGF + s * REGF + lane;
+                    v += (c0[0] + c0[(size_t)320 * REGF]) + (c0[(size_t)640 * REGF] + c0[(size_t)960 * REGF]);
+                }
+                g[s] = v;
+            }
+        stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
+        if (l >= 1) {
+            __syncthreads();
+            stage_frag(lds_w, lds_b, W.t[l], VEL_FH, nullptr, 0);
+            __syncthreads();
+            acc_init<4>(acc, lds_b, 0, false);
+            layer_mfma<4, 64>(lds_w, lane, g, acc);
+        }
+    }
+}
+
+
 int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st);

@@ -195,49 +195,6 @@ __device__ __forceinline__ void velnet_tangent_backward(const VelFrags& W, float
         }
     }
 }
-// value adjoint with the correction term; no input gradient needed
-template <int ACT, bool CORR>
-__device__ __forceinline__ void velnet_value_backward(const VelFrags& W, float* lds_w, float* lds_b, int lane, const float* seed4,
-                                                      const float* zst, const float* corr, float* gst) {
-    float g[64];
-    f32x16 acc[4];
-    g[0] = seed4[0]; g[1] = seed4[1]; g[2] = seed4[2]; g[3] = seed4[3];
-    {
-        float* gw_rows = gst + (size_t)5 * 64 * REGF;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
-    }
-    __syncthreads();
-    stage_frag(lds_w, lds_b, W.t[5], VEL_T5, nullptr, 0);
-    __syncthreads();
-    acc_init<4>(acc, lds_b, 0, false);
-    layer_mfma<4, 4>(lds_w, lane, g, acc);
-#pragma unroll 1
-    for (int l = 4; l >= 0; --l) {
-        const float* zl = zst + (size_t)l * 64 * REGF;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int s = 16 * m + r;
-                float v = act_d1<ACT>(zl[s * REGF + lane]) * acc[m][r];
-                if (CORR) {
-                    const float* c0 = corr + (size_t)l * 64 * REGF + s * REGF + lane;
-                    v += (c0[0] + c0[(size_t)320 * REGF]) + (c0[(size_t)640 * REGF] + c0[(size_t)960 * REGF]);
-                }
-                g[s] = v;
-            }
-        stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
-        if (l >= 1) {
-            __syncthreads();
-            stage_frag(lds_w, lds_b, W.t[l], VEL_FH, nullptr, 0);
-            __syncthreads();
-            acc_init<4>(acc, lds_b, 0, false);
-            layer_mfma<4, 64>(lds_w, lane, g, acc);
-        }
-    }
-}
-
 // Pipelined forms (engine.h: FragPipe - one workgroup per CU, next fragment and next epilogue's stash rows in flight behind
 // the MFMAs).  On entry the pipe's current buffer holds W.t[5].
 template <int ACT>
@@ -734,10 +691,8 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
             ProfScope ps(PK_PDE_FWD, st);
             if (use_jet) {
                 // all five weight_net columns of a tile in one workgroup; the ReLU acceleration net keeps its column kernel
-                if (launch_pde_jet_fwd(ja, (unsigned)(cap / TILE), st)) return 1;
-                ja.only_col = 1;
-                hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 1), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
-                ja.only_col = -1;
+                // (the launch carries the acceleration net's value column as trailing workgroups: they fill the tail of the jet tiles)
+                if (launch_pde_jet_fwd(ja, (unsigned)(cap / TILE), wgs, st)) return 1;
             } else {
                 hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
                 hipLaunchKernelGGL(k_pde_tangent_fwd, PDE_GRID(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
@@ -748,10 +703,7 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
             {
                 ProfScope ps(PK_PDE_BWD, st);
                 if (use_jet) {
-                    if (launch_pde_jet_bwd(ja, (unsigned)(cap / TILE), st)) return 1;
-                    ja.only_col = 4;
-                    hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 1), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
-                    ja.only_col = -1;
+                    if (launch_pde_jet_bwd(ja, (unsigned)(cap / TILE), wgs, st)) return 1;
                 } else {
                     hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
                     hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);

@@ -109,8 +109,27 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_jet_fwd(PdeJetArgs a) {
     float4* xch = reinterpret_cast<float4*>(lds);
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x;
     const int count = pde_pass_count_of(a);
+    if ((int)blockIdx.x >= a.jet_tiles) {
+        // trailing workgroups: value column of the ReLU acceleration net for 4 tiles (the column kernel of pde.hip, riding in this
+        // launch so that its one round of workgroups fills the tail of the jet tiles instead of a launch of its own)
+        const int wg = blockIdx.x - a.jet_tiles;
+        if (wg * WG_SAMPLES >= count) return;
+        const int tile = wg * 4 + w;
+        const int i = tile * TILE + (lane & 31);
+        const float4 q = i < count ? a.qorig[a.klist[a.first + i]] : zero4();
+        float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
+        float o4[4], aw[6];
+        velnet_forward<0, true>(a.Wa, lds, lds + LDS_W_FLOATS, lane, q, T + PDE_ZA * REGF, nullptr, o4);
+        gather6(o4, h, aw);
+        if (h == 0 && i < a.cap) {
+            float* o = a.wout + (size_t)30 * a.cap + i;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[(size_t)k * a.cap] = aw[k];
+        }
+        return;
+    }
+    const int tile = blockIdx.x;
     // whole 128-point groups: the weight-gradient kernel walks the tiles of the last, ragged group too (zero seeds, finite z)
     if (tile * TILE >= (count + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES) return;
     const int i = tile * TILE + (lane & 31);
@@ -213,8 +232,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_jet_bwd(PdeJetArgs a) {
     float4* xch = reinterpret_cast<float4*>(lds);
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x;
     const int count = pde_pass_count_of(a);
+    if ((int)blockIdx.x >= a.jet_tiles) {
+        // trailing workgroups: adjoint of the acceleration net's value column (4 tiles per workgroup)
+        const int wg = blockIdx.x - a.jet_tiles;
+        if (wg * WG_SAMPLES >= count) return;
+        const int tile = wg * 4 + w;
+        const int i = tile * TILE + (lane & 31);
+        float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
+        float r4[4], s6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s6[k] = i < (int)a.cap ? a.seeds[(size_t)(30 + k) * a.cap + i] : 0.f;
+        scatter6(s6, h, r4);
+        velnet_value_backward<0, false>(a.Wa, lds, lds + LDS_W_FLOATS, lane, r4, T + PDE_ZA * REGF, nullptr, T + PDE_GAA * REGF);
+        return;
+    }
+    const int tile = blockIdx.x;
     if (tile * TILE >= (count + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES) return;
     const int i = tile * TILE + (lane & 31);
     float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
@@ -309,15 +342,17 @@ int ensure_jet_attrs() {
     done = true;
     return 0;
 }
-int launch_pde_jet_fwd(const PdeJetArgs& a, unsigned tiles, hipStream_t st) {
+int launch_pde_jet_fwd(const PdeJetArgs& a0, unsigned tiles, unsigned anet_wgs, hipStream_t st) {
     if (ensure_jet_attrs()) return 1;
-    hipLaunchKernelGGL(k_pde_jet_fwd, dim3(tiles), dim3(WG_THREADS), JET_LDS_BYTES, st, a);
+    PdeJetArgs a = a0; a.jet_tiles = (int)tiles;
+    hipLaunchKernelGGL(k_pde_jet_fwd, dim3(tiles + anet_wgs), dim3(WG_THREADS), JET_LDS_BYTES, st, a);
     LAUNCHCK();
     return 0;
 }
-int launch_pde_jet_bwd(const PdeJetArgs& a, unsigned tiles, hipStream_t st) {
+int launch_pde_jet_bwd(const PdeJetArgs& a0, unsigned tiles, unsigned anet_wgs, hipStream_t st) {
     if (ensure_jet_attrs()) return 1;
-    hipLaunchKernelGGL(k_pde_jet_bwd, dim3(tiles), dim3(WG_THREADS), JET_LDS_BYTES, st, a);
+    PdeJetArgs a = a0; a.jet_tiles = (int)tiles;
+    hipLaunchKernelGGL(k_pde_jet_bwd, dim3(tiles + anet_wgs), dim3(WG_THREADS), JET_LDS_BYTES, st, a);
     LAUNCHCK();
     return 0;
 }
