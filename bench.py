@@ -163,7 +163,11 @@ class Step:
         # accumulation into it is atomic), so they are issued on three HIP streams: each chain's workgroups fill the CUs the others
         # leave idle in their tails (most engine kernels run one 128-sample workgroup per CU: a grid of 1055 workgroups is 4.1 rounds).
         self.streams = None
-        if world == 1 and workload == "cfg3" and os.environ.get("NVFI_OVERLAP", "1") != "0":
+        # (several ranks: on by default with RCCL; gloo - the one-GPU logic tests - moves CUDA tensors through the host and serialises badly
+        #  against side streams, so there it needs NVFI_OVERLAP=1)
+        ov = os.environ.get("NVFI_OVERLAP")
+        gloo = world > 1 and os.environ.get("NVFI_BENCH_BACKEND", "nccl") != "nccl"
+        if workload == "cfg3" and (ov == "1" or (ov is None and not gloo)):
             self.streams = [torch.cuda.Stream(device=device) for _ in range(2)]
 
     def rays(self):
@@ -239,7 +243,8 @@ class Step:
 
     def _step_streams(self):
         """Same iteration, three streams: PDE term | non-keyframe render (forward + backward) | keyframe render (forward + backward);
-        the regularisers and the optimiser step follow on the main stream once the three have joined."""
+        the regularisers and the optimiser step follow on the main stream once the three have joined (several ranks: the gradient all-reduce
+        of the renders' share starts as soon as the two renders are done, underneath the PDE chain)."""
         m, f = self.m, self.m.nvfi
         main = torch.cuda.current_stream()
         s_pde, s_r1 = self.streams
@@ -248,12 +253,17 @@ class Step:
         while i % 3 == 0:
             i = int(self.rng.integers(0, 46))
         t_key = 3 * int(self.rng.integers(0, 16)) / 60.0
+        multi = self.world > 1
         with torch.cuda.stream(s_pde):
             s_pde.wait_event(start)
             self.vw *= self.lr_factor
             m.vel_loss_weight = self.vw
+            if multi:      # several ranks: the PDE gradients go through the staging buffer (re-weighted by W*n_r/sum(n_r) at the commit)
+                self.pde_stage.zero()
+                m.vel_grad_targets = self.pde_stage.views
             self.last_lv = m.get_vel_loss(self.n_pts)
             self.pde_counters.append(f.last_pde_counters)
+            pde_out = f.last_pde_out
         with torch.cuda.stream(s_r1):
             s_r1.wait_event(start)
             rays, target = self.rays()
@@ -266,9 +276,23 @@ class Step:
         loss = torch.nn.functional.mse_loss(out[0], target)
         loss.backward()
         self.counters += [c1, c2]
-        main.wait_stream(s_pde); main.wait_stream(s_r1)
         self.L1w *= self.lr_factor; self.tvd *= self.lr_factor; self.tva *= self.lr_factor
-        self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
+        if not multi:
+            main.wait_stream(s_pde); main.wait_stream(s_r1)
+            self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
+        else:
+            # the renders are done first: their gradients (planes, basis, render MLP = the head of the flat buffer, 38 MB) start their
+            # all-reduce on RCCL's stream while the PDE chain is still running on its own; the tail (velocity nets) follows its commit
+            main.wait_stream(s_r1)
+            self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
+            split = self.tail_off is not None and self.comm is None and not os.environ.get("NVFI_NOSPLIT")
+            h = self.bucket.all_reduce_head_start(self.tail_off) if split else None
+            main.wait_stream(s_pde)
+            self.pde_stage.commit_device(pde_out)
+            if split:
+                self.bucket.all_reduce_finish(h, self.tail_off)
+            else:
+                self.bucket.all_reduce_mean(self.comm)
         self.opt.step(zero_grad=True); self.stepped = True
         for g in self.opt.param_groups:
             g["lr"] = g["lr"] * self.lr_factor

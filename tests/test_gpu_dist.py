@@ -21,29 +21,53 @@ T = 19.0 / 60.0
 W_PDE = 0.7
 
 
-def _local_grads(model, o, d, u, tgt, pts, tt, bucket, stage, world):
-    """bench.Step's gradient path for one rank's shard: in-place accumulation into the bucket, PDE term through the stage."""
+def _local_grads(model, o, d, u, tgt, pts, tt, bucket, stage, world, streams=False):
+    """bench.Step's gradient path for one rank's shard: in-place accumulation into the bucket, PDE term through the stage.
+    streams=True is the order of bench.Step._step_streams with several ranks: PDE chain and render on their own HIP streams, the head
+    all-reduce started as soon as the render is differentiated, commit + tail all-reduce after the PDE chain has joined."""
     f = model.nvfi
     f.train()
     f.accumulate_grads_inplace = True
     bucket.zero()
-    f.jitter_override = u
-    try:
-        out = f(T, o, d, True)
-    finally:
-        f.jitter_override = None
-    torch.nn.functional.mse_loss(out[0], tgt).backward()
     tail = bucket.tail_offset(list(f.vel.parameters()))
-    h = bucket.all_reduce_head_start(tail)
-    stage.zero()
     model.vel_loss_weight = W_PDE
     model.vel_grad_targets = stage.views
-    model.get_vel_loss(points=pts, t=tt)
-    stage.commit_device(f.last_pde_out)
+
+    def render_term():
+        f.jitter_override = u
+        try:
+            out = f(T, o, d, True)
+        finally:
+            f.jitter_override = None
+        torch.nn.functional.mse_loss(out[0], tgt).backward()
+
+    if not streams:
+        render_term()
+        h = bucket.all_reduce_head_start(tail)
+        stage.zero()
+        model.get_vel_loss(points=pts, t=tt)
+        stage.commit_device(f.last_pde_out)
+        bucket.all_reduce_finish(h, tail)
+        return
+    main = torch.cuda.current_stream()
+    s_pde, s_r = torch.cuda.Stream(), torch.cuda.Stream()
+    start = torch.cuda.Event(); start.record(main)
+    with torch.cuda.stream(s_pde):
+        s_pde.wait_event(start)
+        stage.zero()
+        model.get_vel_loss(points=pts, t=tt)
+        pde_out = f.last_pde_out
+    with torch.cuda.stream(s_r):
+        s_r.wait_event(start)
+        render_term()
+    main.wait_stream(s_r)
+    h = bucket.all_reduce_head_start(tail)
+    main.wait_stream(s_pde)
+    stage.commit_device(pde_out)
     bucket.all_reduce_finish(h, tail)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, streams):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     torch.cuda.set_device(0)
@@ -60,7 +84,7 @@ def _worker(rank, world, port, out):
     bucket = GradBucket(params)
     stage = PdeGradStage(f._pde_params())
     _local_grads(model, cu(gold["A:rays_o"][lo:hi]), cu(gold["A:rays_d"][lo:hi]), torch.from_numpy(gold["A:train_nonkey:u"][lo:hi].copy()),
-                 cu(gold["A:train_nonkey:target"][lo:hi]), cu(gold["A:pde:points"][plo:phi]), cu(gold["A:pde:t"][plo:phi]), bucket, stage, world)
+                 cu(gold["A:train_nonkey:target"][lo:hi]), cu(gold["A:pde:points"][plo:phi]), cu(gold["A:pde:t"][plo:phi]), bucket, stage, world, streams)
     torch.cuda.synchronize()
     if rank == 0:
         g = named_grads(model)
@@ -69,10 +93,11 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_the_union_batch(tmp_path):
+@pytest.mark.parametrize("streams", [False, True])
+def test_two_ranks_on_one_gpu_match_the_union_batch(tmp_path, streams):
     out = str(tmp_path / "g2.npz")
-    port = 29600 + (os.getpid() % 1500)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29600 + (os.getpid() % 1500) + (7 if streams else 0)
+    mp.spawn(_worker, args=(2, port, out, streams), nprocs=2, join=True)
     got = np.load(out)
     # single process, union batch (same kernels, plain autograd accumulation)
     gold = np.load(os.path.join(GOLD, "hotpath.npz"))
@@ -100,14 +125,18 @@ def test_two_ranks_on_one_gpu_match_the_union_batch(tmp_path):
     assert 0 < float(got["n_kept"]) < int(f.last_pde_n_kept)      # rank 0 kept only its share of the points
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
+@pytest.mark.parametrize("scaling", ["weak", "strong", "weak-streams"])
 def test_bench_runs_as_two_ranks(scaling):
     """bench.py under torch.distributed.run with 2 ranks on the one GPU (NVFI_BENCH_BACKEND=gloo): the multi-rank branch of the step
     (staged PDE gradients, split all-reduce, MAX-over-ranks timing) executes end to end and rank 0 prints one JSON line."""
     env = dict(os.environ, NVFI_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    port = 29700 + (os.getpid() % 1500) + (1 if scaling == "strong" else 0)
+    streams = scaling.endswith("-streams")      # the three-stream step with the split all-reduce under the PDE chain (default with RCCL)
+    if streams:
+        env["NVFI_OVERLAP"] = "1"
+        scaling = "weak"
+    port = 29700 + (os.getpid() % 1500) + (1 if scaling == "strong" else 0) + (2 if streams else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "64", "--pts", "16384", "--no-cpu-baseline", "--scaling", scaling]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "64", "--pts", "16384", "--prime", "1", "--no-cpu-baseline", "--scaling", scaling]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
