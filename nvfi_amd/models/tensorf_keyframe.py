@@ -61,7 +61,7 @@ class _RenderFn(torch.autograd.Function):
         depth = torch.empty(R, device=dev)
         acc = torch.empty(R, device=dev)
         weights = torch.empty(R, S, device=dev)
-        counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=dev)
+        counters = torch.empty(_lib.NCOUNTERS, dtype=torch.int64, device=dev)      # all 8 entries are written by the call
         _lib.check(L.nvfi_render_fwd(C.byref(desc), C.c_int64(R), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(jitter),
                                      C.c_float(t), C.c_int(flags), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc),
                                      _lib.ptr(weights), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
@@ -565,7 +565,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         nbytes = C.c_int64(0)
         _lib.check(L.nvfi_pde_workspace_bytes(C.byref(desc), C.c_int64(P), C.byref(nbytes)))
         ws = self._scratch("pde", nbytes.value, points.device)
-        out = torch.zeros(4, device=points.device)
+        out = torch.empty(4, device=points.device)       # written by k_pde_finish
         grads = []
         if grad_targets is not None:
             grads = list(grad_targets)
@@ -575,7 +575,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
                     p.grad = torch.zeros_like(p)
                 grads.append(p.grad)
         G = self._grads_struct_vel(grads)
-        counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=points.device)
+        counters = torch.empty(_lib.NCOUNTERS, dtype=torch.int64, device=points.device)
         # no host_info: the call does not wait for the device; the kept count is out[1] / counters[4] (device side)
         _lib.check(L.nvfi_pde_loss_ex(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(float(weight)), _lib.ptr(out),
                                       C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), None, None, C.c_int64(0), None,
