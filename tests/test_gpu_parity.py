@@ -490,3 +490,39 @@ def test_mask_branch_train_gradients(gold, models):
         e = relerr(g[k], g2["A:mask_train:grad:" + k])
         assert e < 5e-4, (k, e)
     model.zero_grad(set_to_none=True)
+
+
+def test_fused_adam_reloaded_state_with_persistent_grads():
+    """the cached launch table also holds the exp_avg / exp_avg_sq pointers.  With persistent gradient buffers (GradBucket:
+    same p / g pointers every step) a load_state_dict() replaces the moment tensors - the next step must use the LOADED moments."""
+    from nvfi_amd.optim import Adam
+    torch.manual_seed(1)
+    shapes = [(1, 24, 13, 11), (128, 128), (6,)]
+    ps_a = [torch.nn.Parameter((torch.randn(*s, device="cuda")).contiguous(memory_format=torch.channels_last) if len(s) == 4 else torch.randn(*s, device="cuda")) for s in shapes]
+    ps_b = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in ps_a]
+    oa, ob = Adam([dict(params=ps_a, lr=1e-2)], betas=(0.9, 0.99)), torch.optim.Adam([dict(params=ps_b, lr=1e-2)], betas=(0.9, 0.99))
+    for p in ps_a + ps_b:
+        p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)       # persistent buffers: pointers never change
+
+    def step(k):
+        for pa, pb in zip(ps_a, ps_b):
+            g = torch.randn_like(pa) * (k + 1)
+            pa.grad.copy_(g); pb.grad.copy_(g)
+        oa.step(); ob.step()
+
+    for k in range(3):
+        step(k)
+    # a foreign state (3 more steps of history on other moments) is loaded into both optimisers
+    sd = ob.state_dict()
+    for st in sd["state"].values():
+        st["exp_avg"] = st["exp_avg"] * 0.5 + 0.1
+        st["exp_avg_sq"] = st["exp_avg_sq"] * 2.0 + 0.01
+    import copy
+    oa.load_state_dict(copy.deepcopy(sd)); ob.load_state_dict(copy.deepcopy(sd))
+    for k in range(3, 6):
+        step(k)
+    for pa, pb in zip(ps_a, ps_b):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    for k in sa["state"]:
+        np.testing.assert_allclose(sa["state"][k]["exp_avg"].cpu().numpy(), sb["state"][k]["exp_avg"].cpu().numpy(), rtol=2e-6, atol=1e-6)      # (torch forms exp_avg with lerp: rounding differs in the last bit)
