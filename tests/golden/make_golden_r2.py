@@ -214,6 +214,61 @@ def main():
         out["A:mask_train:grad:" + k] = npf(pp.grad)
     f.mask_field = None
 
+    # ------------------------------------------------------------------ the training loop itself, three iterations
+    # The body of train_nvfi.py:139-249 (--static_dynamic) on field A with explicit inputs instead of the dataset: per iteration a train-mode
+    # render at a non-keyframe time and one at a keyframe time (MSE against fixed targets), the L1 / TV regularisers with their decaying
+    # weights, get_vel_loss, backward, torch.optim.Adam(get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99)).step(), lr decay.  Recorded:
+    # the CPU-generator draws (jitter, collocation points) so that the HIP path can replay them, the loss of every iteration and the
+    # parameters after the third step.
+    from utils.tensorf_utils import TVLoss
+    cfgL, nvL = build_field(R, "A")
+    f = nvL.nvfi
+    o, d = camera_rays(R, "A")
+    gL = torch.Generator().manual_seed(61)
+    tgt1, tgt2 = torch.rand(o.shape[0], 3, generator=gL), torch.rand(o.shape[0], 3, generator=gL)
+    out["A:loop:target1"], out["A:loop:target2"] = npf(tgt1), npf(tgt2)
+    renL = R["Renderer"](nvL, 0, 0, 2048)
+    f.requires_grad_(True)
+    opt = torch.optim.Adam(nvL.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    lr_factor = 0.1 ** (1 / 30000)
+    L1w, tvd, tva, vw = 8e-4, 1.0, 1.0, 1.0
+    tvreg = TVLoss()
+    ts = f.tmax / (f.num_keyframes - 1)
+    P = 4096
+    for it in range(3):
+        nvL.train(); renL.train()
+        torch.manual_seed(100 + it); out[f"A:loop:{it}:u1"] = npf(torch.rand(o.shape[0], 1))
+        torch.manual_seed(100 + it)
+        r1 = renL.render(19.0 / 60.0, R["Ray"](o, d, 0, 1), white_background=True, mode="train")
+        loss = torch.nn.functional.mse_loss(r1[0], tgt1)
+        torch.manual_seed(200 + it); out[f"A:loop:{it}:u2"] = npf(torch.rand(o.shape[0], 1))
+        torch.manual_seed(200 + it)
+        r2 = renL.render(ts * 1, R["Ray"](o, d, 0, 1), white_background=True, mode="train")
+        loss = loss + 1.0 * torch.nn.functional.mse_loss(r2[0], tgt2)
+        L1w *= lr_factor; loss = loss + L1w * f.density_L1()
+        tvd *= lr_factor; loss = loss + f.TV_loss_density(tvreg) * tvd
+        tva *= lr_factor; loss = loss + f.TV_loss_app(tvreg) * tva
+        vw *= lr_factor
+        torch.manual_seed(300 + it)
+        mn, mx = f.aabb
+        pts = torch.rand(P, 3) * (mx - mn) + mn
+        tt = torch.rand(P, 1)
+        out[f"A:loop:{it}:points"], out[f"A:loop:{it}:t"] = npf(pts), npf(tt)
+        torch.manual_seed(300 + it)
+        loss_vel = nvL.get_vel_loss(P)
+        if loss_vel > 0:
+            loss = loss + vw * loss_vel
+        out[f"A:loop:{it}:loss"] = npf(loss)
+        out[f"A:loop:{it}:loss_vel"] = npf(loss_vel if torch.is_tensor(loss_vel) else torch.tensor(loss_vel))
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        for gq in opt.param_groups:
+            gq["lr"] = gq["lr"] * lr_factor
+    for k, v in nvL.state_dict().items():
+        if not k.startswith("nvfi.vel.vel_net."):
+            out["A:loop:final:" + k] = npf(v)
+
     np.savez_compressed(os.path.join(HERE, "r2.npz"),
                         **{k: (v.astype(np.float32) if v.dtype == np.float64 and v.ndim > 0 else v) for k, v in out.items()})
     print("wrote", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "r2.npz")), "bytes")
