@@ -161,6 +161,16 @@ __device__ __forceinline__ void plane_mults(const nvfi_field_desc& f, int i, flo
     my = i < 3 ? (float)(f.G[bb[i]] - 1) / 2.f : (float)(f.K - 1) / 2.f;
 }
 
+// degree-2 real SH bases at an (un-normalised) direction (models/sh.py:87-110)
+__device__ __forceinline__ void sh_bases9(const float* d, float* b) {
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    const float x = d[0], y = d[1], z = d[2];
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[0] = C0; b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
+    b[4] = C2[0] * xy; b[5] = C2[1] * yz; b[6] = C2[2] * (2.0f * zz - xx - yy); b[7] = C2[3] * xz; b[8] = C2[4] * (xx - yy);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -416,6 +416,25 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
     f32x16 o1[1];
     acc_init<1>(o1, lds_b, h, false);
     layer_mfma<1, 24>(lds_w, lane, x, o1);
+    if (f.shading == 1) {
+        // SHRender (tensorf_model_utils.py:292-296, sh.py:87-110): the 27 features are rows (r&3)+8(r>>2)+4h of the basis tile, split over the
+        // lane pair (l, l+32); colour c = relu(sum_k SH_k(viewdir) feat[9c + k] + 0.5).  No MLP, no positional encodings.
+        float sh[9];
+        sh_bases9(vd, sh);
+        float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < 27) part[row / 9] += sh[row % 9] * o1[0][r];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[c] += __shfl_xor(part[c], 32);
+        if (active && h == 0) {
+            float4 c = make_float4(fmaxf(part[0] + 0.5f, 0.f), fmaxf(part[1] + 0.5f, 0.f), fmaxf(part[2] + 0.5f, 0.f), 0.f);
+            a.rgbs[a.rgb_dense ? n : i] = c;
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = o1[0][r];
     x[16] = h ? q.x : vd[0]; x[17] = h ? q.y : vd[1]; x[18] = h ? q.z : vd[2];
@@ -472,6 +491,37 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
     float* stb = a.stash_b + (size_t)tile * (APP_B_ROWS * REGF);
     float g[64];
     f32x16 acc[4];
+    float gpts[3];
+    if (f.shading == 1) {
+        // SHRender backward: d pre_c = w * gr_c where the stored colour is positive (relu'), d feat[9c + k] = SH_k(viewdir) * d pre_c
+        float gpre[3] = {0.f, 0.f, 0.f};
+        float vd[3] = {0.f, 0.f, 0.f};
+        if (active) {
+            const int r = n / a.S;
+            const float* vp = a.rays_d + 3 * (size_t)r;
+            vd[0] = vp[0]; vd[1] = vp[1]; vd[2] = vp[2];
+            if (a.g_rgb) {
+                const float4 pre = a.rgb_pre[r];
+                const float pv[3] = {pre.x, pre.y, pre.z};
+                const float4 c = a.rgbs[i];
+                const float cv[3] = {c.x, c.y, c.z};
+                const float w = a.weight[n];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float gr = (pv[k] >= 0.f && pv[k] <= 1.f) ? a.g_rgb[3 * (size_t)r + k] : 0.f;
+                    gpre[k] = cv[k] > 0.f ? w * gr : 0.f;
+                }
+            }
+        }
+        float sh[9];
+        sh_bases9(vd, sh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            acc[0][r] = row < 27 ? sh[row % 9] * gpre[row / 9] : 0.f;
+        }
+        gpts[0] = gpts[1] = gpts[2] = 0.f;
+    } else {
     // seeds: go_c = w * gr_c * c(1-c) in rows 0..2 of a D tile (lane h=0 regs 0..2)
     {
         float go[3] = {0.f, 0.f, 0.f};
@@ -524,7 +574,6 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
     acc_init<4>(acc, lds_b, 0, false);
     layer_mfma<4, 64>(lds_w, lane, g, acc);
     // acc = gradient wrt the 110 input slots (RENDER_IN layout)
-    float gpts[3];
     {
         const float* xin = stf + 32 * REGF;
 #pragma unroll
@@ -542,6 +591,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
             gpts[c] = s;
         }
     }
+    }   // MLP_PE
     // gfeat (tile 0) -> stash, then basis^T -> gg (48 channels in gather layout)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { g[r] = acc[0][r]; stb[(144 + r) * REGF + lane] = g[r]; }
@@ -873,12 +923,14 @@ int pack_render_frags(const nvfi_field_desc* f, float* buf, RenderFrags* out, Pa
     };
     int rc = 0;
     rc |= add(f->basis, nullptr, fb, nullptr, f->app_dim, f->Ca, 1, 24, RK_NATURAL, SK_HIDDEN, 0);
-    rc |= add(f->rW[0], f->rb[0], f1, b1, 128, 110, 4, 55, RK_NATURAL, SK_RENDER_IN, 0);
-    rc |= add(f->rW[1], f->rb[1], f2, b2, 128, 128, 4, 64, RK_NATURAL, SK_HIDDEN, 0);
-    rc |= add(f->rW[2], f->rb[2], f3, b3, 3, 128, 1, 64, RK_NATURAL, SK_HIDDEN, 0);
-    rc |= add(f->rW[2], nullptr, t3, nullptr, 3, 128, 4, 4, RK_NATURAL, SK_HIDDEN, 1);
-    rc |= add(f->rW[1], nullptr, t2, nullptr, 128, 128, 4, 64, RK_NATURAL, SK_HIDDEN, 1);
-    rc |= add(f->rW[0], nullptr, t1, nullptr, 128, 110, 4, 64, RK_RENDER_IN, SK_HIDDEN, 1);
+    if (f->shading == 0) {      // SH shading has no render MLP (tensorf_base.py:196-197)
+        rc |= add(f->rW[0], f->rb[0], f1, b1, 128, 110, 4, 55, RK_NATURAL, SK_RENDER_IN, 0);
+        rc |= add(f->rW[1], f->rb[1], f2, b2, 128, 128, 4, 64, RK_NATURAL, SK_HIDDEN, 0);
+        rc |= add(f->rW[2], f->rb[2], f3, b3, 3, 128, 1, 64, RK_NATURAL, SK_HIDDEN, 0);
+        rc |= add(f->rW[2], nullptr, t3, nullptr, 3, 128, 4, 4, RK_NATURAL, SK_HIDDEN, 1);
+        rc |= add(f->rW[1], nullptr, t2, nullptr, 128, 128, 4, 64, RK_NATURAL, SK_HIDDEN, 1);
+        rc |= add(f->rW[0], nullptr, t1, nullptr, 128, 110, 4, 64, RK_RENDER_IN, SK_HIDDEN, 1);
+    }
     rc |= add(f->basis, nullptr, tb, nullptr, f->app_dim, f->Ca, 2, 16, RK_NATURAL, SK_HIDDEN, 1);
     if (rc) return nvfi_fail(3, "too many pack jobs");
     out->fb = fb; out->f1 = f1; out->b1 = b1; out->f2 = f2; out->b2 = b2; out->f3 = f3; out->b3 = b3;
@@ -887,8 +939,8 @@ int pack_render_frags(const nvfi_field_desc* f, float* buf, RenderFrags* out, Pa
 }
 
 static int check_desc(const nvfi_field_desc* f) {
-    if (f->Cd != 24 || f->Ca != 48 || f->app_dim != 32)
-        return nvfi_fail(2, "unsupported component counts Cd=%d Ca=%d app_dim=%d (kernels are built for 24/48/32)", f->Cd, f->Ca, f->app_dim);
+    if (f->Cd != 24 || f->Ca != 48 || f->app_dim != (f->shading == 1 ? 27 : 32) || f->shading < 0 || f->shading > 1)
+        return nvfi_fail(2, "unsupported component counts Cd=%d Ca=%d app_dim=%d shading=%d (kernels are built for 24/48/32 with MLP_PE, 24/48/27 with SH)", f->Cd, f->Ca, f->app_dim, f->shading);
     if (f->n_samples < 1 || f->n_samples > 1024) return nvfi_fail(2, "n_samples=%d outside [1,1024]", f->n_samples);
     return 0;
 }

@@ -36,6 +36,11 @@ class MLPRender_PE(nn.Module):
         raise NotImplementedError("MLPRender_PE is evaluated inside the fused appearance kernel; use field.app_at(xyzt, viewdirs)")
 
 
+def SHRender(xyz_sampled, viewdirs, features, kwargs=None):
+    """tensorf_model_utils.py:292-296 as a stand-alone call (inside a render it is fused into k_app_fwd / k_app_bwd)."""
+    return TensorVMKeyframeTimeKplane.sh_render(viewdirs, features)
+
+
 def _cl(t):
     return t.contiguous(memory_format=torch.channels_last)
 
@@ -219,9 +224,17 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         self.init_svd_volume(device)
         self.shadingMode = cfg.shadingMode
         self.pos_pe, self.view_pe, self.fea_pe, self.featureC = cfg.pos_pe, cfg.view_pe, cfg.fea_pe, cfg.featureC
-        if self.shadingMode != "MLP_PE" or self.pos_pe != 6 or self.view_pe != 6 or self.featureC != 128:
-            raise NotImplementedError("only shadingMode=MLP_PE with pos_pe=view_pe=6, featureC=128 is on the hot path")
-        self.renderModule = MLPRender_PE(self.app_dim, self.view_pe, self.pos_pe, self.featureC).to(device)
+        if self.shadingMode == "SH":
+            # tensorf_base.py:196-197: renderModule is the FUNCTION SHRender (no parameters); basis_mat maps the 48 plane products to 27 SH coefficients
+            if self.app_dim != 27:
+                raise NotImplementedError("shadingMode=SH needs app_dim=27 (3 colours x 9 degree-2 SH coefficients)")
+            self.renderModule = SHRender
+        elif self.shadingMode == "MLP_PE":
+            if self.pos_pe != 6 or self.view_pe != 6 or self.featureC != 128 or self.app_dim != 32:
+                raise NotImplementedError("shadingMode=MLP_PE is built for pos_pe=view_pe=6, featureC=128, app_dim=32 (every shipped config)")
+            self.renderModule = MLPRender_PE(self.app_dim, self.view_pe, self.pos_pe, self.featureC).to(device)
+        else:
+            raise NotImplementedError("shadingMode must be MLP_PE or SH (MLP_Fea / MLP / RGB* are not on the hot path: no shipped config uses them)")
         self.use_vel = bool(cfg.use_vel)
         if self.use_vel:
             self.vel_net = VelBasis().to(device)
@@ -297,8 +310,11 @@ class TensorVMKeyframeTimeKplane(nn.Module):
     def _render_params(self):
         ps = list(self.density_plane_space) + list(self.density_plane_time) + list(self.app_plane_space) + list(self.app_plane_time)
         ps.append(self.basis_mat.weight)
-        for i in (0, 2, 4):
-            ps += [self.renderModule.mlp[i].weight, self.renderModule.mlp[i].bias]
+        if self.shadingMode == "SH":
+            ps += [None] * 6                      # no render MLP: the six slots stay empty so that the velocity slots keep their index
+        else:
+            for i in (0, 2, 4):
+                ps += [self.renderModule.mlp[i].weight, self.renderModule.mlp[i].bias]
         if self.use_vel:
             for lin in VelBasis.linears(self.vel_net.weight_net):
                 ps += [lin.weight, lin.bias]
@@ -329,6 +345,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         d.G[:] = self._grid_host
         d.K = int(self.num_keyframes)
         d.Cd, d.Ca, d.app_dim = int(self.density_n_comp[0]), int(self.app_n_comp[0]), int(self.app_dim)
+        d.shading = 1 if self.shadingMode == "SH" else 0
         d.n_samples = int(self.nSamples)
         d.use_vel = int(self.use_vel)
         gsur, lo, hi = self._gate()
@@ -679,8 +696,9 @@ class TensorVMKeyframeTimeKplane(nn.Module):
               {"params": self.app_plane_space, "lr": lr_init_spatialxyz},
               {"params": self.app_plane_time, "lr": lr_init_spatialxyz},
               {"params": self.basis_mat.parameters(), "lr": lr_init_network},
-              {"params": self.basis_mat_density.parameters(), "lr": lr_init_network},
-              {"params": self.renderModule.parameters(), "lr": lr_init_network}]
+              {"params": self.basis_mat_density.parameters(), "lr": lr_init_network}]
+        if isinstance(self.renderModule, nn.Module):
+            gv += [{"params": self.renderModule.parameters(), "lr": lr_init_network}]
         if self.use_vel:
             gv += [{"params": self.vel.parameters(), "lr": lr_init_network}]
         return gv

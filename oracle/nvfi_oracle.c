@@ -569,6 +569,26 @@ void orc_sample_alpha(const orc_field_t* f, int64_t N, const float* xyz, float* 
     for (int64_t n = 0; n < N; ++n) alpha[n] = sample_alpha_one(f, xyz + 3 * n);
 }
 
+/* degree-2 real SH bases at (un-normalised) direction d: models/sh.py:87-110 */
+static inline void sh_bases9(const float* d, float* b) {
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    float x = d[0], y = d[1], z = d[2];
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[0] = C0; b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
+    b[4] = C2[0] * xy; b[5] = C2[1] * yz; b[6] = C2[2] * (2.0f * zz - xx - yy); b[7] = C2[3] * xz; b[8] = C2[4] * (xx - yy);
+}
+/* SHRender inside render_pts (shadingMode "SH", tensorf_base.py:196-197; tensorf_model_utils.py:292-296): rgb = relu(sum_k sh_k feat[9c+k] + 0.5) */
+static inline void sh_shade(const float* d, const float* feat27, float* rgb3) {
+    float b[9];
+    sh_bases9(d, b);
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.f;
+        for (int k = 0; k < 9; ++k) s += b[k] * feat27[9 * c + k];
+        s += 0.5f;
+        rgb3[c] = s > 0.f ? s : 0.f;
+    }
+}
 /* ------------------------------------------------------------------ a-17 SHRender (tensorf_model_utils.py:292-296, sh.py:87-110) */
 void orc_sh_render(int64_t N, const float* view, const float* ft, float* rgb) {
     const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
@@ -707,8 +727,13 @@ orc_ctx_t* orc_render_fwd(const orc_field_t* f, int64_t R, const float* o, const
             float q[4] = {xw[3 * j], xw[3 * j + 1], xw[3 * j + 2], tn_eval};
             float g[MAXC], feat[32], in[RIN], rgb3[3];
             app_feature_one(f, q, g, feat);
-            render_input(feat, d + 3 * r, xw + 3 * j, in);
-            render_mlp_fwd(f, in, rr->mz1 ? rr->mz1 + (size_t)mi * HID : NULL, rr->mz2 ? rr->mz2 + (size_t)mi * HID : NULL, rgb3);
+            if (f->shading == 1) {
+                sh_shade(d + 3 * r, feat, rgb3);
+                memset(in, 0, sizeof(in));
+            } else {
+                render_input(feat, d + 3 * r, xw + 3 * j, in);
+                render_mlp_fwd(f, in, rr->mz1 ? rr->mz1 + (size_t)mi * HID : NULL, rr->mz2 ? rr->mz2 + (size_t)mi * HID : NULL, rgb3);
+            }
             if (rr->midx) {
                 rr->midx[mi] = j;
                 memcpy(rr->min_ + (size_t)mi * RIN, in, sizeof(in));
@@ -831,6 +856,17 @@ void orc_render_bwd(orc_ctx_t* cx, const float* g_rgb, const float* g_depth, con
             const float* z1 = rr->mz1 + (size_t)mi * HID; const float* z2 = rr->mz2 + (size_t)mi * HID;
             const float* c3 = cx->rgbs + ((size_t)r * S + j) * 3;
             float go[3], gh2[HID], gz2[HID], gh1[HID], gz1[HID], gin[RIN], h1[HID], h2[HID];
+            if (f->shading == 1) {
+                /* SHRender backward: relu' (the stored colour is positive exactly where the pre-activation was), then the SH bases */
+                float b9[9];
+                sh_bases9(cx->d + 3 * r, b9);
+                for (int k = 0; k < RIN; ++k) gin[k] = 0.f;
+                for (int c = 0; c < 3; ++c) {
+                    float gpre = c3[c] > 0.f ? w[j] * gr[c] : 0.f;
+                    for (int k = 0; k < 9; ++k) gin[9 * c + k] = b9[k] * gpre;
+                }
+                goto basis_part;
+            }
             for (int c = 0; c < 3; ++c) go[c] = w[j] * gr[c] * c3[c] * (1.f - c3[c]);
             for (int i = 0; i < HID; ++i) { h1[i] = z1[i] > 0.f ? z1[i] : 0.f; h2[i] = z2[i] > 0.f ? z2[i] : 0.f; gh2[i] = 0.f; gh1[i] = 0.f; }
             for (int o = 0; o < 3; ++o) {
@@ -860,6 +896,7 @@ void orc_render_bwd(orc_ctx_t* cx, const float* g_rgb, const float* g_depth, con
                 gx[3 * j + c] += s;
             }
             /* feat = basis * g48 */
+        basis_part:;
             const float* g48 = rr->mg + (size_t)mi * f->Ca;
             float gg[MAXC];
             for (int c = 0; c < f->Ca; ++c) gg[c] = 0.f;

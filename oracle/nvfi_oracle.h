@@ -28,6 +28,7 @@ typedef struct {
     int32_t use_vel;     /* cfg.use_vel                         (tensorf_keyframe.py:92) */
     int32_t gate_sur;    /* 0: VelocityAABB(eps) 1: VelocityAABBSur (velocity_field.py:21-51) */
     int32_t has_amask;   /* alphaMask present (eval only)       (tensorf_keyframe.py:656) */
+    int32_t shading;     /* 0: MLP_PE (MLPRender_PE)  1: SH (SHRender on 27 features; tensorf_base.py:196-197) */
     int32_t am_dims[3];  /* alpha volume W,H,D */
     float aabb[6];       /* min xyz, max xyz */
     float near_, far_, step_size;

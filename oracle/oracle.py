@@ -18,7 +18,7 @@ fp = C.POINTER(C.c_float)
 class OrcField(C.Structure):
     _fields_ = [
         ("G", C.c_int32 * 3), ("K", C.c_int32), ("Cd", C.c_int32), ("Ca", C.c_int32), ("app_dim", C.c_int32),
-        ("n_samples", C.c_int32), ("use_vel", C.c_int32), ("gate_sur", C.c_int32), ("has_amask", C.c_int32),
+        ("n_samples", C.c_int32), ("use_vel", C.c_int32), ("gate_sur", C.c_int32), ("has_amask", C.c_int32), ("shading", C.c_int32),
         ("am_dims", C.c_int32 * 3),
         ("aabb", C.c_float * 6), ("near_", C.c_float), ("far_", C.c_float), ("step_size", C.c_float),
         ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float),
@@ -142,7 +142,8 @@ class FieldSpec:
             f.aps[i] = _p(self.p[f"app_plane_space.{i}"])
             f.apt[i] = _p(self.p[f"app_plane_time.{i}"])
         f.basis = _p(self.p["basis_mat.weight"])
-        for i, k in enumerate((0, 2, 4)):
+        f.shading = 1 if str(m.get("shadingMode", "MLP_PE")) == "SH" else 0      # SH: no render MLP (tensorf_base.py:196-197)
+        for i, k in enumerate((0, 2, 4) if not f.shading else ()):
             f.rW[i] = _p(self.p[f"renderModule.mlp.{k}.weight"])
             f.rb[i] = _p(self.p[f"renderModule.mlp.{k}.bias"])
         has_vel = "vel_net.weight_net.1.weight" in self.p      # radiance-only fields (use_vel: False) carry no velocity nets
@@ -172,7 +173,7 @@ class FieldSpec:
             G.aps[i] = _p(g[f"app_plane_space.{i}"])
             G.apt[i] = _p(g[f"app_plane_time.{i}"])
         G.basis = _p(g["basis_mat.weight"])
-        for i, k in enumerate((0, 2, 4)):
+        for i, k in enumerate((0, 2, 4) if "renderModule.mlp.0.weight" in g else ()):
             G.rW[i] = _p(g[f"renderModule.mlp.{k}.weight"])
             G.rb[i] = _p(g[f"renderModule.mlp.{k}.bias"])
         for i, k in enumerate(VEL_KEYS if "vel_net.weight_net.1.weight" in g else []):

@@ -214,6 +214,51 @@ def main():
         out["A:mask_train:grad:" + k] = npf(pp.grad)
     f.mask_field = None
 
+    # ------------------------------------------------------------------ shadingMode "SH" (a-17 inside the render call): app_dim = 27, no render MLP
+    # (tensorf_base.py:196-197, tensorf_model_utils.py:292-296).  Field "D" = the bat-like field A with that shading: eval renders and a
+    # train-mode render with every gradient.
+    cfgD = make_cfg(R, "A")
+    cfgD.nvfi.shadingMode = "SH"
+    cfgD.nvfi.app_dim = 27
+    torch.manual_seed(233)
+    aabbD = torch.stack([torch.tensor(cfgD.nvfi[b]) for b in ["bbox_x", "bbox_y", "bbox_z"]], dim=-1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        nvD = R["NVFi"](cfgD, "cpu", aabbD, [20, 18, 16], [cfgD.dataset.near, cfgD.dataset.far])
+    f = nvD.nvfi
+    gD = torch.Generator().manual_seed(71)
+    with torch.no_grad():
+        for i in range(3):
+            pl = f.density_plane_space[i]
+            H, W = pl.shape[-2:]
+            yy = torch.linspace(-1, 1, H)[:, None]; xx = torch.linspace(-1, 1, W)[None, :]
+            pl.mul_((3.2 * torch.sqrt(torch.exp(-xx ** 2 / (2 * 0.45 ** 2)) * torch.exp(-yy ** 2 / (2 * 0.45 ** 2))))[None, None])
+            f.density_plane_time[i].add_(0.15 * torch.randn(f.density_plane_time[i].shape, generator=gD))
+            f.app_plane_time[i].add_(0.25 * torch.randn(f.app_plane_time[i].shape, generator=gD))
+            f.app_plane_space[i].mul_(6.0)
+        f.basis_mat.weight.mul_(25.0)           # SH coefficients of O(1): colours leave the relu(. + 0.5) plateau
+        last = f.vel_net.weight_net[-1][0]
+        last.weight.mul_(4.0); last.bias.add_(0.3 * torch.randn(last.bias.shape, generator=gD))
+    dump_sd(out, "D:", nvD)
+    o, d = camera_rays(R, "A")
+    renD = R["Renderer"](nvD, 0, 0, 2048)
+    for name, tt in (("nonkey", 19.0 / 60.0), ("key", 0.25)):
+        r = renD.render(tt, R["Ray"](o, d, 0, 1), white_background=True, mode="test")
+        for nm, v in zip(("rgb", "depth", "acc"), r[:3]):
+            out[f"D:render_{name}:{nm}"] = npf(v)
+    nvD.zero_grad(set_to_none=True)
+    tgtD = torch.rand(o.shape[0], 3, generator=gD)
+    torch.manual_seed(21)
+    out["D:train:u"] = npf(torch.rand(o.shape[0], 1))
+    torch.manual_seed(21)
+    r = renD.render(19.0 / 60.0, R["Ray"](o, d, 0, 1), white_background=True, mode="train")
+    lossD = torch.nn.functional.mse_loss(r[0], tgtD) + 0.01 * r[1].mean()
+    lossD.backward()
+    out["D:train:target"], out["D:train:loss"], out["D:train:rgb"] = npf(tgtD), npf(lossD), npf(r[0])
+    for k, pp in nvD.named_parameters():
+        if k.startswith("nvfi.vel.vel_net.") or pp.grad is None:
+            continue
+        out["D:train:grad:" + k] = npf(pp.grad)
+
     # ------------------------------------------------------------------ the training loop itself, three iterations
     # The body of train_nvfi.py:139-249 (--static_dynamic) on field A with explicit inputs instead of the dataset: per iteration a train-mode
     # render at a non-keyframe time and one at a keyframe time (MSE against fixed targets), the L1 / TV regularisers with their decaying
