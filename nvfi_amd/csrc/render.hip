@@ -664,7 +664,19 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
 #define SCATTER_SPW 8
 __device__ __forceinline__ float dpp_xor1(float v) { return __shfl_xor(v, 1); }
 
-template <int C>
+// DET: the gradient pointers address int64 shadow planes and every contribution is added as a fixed-point integer (2^50 per unit):
+// integer addition is associative, so the sums are bit-identical whatever order the atomics arrive in (NVFI_DETERMINISTIC=1).
+#define DET_SCALE 1125899906842624.0      /* 2^50: +-8192 of range, 8.9e-16 of resolution */
+template <bool DET>
+__device__ __forceinline__ void grad_add(float* g, size_t idx, float v) {
+    if (DET) atomicAdd(reinterpret_cast<unsigned long long*>(g) + idx, (unsigned long long)__double2ll_rn((double)v * DET_SCALE));
+    else atomicAdd(g + idx, v);
+}
+__global__ void k_det_finish(const long long* __restrict__ shadow, float* __restrict__ g, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) g[i] += (float)((double)shadow[i] * (1.0 / DET_SCALE));
+}
+template <int C, bool DET = false>
 __global__ __launch_bounds__(256) void k_plane_scatter(ScatterArgs a) {
     const int lane = threadIdx.x & 63;
     const int wg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -728,14 +740,14 @@ __global__ __launch_bounds__(256) void k_plane_scatter(ScatterArgs a) {
                 const bool my0 = dx0 ? b[p].m1 : b[p].m0, my1 = dx0 ? b[p].m3 : b[p].m2;
                 const float wx = dx0 ? b[p].w : b[p].e;
                 const size_t o0 = (size_t)(b[p].base + dx0) * C + ch, o1 = o0 + (size_t)b[p].W * C;
-                if (my0) atomicAdd(gp[p] + o0, (wx * b[p].s) * o);
-                if (my1) atomicAdd(gp[p] + o1, (wx * b[p].n) * o);
+                if (my0) grad_add<DET>(gp[p], o0, (wx * b[p].s) * o);
+                if (my1) grad_add<DET>(gp[p], o1, (wx * b[p].n) * o);
             } else {
                 const size_t o0 = (size_t)b[p].base * C + ch, o1 = o0 + (size_t)b[p].W * C;
-                if (b[p].m0) atomicAdd(gp[p] + o0, (b[p].e * b[p].s) * o);
-                if (b[p].m1) atomicAdd(gp[p] + o0 + C, (b[p].w * b[p].s) * o);
-                if (b[p].m2) atomicAdd(gp[p] + o1, (b[p].e * b[p].n) * o);
-                if (b[p].m3) atomicAdd(gp[p] + o1 + C, (b[p].w * b[p].n) * o);
+                if (b[p].m0) grad_add<DET>(gp[p], o0, (b[p].e * b[p].s) * o);
+                if (b[p].m1) grad_add<DET>(gp[p], o0 + C, (b[p].w * b[p].s) * o);
+                if (b[p].m2) grad_add<DET>(gp[p], o1, (b[p].e * b[p].n) * o);
+                if (b[p].m3) grad_add<DET>(gp[p], o1 + C, (b[p].w * b[p].n) * o);
             }
         }
     }
@@ -877,6 +889,25 @@ static SideStream g_side;
 static int scatter_mask() { static int m = -1; if (m < 0) { const char* e = getenv("NVFI_SCATTER_MASK"); m = e ? atoi(e) : 63; } return m; }
 
 
+// NVFI_DETERMINISTIC=1: bit-reproducible plane gradients for tests.  The sorted-tile path sums in an order that
+// depends on atomic cursors; this mode takes the plain atomic scatter instead and accumulates in fixed point (k_plane_scatter<C, true>).
+static bool det_mode() { static int d = -1; if (d < 0) { const char* e = getenv("NVFI_DETERMINISTIC"); d = (e && atoi(e) != 0) ? 1 : 0; } return d != 0; }
+static int64_t plane_elems(const nvfi_field_desc* f, int64_t* off /* [12]: dps[3] dpt[3] aps[3] apt[3] */) {
+    const int A[3] = {0, 0, 1}, Bx[3] = {1, 2, 2}, Cc[3] = {2, 1, 0};
+    int64_t n = 0;
+    for (int i = 0; i < 3; ++i) { off[i] = n; n += (int64_t)f->G[A[i]] * f->G[Bx[i]] * f->Cd; }
+    for (int i = 0; i < 3; ++i) { off[3 + i] = n; n += (int64_t)f->K * f->G[Cc[i]] * f->Cd; }
+    for (int i = 0; i < 3; ++i) { off[6 + i] = n; n += (int64_t)f->G[A[i]] * f->G[Bx[i]] * f->Ca; }
+    for (int i = 0; i < 3; ++i) { off[9 + i] = n; n += (int64_t)f->K * f->G[Cc[i]] * f->Ca; }
+    return n;
+}
+static int launch_scatter_det(ScatterArgs& sa, int C, int64_t N, hipStream_t st) {
+    const unsigned sc_blocks = (unsigned)((N + 4 * SCATTER_SPW - 1) / (4 * SCATTER_SPW));
+    if (C == 24) hipLaunchKernelGGL((k_plane_scatter<24, true>), dim3(sc_blocks), dim3(256), 0, st, sa);
+    else hipLaunchKernelGGL((k_plane_scatter<48, true>), dim3(sc_blocks), dim3(256), 0, st, sa);
+    LAUNCHCK();
+    return 0;
+}
 // plane-gradient scatter: LDS-privatised time rows when they fit, plain channel-parallel atomics otherwise
 static int launch_scatter(const nvfi_field_desc* f, ScatterArgs& sa, int C, int64_t N, float tn, hipStream_t st) {
     int gmax = f->G[0] > f->G[1] ? f->G[0] : f->G[1];
@@ -974,6 +1005,7 @@ struct RenderPlan {
     float *vel_frag, *render_frag;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     float *slabs;
+    long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
     TileWork tw; bool tiles;   // sorted-tile plane scatter (scatter.hip); tiles = false: grid too large, atomic scatter instead
     int64_t total;
 };
@@ -1010,7 +1042,9 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
         P->app_f = B.take<float>(P->cap_tiles * (int64_t)(APP_F_ROWS * REGF));
         P->app_b = B.take<float>(P->cap_tiles * (int64_t)(APP_B_ROWS * REGF));
         P->slabs = B.take<float>((int64_t)NSLAB_MAX * SLAB_FLOATS * 6);
-        P->tiles = tile_geom(f, &P->tw.g) == 0 && use_tiles();
+        P->tiles = tile_geom(f, &P->tw.g) == 0 && use_tiles() && !det_mode();
+        P->shadow = nullptr;
+        if (det_mode()) { int64_t off[12]; P->shadow = B.take<long long>(plane_elems(f, off)); }
         if (P->tiles) plan_tile_scatter(B, f, N, &P->tw);
         if (nsteps > 0) {
             const int64_t nev = 2 * (int64_t)nsteps;
@@ -1152,7 +1186,20 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     const int64_t N = P.N;
     const float tn = f->use_vel ? norm_time(*f, base) : norm_time(*f, t);
     const unsigned ray_blocks = (unsigned)((R + 3) / 4);
-    const bool side = g_side.get() != 0 && !P.tiles;   // the tile scatter reuses one og buffer for both branches: same stream
+    const bool side = g_side.get() != 0 && !P.tiles && !det_mode();   // the tile scatter reuses one og buffer for both branches: same stream
+    // deterministic mode: the scatters add fixed-point integers into int64 shadow planes; k_det_finish folds them into the gradients
+    nvfi_grads gdet = *grads;
+    int64_t det_off[12]; int64_t det_n = 0;
+    if (det_mode()) {
+        det_n = plane_elems(f, det_off);
+        HIPCK(hipMemsetAsync(P.shadow, 0, (size_t)det_n * sizeof(long long), st));
+        for (int i = 0; i < 3; ++i) {
+            if (gdet.dps[i]) gdet.dps[i] = reinterpret_cast<float*>(P.shadow + det_off[i]);
+            if (gdet.dpt[i]) gdet.dpt[i] = reinterpret_cast<float*>(P.shadow + det_off[3 + i]);
+            if (gdet.aps[i]) gdet.aps[i] = reinterpret_cast<float*>(P.shadow + det_off[6 + i]);
+            if (gdet.apt[i]) gdet.apt[i] = reinterpret_cast<float*>(P.shadow + det_off[9 + i]);
+        }
+    }
     // fragments were packed by the forward into the same workspace
     VelFrags VW; RenderFrags RW; PackJobs dummy; dummy.n = 0;
     if (f->use_vel && nsteps > 0) pack_vel_frags(f->vW, f->vb, P.vel_frag, &VW, &dummy);
@@ -1184,11 +1231,11 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
         }
     } else if (want_aplanes) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
-        sa.f = *f; sa.count = P.counters + 1; sa.list = P.mlist; sa.xw = P.xw; sa.tn = tn; sa.gg = P.gg; sa.g = *grads; sa.plane_mask = scatter_mask();
+        sa.f = *f; sa.count = P.counters + 1; sa.list = P.mlist; sa.xw = P.xw; sa.tn = tn; sa.gg = P.gg; sa.g = det_mode() ? gdet : *grads; sa.plane_mask = scatter_mask();
         hipStream_t ss = st;
         if (side) { HIPCK(hipEventRecord(g_side.fork[0], st)); HIPCK(hipStreamWaitEvent(g_side.s, g_side.fork[0], 0)); ss = g_side.s; forked = true; }
         ProfScope ps(PK_APP_SCATTER, ss);
-        if (launch_scatter(f, sa, 48, N, tn, ss)) return 1;
+        if (det_mode() ? launch_scatter_det(sa, 48, N, ss) : launch_scatter(f, sa, 48, N, tn, ss)) return 1;
     }
     LAUNCHCK();
     // render-MLP weight gradients
@@ -1242,11 +1289,21 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     } else if (nsteps > 0) { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
     if (!P.tiles && want_dplanes) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
-        sa.f = *f; sa.count = P.counters + 0; sa.list = P.vlist; sa.xw = P.xw; sa.tn = tn; sa.gxpre = P.gxpre; sa.g = *grads; sa.plane_mask = scatter_mask();
+        sa.f = *f; sa.count = P.counters + 0; sa.list = P.vlist; sa.xw = P.xw; sa.tn = tn; sa.gxpre = P.gxpre; sa.g = det_mode() ? gdet : *grads; sa.plane_mask = scatter_mask();
         hipStream_t ss = st;
         if (side) { HIPCK(hipEventRecord(g_side.fork[1], st)); HIPCK(hipStreamWaitEvent(g_side.s, g_side.fork[1], 0)); ss = g_side.s; forked = true; }
         ProfScope ps(PK_DENSITY_SCATTER, ss);
-        if (launch_scatter(f, sa, 24, N, tn, ss)) return 1;
+        if (det_mode() ? launch_scatter_det(sa, 24, N, ss) : launch_scatter(f, sa, 24, N, tn, ss)) return 1;
+    }
+    if (det_mode()) {
+        float* const real[12] = {grads->dps[0], grads->dps[1], grads->dps[2], grads->dpt[0], grads->dpt[1], grads->dpt[2],
+                                 grads->aps[0], grads->aps[1], grads->aps[2], grads->apt[0], grads->apt[1], grads->apt[2]};
+        for (int k = 0; k < 12; ++k) {
+            if (!real[k]) continue;
+            const int64_t n = (k + 1 < 12 ? det_off[k + 1] : det_n) - det_off[k];
+            hipLaunchKernelGGL(k_det_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P.shadow + det_off[k], real[k], n);
+        }
+        LAUNCHCK();
     }
     LAUNCHCK();
     // RK2 adjoint + velocity-net weight gradients

@@ -167,3 +167,22 @@ def test_fast_activation_and_trig_error_bounds():
             print(f"trig_sel kind {kind} |a|<={lim}: max abs err {abs_err.max():.3e}, max ulp {ulp.max():.2f}")
             assert abs_err.max() < 2.5e-7, (kind, lim, abs_err.max())       # absolute: what enters the MLP's first layer
             assert np.percentile(ulp, 99.9) <= tol_ulp + 1.0, (kind, lim, np.percentile(ulp, 99.9))
+
+
+def test_deterministic_mode():
+    """NVFI_DETERMINISTIC=1: the plane-gradient scatter accumulates fixed-point integers, so three backward passes over
+    2048 rays that all cross the same texels give BIT-IDENTICAL gradients for every parameter (planes, basis, render MLP, velocity net),
+    and the numbers still match the reference goldens."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "det_check.py")], env=dict(os.environ, NVFI_DETERMINISTIC="1"), cwd=root,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    bad = [k for k, v in res["bit_identical"].items() if not v]
+    assert not bad, bad
+    assert len(res["bit_identical"]) >= 30
+    assert res["worst_relerr_vs_reference"] < 5e-4, res["worst_relerr_vs_reference"]
