@@ -285,7 +285,7 @@ class Step:
             # all-reduce on RCCL's stream while the PDE chain is still running on its own; the tail (velocity nets) follows its commit
             main.wait_stream(s_r1)
             self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
-            split = self.tail_off is not None and self.comm is None and not os.environ.get("NVFI_NOSPLIT")
+            split = self.tail_off is not None and self.comm is None
             h = self.bucket.all_reduce_head_start(self.tail_off) if split else None
             main.wait_stream(s_pde)
             self.pde_stage.commit_device(pde_out)
