@@ -186,3 +186,17 @@ def test_deterministic_mode():
     assert not bad, bad
     assert len(res["bit_identical"]) >= 30
     assert res["worst_relerr_vs_reference"] < 5e-4, res["worst_relerr_vs_reference"]
+
+
+def test_pde_column_kernels_still_match_goldens():
+    """NVFI_PDE_JET=0 keeps the round-1 column-parallel Jacobian kernels of pde.hip (one workgroup per (tile, column)); they must keep
+    passing the functorch-Jacobian / loss / gradient goldens next to the fused five-column kernels of pde_jet.hip (the default)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NVFI_PDE_JET="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_fullsize_chessboard.py"),
+                        "-q", "-x", "-m", "gpu", "-k", "pde"], env=env, cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
