@@ -542,15 +542,18 @@ def main():
         pc = torch.stack(step.pde_counters).sum(0).cpu().numpy() if step.pde_counters else np.zeros(8)
         V, Nw, M, E = float(c[0]), float(c[1]), float(c[2]), float(c[3])
         kept, pre_evals = float(pc[4]), float(pc[3])
+        pre_mode = os.environ.get("NVFI_PDE_PREFILTER", "fp32")
         flops = {"rk2_fwd": E * VEL_FLOP, "rk2_bwd": E * VEL_FLOP, "app_fwd": M * APP_FLOP, "app_bwd": M * APP_FLOP,
                  "wgrad": E * VEL_FLOP + M * APP_FLOP + kept * 6 * VEL_FLOP, "pde_fwd": kept * 6 * VEL_FLOP,
                  "pde_bwd": kept * 6 * VEL_FLOP, "pde_prefilter": pre_evals * VEL_FLOP}
+        if pre_mode == "fp16band":      # opt-in: the class is an fp16-input pass + a short fp32 list; no fp32-MFMA figure applies to it
+            del flops["pde_prefilter"]
         times = {CLASSES[i]: (tot[i], cnt[i]) for i in range(min(ncls, len(CLASSES)))}
         # per step: what the kernels counted (V valid samples, N samples warped by RK2, M appearance-masked samples, E velocity-net
         # evaluations of the render warp, P' collocation points kept by the occupancy prefilter, prefilter net evaluations)
         work = dict(steps=psteps, V=V / psteps, N=Nw / psteps, M=M / psteps, E=E / psteps, P_kept=kept / psteps, prefilter_evals=pre_evals / psteps,
                     gflop_per_step={k: v / psteps / 1e9 for k, v in flops.items()}, gflop_per_step_total=sum(flops.values()) / psteps / 1e9,
-                    ms_per_step_profiled_serial=tprof * 1e3,
+                    ms_per_step_profiled_serial=tprof * 1e3, prefilter=pre_mode, prefilter_fp32_reevaluated_points=float(pc[5]) / psteps,
                     streams=("3 HIP streams in the timed region (PDE term | non-keyframe render | keyframe render); the profiled pass is issued on one stream"
                              if streams is not None else "one stream"))
         traffic_all = (_load_json(f"{PROFILE_TAG}_traffic.json") or {}).get("bytes_per_launch", {})
@@ -584,7 +587,9 @@ def main():
     out = {
         "metric": "training rays/sec (fwd+bwd incl. PDE loss), 'bat' scene", "value": value, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32" if os.environ.get("NVFI_PDE_PREFILTER", "fp32") != "fp16band" else "f32 (opt-in: fp16-input pre-pass of the PDE occupancy prefilter, fp32 re-evaluation band)",
+        "data": "synthetic",
         "config": {"workload": ("bat.yaml + velocity field + PDE divergence loss (configs[2]): 199^3 grid, K=16, 128 samples/ray, "
                                 "2 renders x 2048 rays + PDE on 262144 collocation points + plane regularisers + Adam, per GPU"
                                 if args.workload == "cfg3" else

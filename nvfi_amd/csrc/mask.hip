@@ -6,6 +6,7 @@
 // activations (they are the B operands of the weight gradients and carry the ReLU mask of the adjoint pass) and the softmax
 // output; the backward walks the transposed fragments and leaves the adjoints in the MFMA register layout for k_wgrad.
 #include "common.h"
+#include "engine16.h"
 #include <string.h>
 
 #define MK_F_ROWS (16 + 4 * 64 + 16)   // forward stash per tile: x0 (16) | h1..h4 (64 each) | softmax (16)
@@ -160,8 +161,6 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_bwd(MkArgs a) {
 // features: lane (n, h) supplies k = 8h + j  <->  feature 16 s + 8 (j >> 2) + 4 h + (j & 3), which is exactly registers
 // 8s .. 8s+7 of the previous layer's D-layout output - so, as in the fp32 engine, activations never leave registers and the
 // permutation lives in the packed weight fragments.  32 MFMAs of 32 cycles per 128x128 layer instead of 256 of 64.
-typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 __host__ __device__ inline int feat16(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 
 struct Pack16Job { const float* W; h8_t* frag; int out, in, MT, NS, transposed; };
@@ -197,13 +196,6 @@ __device__ __forceinline__ void stage16(h8_t* lds_w, const h8_t* __restrict__ fr
     float4* dst = reinterpret_cast<float4*>(lds_w);
     for (int i = threadIdx.x; i < n8; i += WG_THREADS) dst[i] = src[i];
     if (threadIdx.x < 128) lds_b[threadIdx.x] = (bias && threadIdx.x < nb) ? bias[threadIdx.x] : 0.f;
-}
-template <int NS>
-__device__ __forceinline__ void to_h8(const float* x, h8_t* B) {
-#pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) B[sidx][j] = (_Float16)x[8 * sidx + j];
 }
 // one layer: MT output tiles, NS k-steps; epi(m, acc)
 template <int MT, int NS, class Epi>

@@ -52,6 +52,30 @@ __device__ __forceinline__ int pde_pass_count_of(const PdeJetArgs& a) {
     return c <= 0 ? 0 : (c > a.cap ? (int)a.cap : (int)c);
 }
 int launch_frag_x4(const X4Jobs& jobs, hipStream_t st);
+
+// feature-split per-point RK2 (vel_split.hip): one 32-point tile per workgroup, x4 weight fragments straight from L2
+struct SplitArgs {
+    nvfi_field_desc f;
+    const float4* f4[6]; const float* bv[6];
+    const int* count; int64_t n_direct;      // device count of list entries (NULL -> n_direct)
+    const int* list; float4* xw;             // list[i] -> point index (NULL: identity); positions updated in place
+    const float* pt_t; const float* pt_base; int pt_by_list; float dt_max; int max_steps;
+};
+int launch_rk2_split(const SplitArgs& a, int64_t cap_points, int wide, hipStream_t st);
+
+// opt-in fp16 pre-pass of the prefilter (pre16.hip)
+#define PRE16_IMAGE_BYTES 150528   // fp16 fragments of the six weight_net layers (144 KB) + fp32 biases: staged into LDS once per workgroup
+struct Pre16Args {
+    nvfi_field_desc f;
+    void* img;                     // PRE16_IMAGE_BYTES of workspace
+    int64_t P; const int* list;    // bucket order -> point index
+    const float4* xw; float4* xout; uint8_t* near;
+    const float* pt_t; const float* pt_base; float dt_max; int max_steps; float eps_gate;
+};
+int launch_pre16(const nvfi_field_desc* f, Pre16Args a, hipStream_t st);
+int launch_pde_band(const nvfi_field_desc* f, int64_t P, const int* perm, const float* sig, const uint8_t* near, float band, uint8_t* flags,
+                    int* cnt, hipStream_t st);
+int launch_pde_band_map(int64_t P, const int* bcount, const int* perm, int* blist, hipStream_t st);
 // tiles: capacity in 32-point tiles (five weight_net columns each); anet_wgs: capacity in 128-point workgroups of the acceleration net
 int launch_pde_jet_fwd(const PdeJetArgs& a, unsigned tiles, unsigned anet_wgs, hipStream_t st);
 int launch_pde_jet_bwd(const PdeJetArgs& a, unsigned tiles, unsigned anet_wgs, hipStream_t st);

@@ -543,11 +543,12 @@ __global__ void k_pde_pass_count(const int* kcount, int64_t first, int64_t cap, 
     }
 }
 // counters[1] = candidates, [3] = prefilter net evaluations (2 per RK2 step, from the step-class histogram), [4] = kept points
-__global__ void k_pde_counters(const int* cls_count, const int* kcount, int64_t P, int64_t* c8) {
+// [5] = points re-evaluated in fp32 behind the opt-in fp16 pre-pass (pre16.hip), 0 otherwise
+__global__ void k_pde_counters(const int* cls_count, const int* kcount, int64_t P, int pre16, int64_t* c8) {
     if (threadIdx.x == 0) {
         int64_t evals = 0;
         for (int c = 0; c < PDE_MAX_CLASS; ++c) evals += 2ll * c * cls_count[c];
-        c8[0] = 0; c8[1] = P; c8[2] = 0; c8[3] = evals; c8[4] = *kcount; c8[5] = c8[6] = c8[7] = 0;
+        c8[0] = 0; c8[1] = P; c8[2] = 0; c8[3] = evals; c8[4] = *kcount; c8[5] = pre16 ? kcount[1] : 0; c8[6] = c8[7] = 0;
     }
 }
 __global__ void k_pde_finish(const double* sums, const int* kcount, float* out) {
@@ -566,6 +567,7 @@ struct PdePlan {
     int *cls, *rank, *cls_count, *perm, *cnt, *off, *klist, *kcount, *dcount;
     uint8_t* flags;
     float* sig;     // density at the warped points (prefilter)
+    float4* xw16; uint8_t* near; int* blist; int* bcount; void* img16;   // fp16 pre-pass (pre16.hip)
     double* sums;
     float *vel_frag, *a_frag, *vel_x4, *stash, *seeds, *wout, *slabs;
     int64_t chunk, total;
@@ -580,6 +582,8 @@ static void plan_pde(int64_t P, void* ws, PdePlan* L) {
     L->flags = B.take<uint8_t>(nw * 64);
     L->sig = B.take<float>(nw * 64);
     L->sums = B.take<double>(4);
+    L->xw16 = B.take<float4>(P); L->near = B.take<uint8_t>(nw * 64); L->blist = B.take<int>(P); L->bcount = L->cls_count + PDE_MAX_CLASS + 1;
+    L->img16 = B.take<float4>(PRE16_IMAGE_BYTES / 16);
     L->dcount = B.take<int>(16);
     L->vel_frag = B.take<float>(VEL_FRAG_FLOATS); L->a_frag = B.take<float>(VEL_FRAG_FLOATS);
     L->vel_x4 = B.take<float>(VEL_X4_FLOATS);
@@ -628,8 +632,18 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
     // fused jet kernels (pde_jet.hip; NVFI_PDE_JET=0 keeps the column kernels for every column): x4 copies of the v-net fragments
     static int use_jet = -1;
     if (use_jet < 0) { const char* e = getenv("NVFI_PDE_JET"); use_jet = e ? atoi(e) : 1; }
+    // prefilter mode: fp32 (default) | fp16band (pre16.hip: fp16-input pass + fp32 re-evaluation of the unsafe points) | split32
+    // (the whole fp32 prefilter on the feature-split kernel of vel_split.hip: same numbers, for measurements)
+    static int pre16 = -1; static float band16 = 0.1f, eps16 = 2e-3f;
+    if (pre16 < 0) {
+        const char* e = getenv("NVFI_PDE_PREFILTER");
+        if (e && strcmp(e, "fp16band") && strcmp(e, "fp32") && strcmp(e, "split32")) return nvfi_fail(2, "NVFI_PDE_PREFILTER must be fp32, fp16band or split32");
+        pre16 = !e ? 0 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "split32") ? 2 : 0));
+        if ((e = getenv("NVFI_PDE_BAND"))) band16 = (float)atof(e);
+        if ((e = getenv("NVFI_PDE_GATE_EPS"))) eps16 = (float)atof(e);
+    }
     const float4* f4[6] = {nullptr}; const float4* t4[6] = {nullptr};
-    if (use_jet) {
+    if (use_jet || pre16) {
         X4Jobs xj; xj.n = 0;
         float* p = L.vel_x4;
         auto add = [&](const float* src, int MT, int NS, const float4** slot) {
@@ -651,16 +665,39 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
     hipLaunchKernelGGL(k_pde_bucket, dim3(pb), dim3(256), 0, st, P, L.cls, L.rank, L.cls_count, L.perm, L.pt_t_perm, L.pt_base_perm, L.pt_t, L.pt_base);
     LAUNCHCK();
     // RK2 back-advection in bucket order (per-point times)
-    {
-        Rk2Args ra; memset(&ra, 0, sizeof(ra));
-        ra.f = *f; ra.Wv = VW; ra.count = nullptr; ra.n_direct = P; ra.list = L.perm; ra.xw = L.xw; ra.xout = nullptr;
-        ra.pt_t = L.pt_t_perm; ra.pt_base = L.pt_base_perm; ra.dt_max = dt_max_of(*f); ra.max_steps = PDE_MAX_CLASS;
-        if (launch_rk2_fwd(ra, P, false, false, st)) return 1;
-    }
     const int64_t nw = (P + 63) / 64;
-    {
-        DensityArgs da; memset(&da, 0, sizeof(da));
-        da.f = *f; da.n_direct = P; da.xw = L.xw; da.per_point_t = 1; da.sigma_out = L.sig;
+    Rk2Args ra; memset(&ra, 0, sizeof(ra));
+    ra.f = *f; ra.Wv = VW; ra.xw = L.xw; ra.xout = nullptr; ra.dt_max = dt_max_of(*f); ra.max_steps = PDE_MAX_CLASS;
+    DensityArgs da; memset(&da, 0, sizeof(da));
+    da.f = *f; da.per_point_t = 1; da.sigma_out = L.sig;
+    SplitArgs sa; memset(&sa, 0, sizeof(sa));
+    sa.f = *f; sa.xw = L.xw; sa.dt_max = ra.dt_max; sa.max_steps = PDE_MAX_CLASS;
+    for (int l = 0; l < 6; ++l) { sa.f4[l] = f4[l]; sa.bv[l] = VW.b[l]; }
+    if (pre16 == 2) {
+        sa.count = nullptr; sa.n_direct = P; sa.list = L.perm; sa.pt_t = L.pt_t_perm; sa.pt_base = L.pt_base_perm;
+        if (launch_rk2_split(sa, P, 1, st)) return 1;
+        da.n_direct = P; da.xw = L.xw;
+        if (launch_density_q(da, P, st)) return 1;
+    } else if (!pre16) {
+        ra.count = nullptr; ra.n_direct = P; ra.list = L.perm; ra.pt_t = L.pt_t_perm; ra.pt_base = L.pt_base_perm;
+        if (launch_rk2_fwd(ra, P, false, false, st)) return 1;
+        da.n_direct = P; da.xw = L.xw;
+        if (launch_density_q(da, P, st)) return 1;
+    } else {
+        // opt-in (pre16.hip): fp16-input pass over every candidate, then the fp32 kernel for the points whose decision is not safe
+        Pre16Args qa; memset(&qa, 0, sizeof(qa));
+        qa.f = *f; qa.img = L.img16; qa.P = P; qa.list = L.perm; qa.xw = L.xw; qa.xout = L.xw16; qa.near = L.near;
+        qa.pt_t = L.pt_t_perm; qa.pt_base = L.pt_base_perm; qa.dt_max = ra.dt_max; qa.max_steps = PDE_MAX_CLASS; qa.eps_gate = eps16;
+        if (launch_pre16(f, qa, st)) return 1;
+        da.n_direct = P; da.xw = L.xw16;
+        if (launch_density_q(da, P, st)) return 1;
+        if (launch_pde_band(f, P, L.perm, L.sig, L.near, band16, L.flags, L.cnt, st)) return 1;
+        launch_scan_fill(L.cnt, L.off, nw, L.bcount, L.flags, L.blist, st);
+        if (launch_pde_band_map(P, L.bcount, L.perm, L.blist, st)) return 1;
+        // short list, long trajectories: the feature-split kernel (a tile's latency, not the chip's throughput, bounds this pass)
+        sa.count = L.bcount; sa.list = L.blist; sa.pt_t = L.pt_t; sa.pt_base = L.pt_base; sa.pt_by_list = 1;
+        if (launch_rk2_split(sa, P, 0, st)) return 1;
+        da.count = L.bcount; da.list = L.blist; da.xw = L.xw;
         if (launch_density_q(da, P, st)) return 1;
     }
     hipLaunchKernelGGL(k_pde_keep, dim3(pb), dim3(256), 0, st, *f, P, L.sig, L.flags, L.cnt);
@@ -718,7 +755,7 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
     hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, L.kcount, out);
     LAUNCHCK();
     if (counters) {
-        hipLaunchKernelGGL(k_pde_counters, dim3(1), dim3(64), 0, st, L.cls_count, L.kcount, P, counters);
+        hipLaunchKernelGGL(k_pde_counters, dim3(1), dim3(64), 0, st, L.cls_count, L.kcount, P, pre16 == 1, counters);
         LAUNCHCK();
     }
     return 0;

@@ -1,0 +1,214 @@
+// pre16.hip - OPT-IN fp16-input pre-pass of the PDE occupancy prefilter (NVFI_PDE_PREFILTER=fp16band; fp32 stays the default).
+//
+// The prefilter (reference models/nvfi.py:50-64) only DECIDES which collocation points take part in the PDE loss: RK2
+// back-advection (models/tensorf_keyframe.py:575-611), density at the warped point, alpha >= alphaMask_thres.  The decision is
+// insensitive to small position errors except for points whose alpha lies next to the threshold or whose trajectory passes next
+// to a face of the velocity gate (velocity_field.py:28-33,46-51), where a rounding difference flips a branch.  So:
+//   1. k_rk2_pre16 back-advects EVERY candidate with v_mfma_f32_32x32x16_f16 (weights and layer inputs rounded to fp16, fp32
+//      accumulation; encoder, SiLU, basis combination and the RK2 arithmetic in fp32) and flags the points that came within
+//      `eps_gate` of a gate face (or of the rejection box of VelocityAABBSur) at any stage;
+//   2. pde.hip evaluates the density there, puts the flagged points and those with |alpha / thres - 1| <= band on a list,
+//      re-runs the fp32 kernel (k_rk2_fwd, vel.hip) for that list only and takes their density from the fp32 position.
+// Every kept/dropped decision therefore comes either from the fp32 path or from an alpha that is further from the threshold
+// than the band (measured fp16 deviation of alpha: <= 1.2 % on 3 x 10^6 points, tests/studies/prefilter_fp16_study.py; default
+// band 10 %).  The kept points' jets, loss and gradients are computed in fp32 from the ORIGINAL coordinates as before.
+//
+// MI355X layout: in fp16 the whole 6-layer net is 144 KB of fragments + 3 KB of biases, so it is staged into the CU's 160 KB LDS
+// ONCE per workgroup and there is no barrier after that: 8 waves (2 per SIMD) walk their own 32-point tiles independently, one
+// wave's SiLU/encoder VALU work overlapping the other's MFMAs.  The kernel is bound by the SiLU transcendentals, not by MFMA.
+#include "common.h"
+#include "vel.h"
+#include "pde.h"
+#include "engine16.h"
+
+#define P16_THREADS 512
+#define P16_L0 0                                   // 4 tiles x 2 K-steps x 64 lanes (h8 units)
+#define P16_LH(l) (512 + ((l) - 1) * 2048)          // l = 1..4: 4 x 8 x 64
+#define P16_L5 (512 + 4 * 2048)                     // 1 x 8 x 64
+#define P16_H8 (512 + 4 * 2048 + 512)
+static_assert(P16_H8 * 16 + 6 * 128 * 4 == PRE16_IMAGE_BYTES, "image size");
+
+// ---------------------------------------------------------------- packing: the LDS image, built in global memory once per call
+struct Pack16VelArgs { const float* W[6]; const float* b[6]; h8_t* img; };
+__global__ __launch_bounds__(256) void k_pack_vel16(Pack16VelArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < P16_H8) {
+        int l, local, NS, out, in, kind;
+        if (idx < 512) { l = 0; local = idx; NS = 2; out = 128; in = 28; kind = SK_VEL_IN; }
+        else if (idx < P16_L5) { l = 1 + (idx - 512) / 2048; local = (idx - 512) % 2048; NS = 8; out = 128; in = 128; kind = SK_HIDDEN; }
+        else { l = 5; local = idx - P16_L5; NS = 8; out = 6; in = 128; kind = SK_HIDDEN; }
+        const int lane = local & 63, ms = local >> 6, s = ms % NS, m = ms / NS;
+        const int row = 32 * m + (lane & 31), h = lane >> 5;
+        const float* W = a.W[l];
+        h8_t v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int feat = slot_logical(kind, 2 * (8 * s + j) + h);     // register 8s + j of lane half h (engine.h)
+            float w = 0.f;
+            if (row < out && feat >= 0 && feat < in) w = W[(size_t)row * in + feat];
+            v[j] = (_Float16)w;
+        }
+        a.img[idx] = v;
+    }
+    if (idx < 6 * 128) {
+        const int l = idx >> 7, row = idx & 127;
+        float* bias = reinterpret_cast<float*>(a.img + P16_H8);
+        bias[idx] = row < (l < 5 ? 128 : 6) ? a.b[l][row] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------- one layer: MT output tiles, NS K-steps; the epilogue of tile
+// m - 1 is issued behind the MFMAs of tile m (independent work for the scheduler, as in engine.h's layer_tiles)
+template <int MT, int NS, class Epi>
+__device__ __forceinline__ void layer16p(const h8_t* w, const float* bias, int lane, int h, const h8_t* B, Epi epi) {
+    f32x16 prev;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias[32 * m + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc = MFMA16(w[(m * NS + s) * 64 + lane], B[s], acc);
+        if (m > 0) epi(m - 1, prev);
+        prev = acc;
+    }
+    epi(MT - 1, prev);
+}
+
+// gated VelBasis.get_vel weights (velocity_field.py:77-93) of the wave's 32 points; out4 as velnet_forward (engine.h)
+__device__ __forceinline__ void velnet16(const h8_t* W, const float* bias, int lane, int h, const float4& q, float* out4) {
+    float xa[64], xb[64];
+    h8_t B[8];
+    vel_encode_slots(q, h, xb);
+    to_h8<2>(xb, B);
+    layer16p<4, 2>(W + P16_L0, bias, lane, h, B, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xa[16 * m + r] = act_f<1>(acc[r]);
+    });
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+        const int l = 1 + 2 * it;
+        to_h8<8>(xa, B);
+        layer16p<4, 8>(W + P16_LH(l), bias + 128 * l, lane, h, B, [&](int m, const f32x16& acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xb[16 * m + r] = act_f<1>(acc[r]);
+        });
+        to_h8<8>(xb, B);
+        layer16p<4, 8>(W + P16_LH(l + 1), bias + 128 * (l + 1), lane, h, B, [&](int m, const f32x16& acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xa[16 * m + r] = act_f<1>(acc[r]);
+        });
+    }
+    to_h8<8>(xa, B);
+    layer16p<1, 8>(W + P16_L5, bias + 128 * 5, lane, h, B, [&](int, const f32x16& acc) {
+        out4[0] = acc[0]; out4[1] = acc[1]; out4[2] = acc[2]; out4[3] = acc[3];
+    });
+}
+
+__device__ __forceinline__ bool near_gate(const nvfi_field_desc& f, float eps, float x, float y, float z) {
+    return fabsf(x - f.gate_lo[0]) < eps || fabsf(x - f.gate_hi[0]) < eps || fabsf(y - f.gate_lo[1]) < eps || fabsf(y - f.gate_hi[1]) < eps ||
+           fabsf(z - f.gate_lo[2]) < eps || fabsf(z - f.gate_hi[2]) < eps;
+}
+
+// same recurrence as k_rk2_fwd<false, false> (vel.hip), per wave instead of per workgroup
+__global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_pre16(Pre16Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.img);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < PRE16_IMAGE_BYTES / 16; i += P16_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const h8_t* W = reinterpret_cast<const h8_t*>(lds);
+    const float* bias = lds + P16_H8 * 4;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * (P16_THREADS / 64) + (threadIdx.x >> 6);
+    const int64_t i = tile * TILE + (lane & 31);
+    if (tile * TILE >= a.P) return;                     // wave-uniform; no barrier follows
+    const bool active = i < a.P;
+    const int n = active ? a.list[i] : 0;
+    const float4 q0 = active ? a.xw[n] : zero4();
+    float x = q0.x, y = q0.y, z = q0.z;
+    float tcur = active ? a.pt_t[i] : 0.f;
+    float off = active ? tcur - a.pt_base[i] : 0.f;
+    bool near = false;
+#pragma unroll 1
+    for (int s = 0; s < a.max_steps; ++s) {
+        const bool live = fabsf(off) > 0.f;
+        if (!__any(live)) break;
+        const float m = fminf(fabsf(off), a.dt_max);
+        const float dt = off > 0.f ? m : (off < 0.f ? -m : 0.f);
+        float o4[4], w1[6], w2[6], v1[3], v2[3];
+        velnet16(W, bias, lane, h, make_float4(x, y, z, tcur), o4);
+        gather6(o4, h, w1);
+        vel_from_w(w1, x, y, z, v1);
+        if (gated_out(a.f, x, y, z)) { v1[0] = v1[1] = v1[2] = 0.f; }
+        const float hdt = 0.5f * dt;
+        const float px = x - hdt * v1[0], py = y - hdt * v1[1], pz = z - hdt * v1[2];
+        velnet16(W, bias, lane, h, make_float4(px, py, pz, tcur - hdt), o4);
+        gather6(o4, h, w2);
+        vel_from_w(w2, px, py, pz, v2);
+        if (gated_out(a.f, px, py, pz)) { v2[0] = v2[1] = v2[2] = 0.f; }
+        const float nx = x - dt * v2[0], ny = y - dt * v2[1], nz = z - dt * v2[2];
+        const bool rej = a.f.gate_sur && gated_out(a.f, nx, ny, nz);
+        if (live) {
+            near = near || near_gate(a.f, a.eps_gate, x, y, z) || near_gate(a.f, a.eps_gate, px, py, pz) ||
+                   (a.f.gate_sur && near_gate(a.f, a.eps_gate, nx, ny, nz));
+            if (!rej) { x = nx; y = ny; z = nz; }
+            off = off - dt; tcur = tcur - dt;
+        }
+    }
+    if (active && h == 0) { a.xout[n] = make_float4(x, y, z, q0.w); a.near[n] = near ? 1 : 0; }
+}
+
+// alpha at the fp16-warped point: flags = 1 for the points whose decision is left to the fp32 pass.  Walks the points in BUCKET
+// order (perm: most RK2 steps first), so the compacted list keeps the workgroups of the fp32 pass homogeneous in step count.
+__global__ __launch_bounds__(256) void k_pde_band(nvfi_field_desc f, int64_t P, const int* perm, const float* sig, const uint8_t* near,
+                                                  float band, uint8_t* flags, int* cnt) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool b = false;
+    if (i < P) {
+        const int n = perm[i];
+        const float alpha = 1.f - expf(-sig[n] * 0.01f * 25.f);
+        b = near[n] || fabsf(alpha - f.alpha_thres) <= band * f.alpha_thres || !(alpha == alpha);
+        flags[i] = b ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(b);
+    if ((threadIdx.x & 63) == 0 && i < P) cnt[i >> 6] = __popcll(m);
+}
+
+int launch_pre16(const nvfi_field_desc* f, Pre16Args a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_pre16, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
+        attr = true;
+    }
+    Pack16VelArgs pk;
+    for (int l = 0; l < 6; ++l) { pk.W[l] = f->vW[l]; pk.b[l] = f->vb[l]; }
+    pk.img = reinterpret_cast<h8_t*>(a.img);
+    hipLaunchKernelGGL(k_pack_vel16, dim3((P16_H8 + 255) / 256), dim3(256), 0, st, pk);
+    const int64_t tiles = (a.P + TILE - 1) / TILE;
+    const unsigned wgs = (unsigned)((tiles + P16_THREADS / 64 - 1) / (P16_THREADS / 64));
+    {
+        ProfScope ps(PK_PDE_PREFILTER, st);
+        hipLaunchKernelGGL(k_rk2_pre16, dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+    }
+    LAUNCHCK();
+    return 0;
+}
+int launch_pde_band(const nvfi_field_desc* f, int64_t P, const int* perm, const float* sig, const uint8_t* near, float band, uint8_t* flags,
+                    int* cnt, hipStream_t st) {
+    hipLaunchKernelGGL(k_pde_band, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, *f, P, perm, sig, near, band, flags, cnt);
+    LAUNCHCK();
+    return 0;
+}
+// bucket positions -> point indices, in place
+__global__ __launch_bounds__(256) void k_pde_band_map(const int* bcount, const int* perm, int* blist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *bcount) blist[i] = perm[blist[i]];
+}
+int launch_pde_band_map(int64_t P, const int* bcount, const int* perm, int* blist, hipStream_t st) {
+    hipLaunchKernelGGL(k_pde_band_map, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, bcount, perm, blist);
+    LAUNCHCK();
+    return 0;
+}

@@ -29,6 +29,7 @@ struct Rk2Args {
     float tcur[MAX_RK_STEPS];
     // per-point mode
     const float* pt_t; const float* pt_base; float dt_max; int max_steps;
+    int pt_by_list;        // pt_t / pt_base are indexed by the dense index list[i] instead of the compact index i
     // stashes (training)
     float* zst; float* x0st; float* rec; float* gst;
     int64_t cap; int64_t cap_tiles;

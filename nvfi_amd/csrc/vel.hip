@@ -55,8 +55,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_fwd(Rk2Args a) {
     float x = q0.x, y = q0.y, z = q0.z;
     float off = 0.f, tcur = 0.f;
     if (!UNIFORM) {
-        tcur = active ? a.pt_t[i] : 0.f;
-        off = active ? tcur - a.pt_base[i] : 0.f;
+        const int ti = a.pt_by_list ? n : i;
+        tcur = active ? a.pt_t[ti] : 0.f;
+        off = active ? tcur - a.pt_base[ti] : 0.f;
     }
     const int nsteps = UNIFORM ? a.nsteps : a.max_steps;
 #pragma unroll 1

@@ -1,0 +1,180 @@
+// vel_split.hip - per-point RK2 back-advection (reference models/tensorf_keyframe.py:575-611 around the gated VelBasis of
+// models/velocity_field.py:21-98) with ONE 32-point tile per workgroup and the network's FEATURES split over the four waves.
+//
+// k_rk2_fwd (vel.hip) gives every wave its own tile: best throughput per staged weight byte, but a tile's latency is the whole
+// network on one SIMD (~100 k cycles per evaluation), which is what a SHORT list of points pays however few they are - the fp32
+// re-evaluation list behind the fp16 pre-pass of the PDE prefilter (pre16.hip) is such a list.  Here wave w owns output rows
+// [32w, 32w + 32) of every hidden layer (one MFMA tile, the x4 weight fragments of pde_jet.hip read straight from L2 into
+// registers one layer ahead), the four 32-row slices meet in a 16 KB LDS exchange buffer between layers, and the 128 -> 6 output
+// layer is contracted by one wave (rotating with the workgroup index) and broadcast through LDS.  A tile's latency drops ~3.5x.
+//
+// Every accumulator sees the same operands in the same K order as in engine.h's layer_tiles, and every wave carries the same
+// replicated RK2 state, so the result is bit-identical to k_rk2_fwd<false, false>.
+#include "common.h"
+#include "vel.h"
+#include "pde.h"
+
+#define SPLIT_XCH_F4 (16 * 64)              // [s/4][lane] float4: one layer's 128 features x 32 points
+#define SPLIT_LDS_BYTES(NT) ((NT) * (SPLIT_XCH_F4 * 16 + 4 * 64 * 4))
+
+template <int NS4>
+__device__ __forceinline__ void split_load(const float4* __restrict__ a4, int lane, float4* wq) {
+#pragma unroll
+    for (int g = 0; g < NS4; ++g) wq[g] = a4[g * 64 + lane];
+}
+template <int NS4, int NT, int XS>
+__device__ __forceinline__ void split_mfma(const float4* wq, const float (&x)[NT][XS], f32x16* acc) {
+#pragma unroll
+    for (int g = 0; g < NS4; ++g) {
+        const float av[4] = {wq[g].x, wq[g].y, wq[g].z, wq[g].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = MFMA32(av[k], x[t][4 * g + k], acc[t]);
+    }
+}
+
+// one gated-velocity network evaluation of the workgroup's NT tiles; all four waves return the same out4 (lane h=0: w0..w3,
+// h=1: w4, w5) per tile
+template <int NT>
+__device__ __forceinline__ void velnet_split(const SplitArgs& a, float4* xch, float* bc, int w, int owner, int lane, int h,
+                                             const float4* q, float4* wq, float (&out4)[NT][4]) {
+    float x[NT][64];
+    f32x16 acc[NT];
+    {
+        float in0[NT][16];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            vel_encode_slots(q[t], h, in0[t]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = a.bv[0][32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+        }
+        split_mfma<4, NT, 16>(wq, in0, acc);             // wq holds layer 0 (loaded by the caller / the previous evaluation)
+    }
+#pragma unroll 1
+    for (int l = 0; l < 5; ++l) {
+        // the next layer's weights start their trip from L2 now; they land behind the epilogue and the exchange
+        if (l < 4) split_load<16>(a.f4[l + 1] + (size_t)w * 16 * 64, lane, wq);
+        else if (w == owner) split_load<16>(a.f4[5], lane, wq);
+        __syncthreads();                                 // the previous exchange's readers are done
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                xch[(t * 16 + 4 * w + k) * 64 + lane] = make_float4(act_f<1>(acc[t][4 * k]), act_f<1>(acc[t][4 * k + 1]), act_f<1>(acc[t][4 * k + 2]),
+                                                                    act_f<1>(acc[t][4 * k + 3]));
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4) {
+                const float4 v = xch[(t * 16 + s4) * 64 + lane];
+                x[t][4 * s4] = v.x; x[t][4 * s4 + 1] = v.y; x[t][4 * s4 + 2] = v.z; x[t][4 * s4 + 3] = v.w;
+            }
+        if (l < 4) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = a.bv[l + 1][32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+            split_mfma<16, NT, 64>(wq, x, acc);
+        }
+    }
+    if (w == owner) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = a.bv[5][(r & 3) + 8 * (r >> 2) + 4 * h];
+        split_mfma<16, NT, 64>(wq, x, acc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bc[(t * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    // layer 0 of the NEXT evaluation (the caller stops using wq before that)
+    split_load<4>(a.f4[0] + (size_t)w * 4 * 64, lane, wq);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out4[t][r] = bc[(t * 4 + r) * 64 + lane];
+}
+
+template <int NT>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* xch = reinterpret_cast<float4*>(lds);
+    float* bc = lds + NT * SPLIT_XCH_F4 * 4;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int owner = blockIdx.x & 3;
+    const int count = a.count ? *a.count : (int)a.n_direct;
+    if ((int)blockIdx.x * NT * TILE >= count) return;
+    bool active[NT]; int n[NT]; float x[NT], y[NT], z[NT], zw[NT], tcur[NT], off[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int i = (blockIdx.x * NT + t) * TILE + (lane & 31);
+        active[t] = i < count;
+        n[t] = active[t] ? (a.list ? a.list[i] : i) : 0;
+        const float4 q0 = active[t] ? a.xw[n[t]] : zero4();
+        x[t] = q0.x; y[t] = q0.y; z[t] = q0.z; zw[t] = q0.w;
+        const int ti = a.pt_by_list ? n[t] : i;
+        tcur[t] = active[t] ? a.pt_t[ti] : 0.f;
+        off[t] = active[t] ? tcur[t] - a.pt_base[ti] : 0.f;
+    }
+    float4 wq[16];
+    split_load<4>(a.f4[0] + (size_t)w * 4 * 64, lane, wq);
+#pragma unroll 1
+    for (int s = 0; s < a.max_steps; ++s) {
+        bool live[NT], any = false;
+        float dt[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            live[t] = active[t] && fabsf(off[t]) > 0.f;
+            any = any || live[t];
+            const float m = fminf(fabsf(off[t]), a.dt_max);
+            dt[t] = off[t] > 0.f ? m : (off[t] < 0.f ? -m : 0.f);
+        }
+        if (!__any(any)) break;                           // the same decision in all four waves (replicated state)
+        float o4[NT][4], px[NT], py[NT], pz[NT];
+        float4 q[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur[t]);
+        velnet_split<NT>(a, xch, bc, w, owner, lane, h, q, wq, o4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float w1[6], v1[3];
+            gather6(o4[t], h, w1);
+            vel_from_w(w1, x[t], y[t], z[t], v1);
+            if (gated_out(a.f, x[t], y[t], z[t])) { v1[0] = v1[1] = v1[2] = 0.f; }
+            const float hdt = 0.5f * dt[t];
+            px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
+            q[t] = make_float4(px[t], py[t], pz[t], tcur[t] - hdt);
+        }
+        velnet_split<NT>(a, xch, bc, w, owner, lane, h, q, wq, o4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float w2[6], v2[3];
+            gather6(o4[t], h, w2);
+            vel_from_w(w2, px[t], py[t], pz[t], v2);
+            if (gated_out(a.f, px[t], py[t], pz[t])) { v2[0] = v2[1] = v2[2] = 0.f; }
+            const float nx = x[t] - dt[t] * v2[0], ny = y[t] - dt[t] * v2[1], nz = z[t] - dt[t] * v2[2];
+            const bool rej = a.f.gate_sur && gated_out(a.f, nx, ny, nz);   // tensorf_keyframe.py:603-605
+            if (live[t] && !rej) { x[t] = nx; y[t] = ny; z[t] = nz; }
+            if (live[t]) { off[t] = off[t] - dt[t]; tcur[t] = tcur[t] - dt[t]; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (active[t] && h == 0 && w == 0) a.xw[n[t]] = make_float4(x[t], y[t], z[t], zw[t]);
+}
+
+// wide = 0: one tile per workgroup (shortest latency: short lists); wide = 1: two tiles per workgroup share every weight load
+int launch_rk2_split(const SplitArgs& a, int64_t cap_points, int wide, hipStream_t st) {
+    const int64_t tiles = (cap_points + TILE - 1) / TILE;
+    if (tiles <= 0) return 0;
+    ProfScope ps(PK_PDE_PREFILTER, st);
+    if (wide) hipLaunchKernelGGL(k_rk2_split<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(WG_THREADS), SPLIT_LDS_BYTES(2), st, a);
+    else hipLaunchKernelGGL(k_rk2_split<1>, dim3((unsigned)tiles), dim3(WG_THREADS), SPLIT_LDS_BYTES(1), st, a);
+    LAUNCHCK();
+    return 0;
+}

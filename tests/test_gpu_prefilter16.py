@@ -1,0 +1,64 @@
+"""Opt-in fp16 pre-pass of the PDE occupancy prefilter (NVFI_PDE_PREFILTER=fp16band, nvfi_amd/csrc/pre16.hip): the kept mask
+(reference models/nvfi.py:50-64) must be IDENTICAL to the fp32 prefilter's on every field, so loss and gradients - computed in
+fp32 from the original coordinates of the kept points either way - agree to the order of the atomics."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(tmp_path, mode, extra=(), n=262144):
+    out = str(tmp_path / f"pre16_{mode}_{n}.npz")
+    env = dict(os.environ, NVFI_PDE_PREFILTER=mode)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pre16_check.py"), out, str(n), *extra], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return np.load(out)
+
+
+def test_fp16band_prefilter_keeps_exactly_the_fp32_set(tmp_path):
+    a, b = _run(tmp_path, "fp32", ("--bench",)), _run(tmp_path, "fp16band", ("--bench",))
+    for name in ("A", "B", "cfg1", "bench"):
+        ka, kb = a[f"{name}:kept"], b[f"{name}:kept"]
+        P = ka.size
+        band = int(b[f"{name}:counters"][5])
+        print(f"{name}: kept {int(ka.sum())} of {P}; fp32 re-evaluations behind the fp16 pass: {band} ({100.0 * band / P:.2f} %); "
+              f"get_vel_loss {float(a[f'{name}:ms']):.3f} ms fp32 -> {float(b[f'{name}:ms']):.3f} ms fp16band")
+        assert int(a[f"{name}:counters"][5]) == 0
+        assert np.array_equal(ka, kb), (name, int((ka != kb).sum()))
+        assert 0 < band < 0.08 * P, (name, band)
+        assert int(a[f"{name}:counters"][4]) == int(b[f"{name}:counters"][4]) == int(ka.sum())
+        np.testing.assert_allclose(float(a[f"{name}:loss"]), float(b[f"{name}:loss"]), rtol=1e-5)
+        for k in a.files:
+            if k.startswith(f"{name}:grad:"):
+                assert relerr(b[k], a[k]) < 2e-5, k
+
+
+@pytest.mark.parametrize("n", [37, 1000])
+def test_fp16band_ragged_point_counts(tmp_path, n):
+    a, b = _run(tmp_path, "fp32", n=n), _run(tmp_path, "fp16band", n=n)
+    for name in ("A", "B", "cfg1"):
+        assert np.array_equal(a[f"{name}:kept"], b[f"{name}:kept"]), name
+        np.testing.assert_allclose(float(a[f"{name}:loss"]), float(b[f"{name}:loss"]), rtol=1e-5)
+
+
+def test_split32_prefilter_is_the_fp32_prefilter(tmp_path):
+    """vel_split.hip (the kernel behind the fp32 re-evaluation list) run over EVERY candidate: bit-identical positions, hence masks"""
+    a, b = _run(tmp_path, "fp32"), _run(tmp_path, "split32")
+    for name in ("A", "B", "cfg1"):
+        print(f"{name}: get_vel_loss {float(a[f'{name}:ms']):.3f} ms fp32 -> {float(b[f'{name}:ms']):.3f} ms split32")
+        assert np.array_equal(a[f"{name}:kept"], b[f"{name}:kept"]), name
+        np.testing.assert_allclose(float(a[f"{name}:loss"]), float(b[f"{name}:loss"]), rtol=1e-5)
+
+
+def test_unknown_prefilter_mode_is_refused(tmp_path):
+    out = str(tmp_path / "x.npz")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pre16_check.py"), out, "1024"], env=dict(os.environ, NVFI_PDE_PREFILTER="bf16"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "NVFI_PDE_PREFILTER" in (r.stdout + r.stderr)
