@@ -10,12 +10,13 @@
 //
 // Every accumulator sees the same operands in the same K order as in engine.h's layer_tiles, and every wave carries the same
 // replicated RK2 state, so the result is bit-identical to k_rk2_fwd<false, false>.
+#include <stdlib.h>
 #include "common.h"
 #include "vel.h"
 #include "pde.h"
 
 #define SPLIT_XCH_F4 (16 * 64)              // [s/4][lane] float4: one layer's 128 features x 32 points
-#define SPLIT_LDS_BYTES(NT) ((NT) * (SPLIT_XCH_F4 * 16 + 4 * 64 * 4))
+#define SPLIT_LDS_BYTES(NT) ((NT) * (SPLIT_XCH_F4 * 16 + 4 * 64 * 4) + 6 * 128 * 4)
 
 template <int NS4>
 __device__ __forceinline__ void split_load(const float4* __restrict__ a4, int lane, float4* wq) {
@@ -34,29 +35,56 @@ __device__ __forceinline__ void split_mfma(const float4* wq, const float (&x)[NT
     }
 }
 
+// the same with the B operands streamed from the exchange buffer (one 16-byte LDS read per tile and 4 K-steps): no register copy of
+// the layer input, so four tiles fit a wave and every 16-byte weight load feeds 16 MFMAs
+template <int NT>
+__device__ __forceinline__ void split_mfma_lds(const float4* wq, const float4* xl, int tile0, f32x16* acc) {
+    float4 b[NT], bn[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = xl[((tile0 + t) * 16) * 64];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        if (g + 1 < 16) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bn[t] = xl[((tile0 + t) * 16 + g + 1) * 64];
+        }
+        const float av[4] = {wq[g].x, wq[g].y, wq[g].z, wq[g].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float bv = k == 0 ? b[t].x : (k == 1 ? b[t].y : (k == 2 ? b[t].z : b[t].w));
+                acc[t] = MFMA32(av[k], bv, acc[t]);
+            }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = bn[t];
+    }
+}
+
 // one gated-velocity network evaluation of the workgroup's NT tiles; all four waves return the same out4 (lane h=0: w0..w3,
 // h=1: w4, w5) per tile
 template <int NT>
 __device__ __forceinline__ void velnet_split(const SplitArgs& a, float4* xch, float* bc, int w, int owner, int lane, int h,
-                                             const float4* q, float4* wq, float (&out4)[NT][4]) {
-    float x[NT][64];
+                                             const float4* q, float4* wq, const float* lb, float (&out4)[NT][4]) {
     f32x16 acc[NT];
+    const float4* xl = xch + lane;
     {
         float in0[NT][16];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             vel_encode_slots(q[t], h, in0[t]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = a.bv[0][32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+            for (int r = 0; r < 16; ++r) acc[t][r] = lb[32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
         }
         split_mfma<4, NT, 16>(wq, in0, acc);             // wq holds layer 0 (loaded by the caller / the previous evaluation)
     }
+    const int mine = (w - owner) & 3;                    // the tile whose 128 -> 6 output layer this wave contracts (if < NT)
 #pragma unroll 1
     for (int l = 0; l < 5; ++l) {
         // the next layer's weights start their trip from L2 now; they land behind the epilogue and the exchange
         if (l < 4) split_load<16>(a.f4[l + 1] + (size_t)w * 16 * 64, lane, wq);
-        else if (w == owner) split_load<16>(a.f4[5], lane, wq);
-        __syncthreads();                                 // the previous exchange's readers are done
+        else if (mine < NT) split_load<16>(a.f4[5], lane, wq);
+        __syncthreads();                                 // the previous layer's readers of the exchange buffer are done
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -64,31 +92,22 @@ __device__ __forceinline__ void velnet_split(const SplitArgs& a, float4* xch, fl
                 xch[(t * 16 + 4 * w + k) * 64 + lane] = make_float4(act_f<1>(acc[t][4 * k]), act_f<1>(acc[t][4 * k + 1]), act_f<1>(acc[t][4 * k + 2]),
                                                                     act_f<1>(acc[t][4 * k + 3]));
         __syncthreads();
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int s4 = 0; s4 < 16; ++s4) {
-                const float4 v = xch[(t * 16 + s4) * 64 + lane];
-                x[t][4 * s4] = v.x; x[t][4 * s4 + 1] = v.y; x[t][4 * s4 + 2] = v.z; x[t][4 * s4 + 3] = v.w;
-            }
         if (l < 4) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = a.bv[l + 1][32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
-            split_mfma<16, NT, 64>(wq, x, acc);
+                for (int r = 0; r < 16; ++r) acc[t][r] = lb[128 * (l + 1) + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+            split_mfma_lds<NT>(wq, xl, 0, acc);
         }
     }
-    if (w == owner) {
+    // 128 -> 6 output layer: tile t is contracted by wave (owner + t) & 3 alone (one accumulator, K in layer_tiles' order)
+    if (mine < NT) {
+        f32x16 ao[1];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int r = 0; r < 16; ++r) ao[0][r] = lb[128 * 5 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        split_mfma_lds<1>(wq, xl, mine, ao);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = a.bv[5][(r & 3) + 8 * (r >> 2) + 4 * h];
-        split_mfma<16, NT, 64>(wq, x, acc);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bc[(t * 4 + r) * 64 + lane] = acc[t][r];
+        for (int r = 0; r < 4; ++r) bc[(mine * 4 + r) * 64 + lane] = ao[0][r];
     }
     // layer 0 of the NEXT evaluation (the caller stops using wq before that)
     split_load<4>(a.f4[0] + (size_t)w * 4 * 64, lane, wq);
@@ -123,6 +142,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
     }
     float4 wq[16];
     split_load<4>(a.f4[0] + (size_t)w * 4 * 64, lane, wq);
+    // the six bias vectors live in LDS for the whole kernel (3 KB; rows beyond a layer's width read as the fragment's zero padding)
+    float* lb = bc + NT * 4 * 64;
+    for (int k = threadIdx.x; k < 6 * 128; k += WG_THREADS) lb[k] = (k & 127) < (k < 640 ? 128 : 32) ? a.bv[k >> 7][k & 127] : 0.f;
+    __syncthreads();
 #pragma unroll 1
     for (int s = 0; s < a.max_steps; ++s) {
         bool live[NT], any = false;
@@ -139,7 +162,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
         float4 q[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur[t]);
-        velnet_split<NT>(a, xch, bc, w, owner, lane, h, q, wq, o4);
+        velnet_split<NT>(a, xch, bc, w, owner, lane, h, q, wq, lb, o4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float w1[6], v1[3];
@@ -150,7 +173,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
             px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
             q[t] = make_float4(px[t], py[t], pz[t], tcur[t] - hdt);
         }
-        velnet_split<NT>(a, xch, bc, w, owner, lane, h, q, wq, o4);
+        velnet_split<NT>(a, xch, bc, w, owner, lane, h, q, wq, lb, o4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float w2[6], v2[3];
@@ -173,7 +196,16 @@ int launch_rk2_split(const SplitArgs& a, int64_t cap_points, int wide, hipStream
     const int64_t tiles = (cap_points + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
     ProfScope ps(PK_PDE_PREFILTER, st);
-    if (wide) hipLaunchKernelGGL(k_rk2_split<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(WG_THREADS), SPLIT_LDS_BYTES(2), st, a);
+    if (wide) {
+        static int nt = -1;
+        if (nt < 0) {
+            const char* e = getenv("NVFI_SPLIT_NT"); nt = e ? atoi(e) : 4;
+            HIPCK(hipFuncSetAttribute((const void*)k_rk2_split<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES(4)));
+        }
+        if (nt == 1) hipLaunchKernelGGL(k_rk2_split<1>, dim3((unsigned)tiles), dim3(WG_THREADS), SPLIT_LDS_BYTES(1), st, a);
+        else if (nt == 4) hipLaunchKernelGGL(k_rk2_split<4>, dim3((unsigned)((tiles + 3) / 4)), dim3(WG_THREADS), SPLIT_LDS_BYTES(4), st, a);
+        else hipLaunchKernelGGL(k_rk2_split<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(WG_THREADS), SPLIT_LDS_BYTES(2), st, a);
+    }
     else hipLaunchKernelGGL(k_rk2_split<1>, dim3((unsigned)tiles), dim3(WG_THREADS), SPLIT_LDS_BYTES(1), st, a);
     LAUNCHCK();
     return 0;
