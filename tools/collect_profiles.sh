@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_k /tmp/prof_f /tmp/prof_w /tmp/prof_s
+rm -rf /tmp/prof_k /tmp/prof_k16 /tmp/prof_f /tmp/prof_w /tmp/prof_s
 # 0. plain bench lines (no profiler attached): default (with the CPU baseline), other drivers / workloads
 python $REPO/bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_line.err
 python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_line_3steps.json 2>/dev/null
@@ -16,6 +16,11 @@ NVFI_OVERLAP=0 python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_line_
 python $REPO/bench.py --live --no-cpu-baseline > $OUT/${TAG}_bench_line_live.json 2>/dev/null
 python $REPO/bench.py --mode dropin --no-cpu-baseline > $OUT/${TAG}_bench_line_dropin.json 2>/dev/null
 python $REPO/bench.py --workload cfg2 --no-cpu-baseline > $OUT/${TAG}_bench_line_cfg2.json 2>/dev/null
+# opt-in prefilter modes: fp16-input pre-pass with the fp32 band; the fp32 prefilter on the feature-split kernel
+NVFI_PDE_PREFILTER=fp16band python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_line_fp16band.json 2>/dev/null
+NVFI_PDE_PREFILTER=split32 NVFI_SPLIT_NT=2 python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_line_split32.json 2>/dev/null
+rocprofv3 --kernel-trace -d /tmp/prof_k16 -- env NVFI_PDE_PREFILTER=fp16band python $REPO/bench.py --no-cpu-baseline > /dev/null 2>&1
+python $REPO/tools/rocpd_stats.py $(find /tmp/prof_k16 -name "*.db" | head -1) $OUT/${TAG}_kernel_stats_fp16band.csv --after-marker > /dev/null
 # 1. kernel trace of the default bench command: per-kernel statistics of the whole run and of the profiled pass (after the marker)
 rocprofv3 --kernel-trace -d /tmp/prof_k -- python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1
 grep -a "^{" $OUT/${TAG}_prof.log > $OUT/${TAG}_bench_line_rocprof.json
