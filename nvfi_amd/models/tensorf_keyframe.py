@@ -101,7 +101,7 @@ class _RenderFn(torch.autograd.Function):
                     p.grad = torch.zeros_like(p)
                 grads.append(p.grad)
         else:
-            grads = [torch.zeros_like(p) if n else None for p, n in zip(params, need)]
+            grads = _zero_grads(params, need)
         G = field._grads_struct(grads)
         gs = [None if g is None else g.contiguous() for g in (g_rgb, g_depth, g_acc, g_weights)]
         R = rays_o.shape[0]
@@ -112,6 +112,23 @@ class _RenderFn(torch.autograd.Function):
         if inplace:
             return (None,) * (6 + len(params))
         return (None, None, None, None, None, None) + tuple(grads)
+
+
+def _zero_grads(params, need=None):
+    """Fresh zero gradients for `params` (None where `need` is false) as views of ONE zero-filled buffer: one fill launch per backward
+    node instead of one per parameter (the plain-autograd path of the reference's training loop is bound by the host's launch rate)."""
+    need = [True] * len(params) if need is None else list(need)
+    offs, total = [], 0
+    for p, n in zip(params, need):
+        offs.append(total)
+        if n:
+            total += (p.numel() + 63) // 64 * 64      # 256-byte aligned views (the plane-gradient kernels use 16-byte accesses)
+    if total == 0:
+        return [None] * len(params)
+    ref = next(p for p, n in zip(params, need) if n)
+    flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+    # same strides as the parameter (the planes are stored channel-last under an NCHW shape; all parameters are dense)
+    return [flat[o:o + p.numel()].as_strided(p.shape, p.stride()) if n else None for p, n, o in zip(params, need, offs)]
 
 
 class _PdeFn(torch.autograd.Function):
@@ -127,7 +144,7 @@ class _PdeFn(torch.autograd.Function):
         _lib.check(L.nvfi_pde_workspace_bytes(C.byref(desc), C.c_int64(P), C.byref(nbytes)))
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
         out = torch.zeros(4, device=dev)
-        grads = [torch.zeros_like(p) for p in params]
+        grads = _zero_grads(params)
         G = field._grads_struct_vel(grads)
         counters = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device=dev)
         kept = torch.zeros(P, dtype=torch.uint8, device=dev) if field.pde_debug else None
@@ -140,12 +157,19 @@ class _PdeFn(torch.autograd.Function):
         field.last_pde_n_kept = int(info[0])
         field.last_pde_out = out
         field.last_pde_counters = counters
-        ctx.save_for_backward(*grads)
+        ctx.save_for_backward(grads[0]._base)            # the one flat buffer behind the views
+        ctx.shapes = [(p.shape, p.stride()) for p in params]
         return out[0].clone()
 
     @staticmethod
     def backward(ctx, g):
-        return (None, None, None) + tuple(g * gr for gr in ctx.saved_tensors)
+        flat = ctx.saved_tensors[0] * g                  # one launch for all 24 tensors
+        out, o = [], 0
+        for shp, strides in ctx.shapes:
+            n = shp.numel()
+            out.append(flat[o:o + n].as_strided(shp, strides))
+            o += (n + 63) // 64 * 64
+        return (None, None, None) + tuple(out)
 
 
 class _RegFn(torch.autograd.Function):
@@ -173,13 +197,13 @@ class _RegFn(torch.autograd.Function):
         grads = [None] * 9
         cur = field._render_params()[:9]
         cur = cur[:3] + cur[3:6] + cur[6:9]
-        for k in touched:
-            if inplace:
+        if inplace:
+            for k in touched:
                 if cur[k].grad is None:
                     cur[k].grad = torch.zeros_like(cur[k])
                 grads[k] = cur[k].grad
-            else:
-                grads[k] = torch.zeros_like(planes[k])
+        else:
+            grads = _zero_grads(planes, [k in touched for k in range(9)])
         G = field._grads_struct(grads + [None] * 22)
         w3 = torch.zeros(3, device=g.device)
         w3[which] = g
