@@ -22,9 +22,11 @@ def _run(tmp_path, mode, extra=(), n=262144):
     return np.load(out)
 
 
-def test_fp16band_prefilter_keeps_exactly_the_fp32_set(tmp_path):
-    a, b = _run(tmp_path, "fp32", ("--bench",)), _run(tmp_path, "fp16band", ("--bench",))
-    for name in ("A", "B", "cfg1", "bench"):
+@pytest.mark.parametrize("n,extra", [(1000000, ()), (262144, ("--bench",))])
+def test_fp16band_prefilter_keeps_exactly_the_fp32_set(tmp_path, n, extra):
+    """10^6 random points on each of three fields (VERDICT r1 item 5 ii), and the bench field at the bench's 262 144"""
+    a, b = _run(tmp_path, "fp32", extra, n), _run(tmp_path, "fp16band", extra, n)
+    for name in ("A", "B", "cfg1") + (("bench",) if extra else ()):
         ka, kb = a[f"{name}:kept"], b[f"{name}:kept"]
         P = ka.size
         band = int(b[f"{name}:counters"][5])
@@ -46,6 +48,15 @@ def test_fp16band_ragged_point_counts(tmp_path, n):
     for name in ("A", "B", "cfg1"):
         assert np.array_equal(a[f"{name}:kept"], b[f"{name}:kept"]), name
         np.testing.assert_allclose(float(a[f"{name}:loss"]), float(b[f"{name}:loss"]), rtol=1e-5)
+
+
+def test_fp16band_prefilter_under_the_reference_goldens():
+    """the PDE goldens of the reference (kept mask, Jacobians, loss, gradients) with the opt-in prefilter"""
+    env = dict(os.environ, NVFI_PDE_PREFILTER="fp16band")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_fullsize_chessboard.py"), os.path.join(ROOT, "tests", "test_gpu_fullsize.py"), "-k", "pde"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_split32_prefilter_is_the_fp32_prefilter(tmp_path):
