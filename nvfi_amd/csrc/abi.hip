@@ -199,7 +199,7 @@ extern "C" int nvfi_selftest(float* max_err_host, void* stream) {
             if (e > me) me = e;
         }
     *max_err_host = me;
-    hipFree(dW); hipFree(dX); hipFree(dO); hipFree(dF);
+    (void)hipFree(dW); (void)hipFree(dX); (void)hipFree(dO); (void)hipFree(dF);
     delete[] hW; delete[] hX; delete[] hO;
     return 0;
 }

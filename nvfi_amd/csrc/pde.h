@@ -1,6 +1,7 @@
 // pde.h - argument blocks and stash geometry of the PDE kernels (pde.hip)
 #pragma once
 #include "common.h"
+#include "vel.h"
 
 #define PDE_MAX_CLASS 64           // RK2 step-count buckets
 #define PDE_CHUNK 262144           // kept points processed per pass (bounds the stash: 42 KB per point -> 11 GB of address space, touched only up to the kept count; sized for 288 GB of HBM)
@@ -62,6 +63,12 @@ struct SplitArgs {
     const float* pt_t; const float* pt_base; int pt_by_list; float dt_max; int max_steps;
 };
 int launch_rk2_split(const SplitArgs& a, int64_t cap_points, int wide, hipStream_t st);
+// the render warp on the same layout (uniform step sequence, optional training stash)
+#define VEL_X4F_FLOATS (X4_FLOATS(4, 14) + 4 * X4_FLOATS(4, 64) + X4_FLOATS(1, 64))     // forward fragments only
+struct SplitUniArgs { Rk2Args r; const float4* f4[6]; const float* bv[6]; };
+int launch_rk2_split_uni(const SplitUniArgs& a, int64_t cap_samples, bool stash, hipStream_t st);
+// x4 copies of the forward fragments of a packed VelFrags into buf (VEL_X4F_FLOATS); fills f4[6]
+int pack_vel_x4_fwd(const VelFrags& W, float* buf, const float4** f4, hipStream_t st);
 
 // opt-in fp16 pre-pass of the prefilter (pre16.hip)
 #define PRE16_IMAGE_BYTES 150528   // fp16 fragments of the six weight_net layers (144 KB) + fp32 biases: staged into LDS once per workgroup

@@ -632,13 +632,14 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
     // fused jet kernels (pde_jet.hip; NVFI_PDE_JET=0 keeps the column kernels for every column): x4 copies of the v-net fragments
     static int use_jet = -1;
     if (use_jet < 0) { const char* e = getenv("NVFI_PDE_JET"); use_jet = e ? atoi(e) : 1; }
-    // prefilter mode: fp32 (default) | fp16band (pre16.hip: fp16-input pass + fp32 re-evaluation of the unsafe points) | split32
-    // (the whole fp32 prefilter on the feature-split kernel of vel_split.hip: same numbers, for measurements)
+    // prefilter mode: fp32 (default: the feature-split kernel of vel_split.hip) | engine32 (k_rk2_fwd of vel.hip: the same numbers bit for
+    // bit, ~4 % slower) | fp16band (pre16.hip: fp16-input pass + fp32 re-evaluation of the unsafe points)
     static int pre16 = -1; static float band16 = 0.1f, eps16 = 2e-3f;
     if (pre16 < 0) {
         const char* e = getenv("NVFI_PDE_PREFILTER");
-        if (e && strcmp(e, "fp16band") && strcmp(e, "fp32") && strcmp(e, "split32")) return nvfi_fail(2, "NVFI_PDE_PREFILTER must be fp32, fp16band or split32");
-        pre16 = !e ? 0 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "split32") ? 2 : 0));
+        if (e && strcmp(e, "fp16band") && strcmp(e, "fp32") && strcmp(e, "split32") && strcmp(e, "engine32"))
+            return nvfi_fail(2, "NVFI_PDE_PREFILTER must be fp32, engine32 or fp16band");
+        pre16 = !e ? 2 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "engine32") ? 0 : 2));      // 2 = split kernel ("split32" = "fp32")
         if ((e = getenv("NVFI_PDE_BAND"))) band16 = (float)atof(e);
         if ((e = getenv("NVFI_PDE_GATE_EPS"))) eps16 = (float)atof(e);
     }

@@ -44,6 +44,20 @@ int launch_frag_x4(const X4Jobs& jobs, hipStream_t st) {
     return 0;
 }
 
+int pack_vel_x4_fwd(const VelFrags& W, float* buf, const float4** f4, hipStream_t st) {
+    X4Jobs xj; xj.n = 0;
+    float* p = buf;
+    auto add = [&](const float* src, int MT, int NS, const float4** slot) {
+        xj.src[xj.n] = src; xj.dst[xj.n] = p; xj.MT[xj.n] = MT; xj.NS[xj.n] = NS; ++xj.n;
+        *slot = reinterpret_cast<const float4*>(p);
+        p += X4_FLOATS(MT, NS);
+    };
+    add(W.f[0], 4, 14, &f4[0]);
+    for (int l = 1; l <= 4; ++l) add(W.f[l], 4, 64, &f4[l]);
+    add(W.f[5], 1, 64, &f4[5]);
+    return launch_frag_x4(xj, st);
+}
+
 #define JET_NC 5
 #define JET_XCH_FLOATS (JET_NC * 64 * 64)        // 80 KB: [column][s/4][lane][4]
 #define JET_LDS_BYTES (JET_XCH_FLOATS * 4)

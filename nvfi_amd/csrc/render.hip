@@ -12,6 +12,7 @@
 #include "common.h"
 #include "render.h"
 #include "scatter.h"
+#include "pde.h"
 #include <stdlib.h>
 
 // ================================================================ sampling + compaction
@@ -1002,7 +1003,7 @@ struct RenderPlan {
     uint8_t *valid, *mflag, *rflag;
     float4 *xw, *rgbs, *rgb_pre, *gxw, *gxk;
     float *xpre, *gxpre;
-    float *vel_frag, *render_frag;
+    float *vel_frag, *render_frag, *vel_x4;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     float *slabs;
     long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
@@ -1031,6 +1032,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->xw = B.take<float4>(N + 1); P->rgbs = B.take<float4>(N); P->rgb_pre = B.take<float4>(R);
     P->xpre = B.take<float>(N);
     P->vel_frag = B.take<float>(VEL_FRAG_FLOATS);
+    P->vel_x4 = nsteps > 0 ? B.take<float>(VEL_X4F_FLOATS) : nullptr;
     P->render_frag = B.take<float>(RENDER_FRAG_FLOATS);
     P->maskv = (flags & NVFI_WANT_MASK) ? B.take<float>(N * 32) : nullptr;
     P->mask_frag = (flags & NVFI_WANT_MASK) ? B.take<float>(64 * 1024) : nullptr;
@@ -1132,7 +1134,15 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
         ra.nsteps = nsteps;
         for (int s = 0; s < nsteps; ++s) { ra.dt[s] = dts[s]; ra.tcur[s] = tcs[s]; }
         ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles;
-        if (launch_rk2_fwd(ra, N, true, train, st)) return 1;
+        // the feature-split layout of vel_split.hip (NVFI_RK2_SPLIT=0: k_rk2_fwd of vel.hip; same stash, same numbers bit for bit)
+        static int split = -1;
+        if (split < 0) { const char* e = getenv("NVFI_RK2_SPLIT"); split = e ? atoi(e) : 1; }
+        if (split) {
+            SplitUniArgs ua; ua.r = ra;
+            if (pack_vel_x4_fwd(VW, P.vel_x4, ua.f4, st)) return 1;
+            for (int l = 0; l < 6; ++l) ua.bv[l] = VW.b[l];
+            if (launch_rk2_split_uni(ua, N, train, st)) return 1;
+        } else if (launch_rk2_fwd(ra, N, true, train, st)) return 1;
     }
     // density
     DensityArgs da; memset(&da, 0, sizeof(da));

@@ -63,9 +63,12 @@ __device__ __forceinline__ void split_mfma_lds(const float4* wq, const float4* x
 
 // one gated-velocity network evaluation of the workgroup's NT tiles; all four waves return the same out4 (lane h=0: w0..w3,
 // h=1: w4, w5) per tile
-template <int NT>
-__device__ __forceinline__ void velnet_split(const SplitArgs& a, float4* xch, float* bc, int w, int owner, int lane, int h,
-                                             const float4* q, float4* wq, const float* lb, float (&out4)[NT][4]) {
+// STASH (training render): pre-activations z (5 layers x 64 rows, wave w = rows 16w..16w+15 of each layer) and the encoder slots go to
+// the per-(evaluation, tile) stash in exactly the layout of velnet_forward (engine.h), so k_rk2_bwd / k_wgrad read it unchanged
+template <int NT, bool STASH = false>
+__device__ __forceinline__ void velnet_split(const float4* const* f4, float4* xch, float* bc, int w, int owner, int lane, int h,
+                                             const float4* q, float4* wq, const float* lb, float (&out4)[NT][4],
+                                             float* const* zst = nullptr, float* const* x0st = nullptr) {
     f32x16 acc[NT];
     const float4* xl = xch + lane;
     {
@@ -73,6 +76,7 @@ __device__ __forceinline__ void velnet_split(const SplitArgs& a, float4* xch, fl
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             vel_encode_slots(q[t], h, in0[t]);
+            if (STASH && w == t) stash_store<16>(x0st[t], lane, in0[t]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = lb[32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
         }
@@ -82,8 +86,14 @@ __device__ __forceinline__ void velnet_split(const SplitArgs& a, float4* xch, fl
 #pragma unroll 1
     for (int l = 0; l < 5; ++l) {
         // the next layer's weights start their trip from L2 now; they land behind the epilogue and the exchange
-        if (l < 4) split_load<16>(a.f4[l + 1] + (size_t)w * 16 * 64, lane, wq);
-        else if (mine < NT) split_load<16>(a.f4[5], lane, wq);
+        if (l < 4) split_load<16>(f4[l + 1] + (size_t)w * 16 * 64, lane, wq);
+        else if (mine < NT) split_load<16>(f4[5], lane, wq);
+        if (STASH) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane] = acc[t][r];
+        }
         __syncthreads();                                 // the previous layer's readers of the exchange buffer are done
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -110,7 +120,7 @@ __device__ __forceinline__ void velnet_split(const SplitArgs& a, float4* xch, fl
         for (int r = 0; r < 4; ++r) bc[(mine * 4 + r) * 64 + lane] = ao[0][r];
     }
     // layer 0 of the NEXT evaluation (the caller stops using wq before that)
-    split_load<4>(a.f4[0] + (size_t)w * 4 * 64, lane, wq);
+    split_load<4>(f4[0] + (size_t)w * 4 * 64, lane, wq);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
         float4 q[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur[t]);
-        velnet_split<NT>(a, xch, bc, w, owner, lane, h, q, wq, lb, o4);
+        velnet_split<NT>(a.f4, xch, bc, w, owner, lane, h, q, wq, lb, o4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float w1[6], v1[3];
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
             px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
             q[t] = make_float4(px[t], py[t], pz[t], tcur[t] - hdt);
         }
-        velnet_split<NT>(a, xch, bc, w, owner, lane, h, q, wq, lb, o4);
+        velnet_split<NT>(a.f4, xch, bc, w, owner, lane, h, q, wq, lb, o4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float w2[6], v2[3];
@@ -191,6 +201,98 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
         if (active[t] && h == 0 && w == 0) a.xw[n[t]] = make_float4(x[t], y[t], z[t], zw[t]);
 }
 
+// ---------------------------------------------------------------- render warp: every sample takes the same (dt_s, t_s) sequence
+// (k_rk2_fwd<true, STASH> of vel.hip on the feature-split layout; same stash, same records, same numbers)
+template <int NT, bool STASH>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split_uni(SplitUniArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* xch = reinterpret_cast<float4*>(lds);
+    float* bc = lds + NT * SPLIT_XCH_F4 * 4;
+    const Rk2Args& ra = a.r;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int owner = blockIdx.x & 3;
+    const int count = *ra.count;
+    // whole 128-sample groups, as k_rk2_fwd: the adjoint and weight-gradient kernels walk every tile of the last, ragged group
+    if ((int)blockIdx.x * NT * TILE >= (count + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES) return;
+    bool active[NT]; int n[NT], idx[NT]; float x[NT], y[NT], z[NT], zw[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        idx[t] = (blockIdx.x * NT + t) * TILE + (lane & 31);
+        active[t] = idx[t] < count;
+        n[t] = active[t] ? ra.list[idx[t]] : 0;
+        const float4 q0 = active[t] ? ra.xw[n[t]] : zero4();
+        x[t] = q0.x; y[t] = q0.y; z[t] = q0.z; zw[t] = q0.w;
+    }
+    float4 wq[16];
+    split_load<4>(a.f4[0] + (size_t)w * 4 * 64, lane, wq);
+    float* lb = bc + NT * 4 * 64;
+    for (int k = threadIdx.x; k < 6 * 128; k += WG_THREADS) lb[k] = (k & 127) < (k < 640 ? 128 : 32) ? a.bv[k >> 7][k & 127] : 0.f;
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < ra.nsteps; ++s) {
+        const float dt = ra.dt[s], tcur = ra.tcur[s], hdt = 0.5f * dt;
+        float* z1[NT]; float* z2[NT]; float* x1[NT]; float* x2[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const size_t tile = (size_t)blockIdx.x * NT + t;
+            const size_t e1 = (size_t)(2 * s) * ra.cap_tiles + tile, e2 = (size_t)(2 * s + 1) * ra.cap_tiles + tile;
+            z1[t] = STASH ? ra.zst + e1 * (VEL_Z_REGS * REGF) : nullptr; z2[t] = STASH ? ra.zst + e2 * (VEL_Z_REGS * REGF) : nullptr;
+            x1[t] = STASH ? ra.x0st + e1 * (VEL_X0_REGS * REGF) : nullptr; x2[t] = STASH ? ra.x0st + e2 * (VEL_X0_REGS * REGF) : nullptr;
+        }
+        float o4[NT][4], px[NT], py[NT], pz[NT], w1[NT][6];
+        bool g1[NT];
+        float4 q[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur);
+        velnet_split<NT, STASH>(a.f4, xch, bc, w, owner, lane, h, q, wq, lb, o4, z1, x1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float v1[3];
+            gather6(o4[t], h, w1[t]);
+            vel_from_w(w1[t], x[t], y[t], z[t], v1);
+            g1[t] = gated_out(ra.f, x[t], y[t], z[t]);
+            if (g1[t]) { v1[0] = v1[1] = v1[2] = 0.f; }
+            px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
+            q[t] = make_float4(px[t], py[t], pz[t], tcur - hdt);
+        }
+        velnet_split<NT, STASH>(a.f4, xch, bc, w, owner, lane, h, q, wq, lb, o4, z2, x2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float w2[6], v2[3];
+            gather6(o4[t], h, w2);
+            vel_from_w(w2, px[t], py[t], pz[t], v2);
+            const bool g2 = gated_out(ra.f, px[t], py[t], pz[t]);
+            if (g2) { v2[0] = v2[1] = v2[2] = 0.f; }
+            const float nx = x[t] - dt * v2[0], ny = y[t] - dt * v2[1], nz = z[t] - dt * v2[2];
+            const bool rej = ra.f.gate_sur && gated_out(ra.f, nx, ny, nz);   // tensorf_keyframe.py:603-605
+            if (STASH && active[t] && h == 0 && w == (t & 3)) {
+                float* rc = ra.rec + (size_t)s * RK_NF * ra.cap + idx[t];
+                rc[0 * ra.cap] = x[t]; rc[1 * ra.cap] = y[t]; rc[2 * ra.cap] = z[t];
+                rc[3 * ra.cap] = px[t]; rc[4 * ra.cap] = py[t]; rc[5 * ra.cap] = pz[t];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { rc[(6 + k) * ra.cap] = w1[t][k]; rc[(12 + k) * ra.cap] = w2[k]; }
+                rc[18 * ra.cap] = __int_as_float((g1[t] ? 1 : 0) | (g2 ? 2 : 0) | (rej ? 4 : 0));
+            }
+            if (active[t] && !rej) { x[t] = nx; y[t] = ny; z[t] = nz; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (active[t] && h == 0 && w == 0) ra.xw[n[t]] = make_float4(x[t], y[t], z[t], zw[t]);
+}
+
+int launch_rk2_split_uni(const SplitUniArgs& a, int64_t cap_samples, bool stash, hipStream_t st) {
+    const int64_t tiles = (cap_samples + TILE - 1) / TILE;
+    if (tiles <= 0) return 0;
+    ProfScope ps(PK_RK2_FWD, st);
+    const dim3 g((unsigned)((tiles + 1) / 2)), b(WG_THREADS);
+    if (stash) hipLaunchKernelGGL((k_rk2_split_uni<2, true>), g, b, SPLIT_LDS_BYTES(2), st, a);
+    else hipLaunchKernelGGL((k_rk2_split_uni<2, false>), g, b, SPLIT_LDS_BYTES(2), st, a);
+    LAUNCHCK();
+    return 0;
+}
+
 // wide = 0: one tile per workgroup (shortest latency: short lists); wide = 1: two tiles per workgroup share every weight load
 int launch_rk2_split(const SplitArgs& a, int64_t cap_points, int wide, hipStream_t st) {
     const int64_t tiles = (cap_points + TILE - 1) / TILE;
@@ -199,7 +301,7 @@ int launch_rk2_split(const SplitArgs& a, int64_t cap_points, int wide, hipStream
     if (wide) {
         static int nt = -1;
         if (nt < 0) {
-            const char* e = getenv("NVFI_SPLIT_NT"); nt = e ? atoi(e) : 4;
+            const char* e = getenv("NVFI_SPLIT_NT"); nt = e ? atoi(e) : 2;
             HIPCK(hipFuncSetAttribute((const void*)k_rk2_split<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES(4)));
         }
         if (nt == 1) hipLaunchKernelGGL(k_rk2_split<1>, dim3((unsigned)tiles), dim3(WG_THREADS), SPLIT_LDS_BYTES(1), st, a);

@@ -59,11 +59,11 @@ def test_fp16band_prefilter_under_the_reference_goldens():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-def test_split32_prefilter_is_the_fp32_prefilter(tmp_path):
-    """vel_split.hip (the kernel behind the fp32 re-evaluation list) run over EVERY candidate: bit-identical positions, hence masks"""
-    a, b = _run(tmp_path, "fp32"), _run(tmp_path, "split32")
+def test_engine_and_split_prefilters_agree_bit_for_bit(tmp_path):
+    """the default fp32 prefilter runs on vel_split.hip; k_rk2_fwd of vel.hip (engine32) gives bit-identical positions, hence masks"""
+    a, b = _run(tmp_path, "engine32"), _run(tmp_path, "fp32")
     for name in ("A", "B", "cfg1"):
-        print(f"{name}: get_vel_loss {float(a[f'{name}:ms']):.3f} ms fp32 -> {float(b[f'{name}:ms']):.3f} ms split32")
+        print(f"{name}: get_vel_loss {float(a[f'{name}:ms']):.3f} ms engine32 -> {float(b[f'{name}:ms']):.3f} ms fp32 (split kernel)")
         assert np.array_equal(a[f"{name}:kept"], b[f"{name}:kept"]), name
         np.testing.assert_allclose(float(a[f"{name}:loss"]), float(b[f"{name}:loss"]), rtol=1e-5)
 
