@@ -67,6 +67,11 @@ int launch_rk2_split(const SplitArgs& a, int64_t cap_points, int wide, hipStream
 #define VEL_X4F_FLOATS (X4_FLOATS(4, 14) + 4 * X4_FLOATS(4, 64) + X4_FLOATS(1, 64))     // forward fragments only
 struct SplitUniArgs { Rk2Args r; const float4* f4[6]; const float* bv[6]; };
 int launch_rk2_split_uni(const SplitUniArgs& a, int64_t cap_samples, bool stash, hipStream_t st);
+// the adjoint (vel_split.hip: k_rk2_split_bwd); t4[0] = T0 (1 tile x 64 steps), t4[1..4], t4[5] (4 tiles x 4 steps)
+#define VEL_X4B_FLOATS (X4_FLOATS(1, 64) + 4 * X4_FLOATS(4, 64) + X4_FLOATS(4, 4))
+struct SplitBwdArgs { Rk2Args r; const float4* t4[6]; };
+int launch_rk2_split_bwd(const SplitBwdArgs& a, int64_t cap_samples, hipStream_t st);
+int pack_vel_x4_bwd(const VelFrags& W, float* buf, const float4** t4, hipStream_t st);
 // x4 copies of the forward fragments of a packed VelFrags into buf (VEL_X4F_FLOATS); fills f4[6]
 int pack_vel_x4_fwd(const VelFrags& W, float* buf, const float4** f4, hipStream_t st);
 

@@ -58,6 +58,20 @@ int pack_vel_x4_fwd(const VelFrags& W, float* buf, const float4** f4, hipStream_
     return launch_frag_x4(xj, st);
 }
 
+int pack_vel_x4_bwd(const VelFrags& W, float* buf, const float4** t4, hipStream_t st) {
+    X4Jobs xj; xj.n = 0;
+    float* p = buf;
+    auto add = [&](const float* src, int MT, int NS, const float4** slot) {
+        xj.src[xj.n] = src; xj.dst[xj.n] = p; xj.MT[xj.n] = MT; xj.NS[xj.n] = NS; ++xj.n;
+        *slot = reinterpret_cast<const float4*>(p);
+        p += X4_FLOATS(MT, NS);
+    };
+    add(W.t[0], 1, 64, &t4[0]);
+    for (int l = 1; l <= 4; ++l) add(W.t[l], 4, 64, &t4[l]);
+    add(W.t[5], 4, 4, &t4[5]);
+    return launch_frag_x4(xj, st);
+}
+
 #define JET_NC 5
 #define JET_XCH_FLOATS (JET_NC * 64 * 64)        // 80 KB: [column][s/4][lane][4]
 #define JET_LDS_BYTES (JET_XCH_FLOATS * 4)

@@ -1003,7 +1003,7 @@ struct RenderPlan {
     uint8_t *valid, *mflag, *rflag;
     float4 *xw, *rgbs, *rgb_pre, *gxw, *gxk;
     float *xpre, *gxpre;
-    float *vel_frag, *render_frag, *vel_x4;
+    float *vel_frag, *render_frag, *vel_x4, *vel_x4b;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     float *slabs;
     long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
@@ -1033,6 +1033,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->xpre = B.take<float>(N);
     P->vel_frag = B.take<float>(VEL_FRAG_FLOATS);
     P->vel_x4 = nsteps > 0 ? B.take<float>(VEL_X4F_FLOATS) : nullptr;
+    P->vel_x4b = (nsteps > 0 && train) ? B.take<float>(VEL_X4B_FLOATS) : nullptr;
     P->render_frag = B.take<float>(RENDER_FRAG_FLOATS);
     P->maskv = (flags & NVFI_WANT_MASK) ? B.take<float>(N * 32) : nullptr;
     P->mask_frag = (flags & NVFI_WANT_MASK) ? B.take<float>(64 * 1024) : nullptr;
@@ -1323,7 +1324,13 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
         ra.nsteps = nsteps;
         for (int s = 0; s < nsteps; ++s) { ra.dt[s] = dts[s]; ra.tcur[s] = tcs[s]; }
         ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles; ra.gxk = P.gxk;
-        if (launch_rk2_bwd(ra, N, st)) return 1;
+        static int split = -1;
+        if (split < 0) { const char* e = getenv("NVFI_RK2_SPLIT_BWD"); split = e ? atoi(e) : 1; }
+        if (split) {   // vel_split.hip: same adjoint stash bit for bit
+            SplitBwdArgs ba; ba.r = ra;
+            if (pack_vel_x4_bwd(VW, P.vel_x4b, ba.t4, st)) return 1;
+            if (launch_rk2_split_bwd(ba, N, st)) return 1;
+        } else if (launch_rk2_bwd(ra, N, st)) return 1;
         if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 3, (int)P.cap_tiles, 2 * nsteps, BM_SILU, P.slabs, NSLAB,
                              grads->vW, grads->vb, 1.f, st)) return 1;
     }

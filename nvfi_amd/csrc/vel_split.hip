@@ -293,6 +293,187 @@ int launch_rk2_split_uni(const SplitUniArgs& a, int64_t cap_samples, bool stash,
     return 0;
 }
 
+// ---------------------------------------------------------------- RK2 adjoint of the render warp on the same layout
+// (k_rk2_bwd of vel.hip: same recurrence, same stash rows, same K order per accumulator -> the same adjoint stash bit for bit).
+// Wave w owns rows [32w, 32w + 32) of every layer's INPUT gradient (one tile of the transposed weights, x4 fragments from L2), loads
+// only its own 16 z rows and stores only its own 16 adjoint rows per layer and tile; the 128 -> 28 input layer of tile t is
+// contracted by wave (owner + t) & 3 and its 16 slot gradients are broadcast through LDS.  36 KB of LDS instead of the 128 KB
+// double-buffered fragment pipe of k_rk2_bwd: the kernel shares a CU with whatever the other streams run.
+#define SPLIT_BWD_LDS_BYTES(NT) ((NT) * (SPLIT_XCH_F4 * 16 + 16 * 64 * 4))
+
+template <int NT>
+__device__ __forceinline__ void velnet_split_bwd(const float4* const* t4, float4* xch, float* bc, int w, int owner, int lane,
+                                                 const float (&gw4)[NT][4], const float* const* zst, float* const* gst, float4* wq,
+                                                 float (&ge)[NT][16]) {
+    f32x16 acc[NT];
+    float zp[NT][16];
+    const float4* xl = xch + lane;
+    const int mine = (w - owner) & 3;
+    wq[0] = t4[5][(size_t)w * 64 + lane];                 // T5: 4 tiles x 1 group of 4 K-steps
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zp[t][r] = zst[t][(size_t)(4 * 64 + 16 * w + r) * REGF + lane];
+        if (w == t) {                                     // adjoint of the 6 outputs: B operand of the output layer's weight gradient
+            float* gw_rows = gst[t] + (size_t)5 * 64 * REGF;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gw_rows[r * REGF + lane] = r < 4 ? gw4[t][r] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    }
+    {
+        const float av[4] = {wq[0].x, wq[0].y, wq[0].z, wq[0].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = MFMA32(av[k], gw4[t][k], acc[t]);
+    }
+#pragma unroll 1
+    for (int l = 4; l >= 0; --l) {
+        if (l >= 1) split_load<16>(t4[l] + (size_t)w * 16 * 64, lane, wq);
+        else if (mine < NT) split_load<16>(t4[0], lane, wq);
+        float g[NT][16];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                g[t][r] = acc[t][r] * act_d1<1>(zp[t][r]);
+                gst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane] = g[t][r];
+            }
+            if (l >= 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[t][r] = zst[t][(size_t)((l - 1) * 64 + 16 * w + r) * REGF + lane];
+            }
+        }
+        __syncthreads();                                  // the previous layer's readers of the exchange buffer are done
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                xch[(t * 16 + 4 * w + k) * 64 + lane] = make_float4(g[t][4 * k], g[t][4 * k + 1], g[t][4 * k + 2], g[t][4 * k + 3]);
+        __syncthreads();
+        if (l >= 1) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            split_mfma_lds<NT>(wq, xl, 0, acc);
+        }
+    }
+    if (mine < NT) {
+        f32x16 ao[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ao[0][r] = 0.f;
+        split_mfma_lds<1>(wq, xl, mine, ao);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bc[(mine * 16 + r) * 64 + lane] = ao[0][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ge[t][r] = bc[(t * 16 + r) * 64 + lane];
+}
+
+template <int NT>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split_bwd(SplitBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* xch = reinterpret_cast<float4*>(lds);
+    float* bc = lds + NT * SPLIT_XCH_F4 * 4;
+    const Rk2Args& ra = a.r;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int owner = blockIdx.x & 3;
+    const int count = *ra.count;
+    if ((int)blockIdx.x * NT * TILE >= (count + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES) return;
+    bool active[NT]; int idx[NT]; float g3[NT][3];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        idx[t] = (blockIdx.x * NT + t) * TILE + (lane & 31);
+        active[t] = idx[t] < count;
+        const float4 gin = active[t] ? ra.gxk[ra.list[idx[t]]] : zero4();   // upstream gradient of the warped position
+        g3[t][0] = gin.x; g3[t][1] = gin.y; g3[t][2] = gin.z;
+    }
+    float4 wq[16];
+#pragma unroll 1
+    for (int s = ra.nsteps - 1; s >= 0; --s) {
+        const float dt = ra.dt[s], tcur = ra.tcur[s];
+        float gacc[NT][3], gup[NT][3];
+        bool g1[NT], g2[NT], rej[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float* rc = ra.rec + (size_t)s * RK_NF * ra.cap + (active[t] ? idx[t] : 0);
+            const int flags = active[t] ? __float_as_int(rc[18 * ra.cap]) : 7;
+            g1[t] = flags & 1; g2[t] = flags & 2; rej[t] = flags & 4;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { gacc[t][c] = 0.f; gup[t][c] = g3[t][c]; }
+        }
+#pragma unroll 1
+        for (int e = 1; e >= 0; --e) {
+            const int po = e ? 3 : 0, wo = e ? 12 : 6;
+            const float coef = e ? -dt : -0.5f * dt;
+            const float te = e ? tcur - 0.5f * dt : tcur;
+            float r4[NT][4], gloc[NT][3], ge[NT][16];
+            const float* zs[NT]; float* gs[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float* rc = ra.rec + (size_t)s * RK_NF * ra.cap + (active[t] ? idx[t] : 0);
+                const bool gate = e ? g2[t] : g1[t];
+                const size_t es = (size_t)(2 * s + e) * ra.cap_tiles + (size_t)blockIdx.x * NT + t;
+                zs[t] = ra.zst + es * (VEL_Z_REGS * REGF); gs[t] = ra.gst + es * (VEL_G_REGS * REGF);
+                float p[3], wv[6], gv[3], gw[6];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[c] = active[t] ? rc[(po + c) * ra.cap] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) wv[k] = active[t] ? rc[(wo + k) * ra.cap] : 0.f;
+                const bool on = active[t] && !rej[t] && !gate;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gv[c] = on ? coef * gup[t][c] : 0.f;
+                gw[0] = gv[0]; gw[1] = gv[1]; gw[2] = gv[2];
+                gw[3] = p[2] * gv[1] - p[1] * gv[2];
+                gw[4] = -p[2] * gv[0] + p[0] * gv[2];
+                gw[5] = p[1] * gv[0] - p[0] * gv[1];
+                gloc[t][0] = -wv[5] * gv[1] + wv[4] * gv[2];
+                gloc[t][1] = wv[5] * gv[0] - wv[3] * gv[2];
+                gloc[t][2] = -wv[4] * gv[0] + wv[3] * gv[1];
+                scatter6(gw, h, r4[t]);
+            }
+            velnet_split_bwd<NT>(a.t4, xch, bc, w, owner, lane, r4, zs, gs, wq, ge);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float* rc = ra.rec + (size_t)s * RK_NF * ra.cap + (active[t] ? idx[t] : 0);
+                float p[3], x0[16];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[c] = active[t] ? rc[(po + c) * ra.cap] : 0.f;
+                vel_encode_slots(make_float4(p[0], p[1], p[2], te), h, x0);
+                const float4 gq = vel_encode_bwd(ge[t], x0, h);
+                gloc[t][0] += gq.x; gloc[t][1] += gq.y; gloc[t][2] += gq.z;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { gacc[t][c] += gloc[t][c]; gup[t][c] = gloc[t][c]; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (active[t] && !rej[t]) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g3[t][c] = g3[t][c] + gacc[t][c] + 0.f;
+            }
+    }
+}
+
+int launch_rk2_split_bwd(const SplitBwdArgs& a, int64_t cap_samples, hipStream_t st) {
+    const int64_t tiles = (cap_samples + TILE - 1) / TILE;
+    if (tiles <= 0) return 0;
+    ProfScope ps(PK_RK2_BWD, st);
+    static int nt = -1;
+    if (nt < 0) { const char* e = getenv("NVFI_SPLIT_BWD_NT"); nt = e ? atoi(e) : 2; }
+    if (nt == 1) hipLaunchKernelGGL(k_rk2_split_bwd<1>, dim3((unsigned)tiles), dim3(WG_THREADS), SPLIT_BWD_LDS_BYTES(1), st, a);
+    else hipLaunchKernelGGL(k_rk2_split_bwd<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(WG_THREADS), SPLIT_BWD_LDS_BYTES(2), st, a);
+    LAUNCHCK();
+    return 0;
+}
+
 // wide = 0: one tile per workgroup (shortest latency: short lists); wide = 1: two tiles per workgroup share every weight load
 int launch_rk2_split(const SplitArgs& a, int64_t cap_points, int wide, hipStream_t st) {
     const int64_t tiles = (cap_points + TILE - 1) / TILE;

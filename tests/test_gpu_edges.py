@@ -203,12 +203,12 @@ def test_pde_column_kernels_still_match_goldens():
 
 
 def test_engine_rk2_kernels_still_match_goldens():
-    """NVFI_RK2_SPLIT=0 / NVFI_PDE_PREFILTER=engine32 keep k_rk2_fwd of vel.hip (one tile per wave, weights staged in LDS) for the render
-    warp and the PDE prefilter instead of the feature-split kernels of vel_split.hip (the default): the same goldens must pass."""
+    """NVFI_RK2_SPLIT=0 / NVFI_RK2_SPLIT_BWD=0 / NVFI_PDE_PREFILTER=engine32 keep k_rk2_fwd / k_rk2_bwd of vel.hip (one tile per wave, weights
+    staged in LDS) for the render warp, its adjoint and the PDE prefilter instead of the feature-split kernels of vel_split.hip (the default): the same goldens must pass."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, NVFI_RK2_SPLIT="0", NVFI_PDE_PREFILTER="engine32")
+    env = dict(os.environ, NVFI_RK2_SPLIT="0", NVFI_RK2_SPLIT_BWD="0", NVFI_PDE_PREFILTER="engine32")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_fullsize_chessboard.py"),
                         os.path.join(root, "tests", "test_gpu_training_loop.py"), "-q", "-x", "-m", "gpu"], env=env, cwd=root, capture_output=True, text=True)

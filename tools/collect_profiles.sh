@@ -18,7 +18,7 @@ python $REPO/bench.py --mode dropin --no-cpu-baseline > $OUT/${TAG}_bench_line_d
 python $REPO/bench.py --workload cfg2 --no-cpu-baseline > $OUT/${TAG}_bench_line_cfg2.json 2>/dev/null
 # other kernel selections: opt-in fp16-input pre-pass with the fp32 band; the engine kernels of vel.hip instead of vel_split.hip
 NVFI_PDE_PREFILTER=fp16band python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_line_fp16band.json 2>/dev/null
-NVFI_PDE_PREFILTER=engine32 NVFI_RK2_SPLIT=0 python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_line_engine32.json 2>/dev/null
+NVFI_PDE_PREFILTER=engine32 NVFI_RK2_SPLIT=0 NVFI_RK2_SPLIT_BWD=0 python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_line_engine32.json 2>/dev/null
 rocprofv3 --kernel-trace -d /tmp/prof_k16 -- env NVFI_PDE_PREFILTER=fp16band python $REPO/bench.py --no-cpu-baseline > /dev/null 2>&1
 python $REPO/tools/rocpd_stats.py $(find /tmp/prof_k16 -name "*.db" | head -1) $OUT/${TAG}_kernel_stats_fp16band.csv --after-marker > /dev/null
 # 1. kernel trace of the default bench command: per-kernel statistics of the whole run and of the profiled pass (after the marker)

@@ -10,7 +10,7 @@ CLASSES = {
     "wgrad": ["k_wgrad"],
     "pde_prefilter": ["void k_rk2_fwd<false, false>", "void k_rk2_split<2>", "void k_rk2_split<1>", "void k_rk2_split<4>", "k_rk2_pre16"],
     "rk2_fwd": ["void k_rk2_fwd<true, true>", "void k_rk2_split_uni<2, true>"],
-    "rk2_bwd": ["k_rk2_bwd"],
+    "rk2_bwd": ["k_rk2_bwd", "void k_rk2_split_bwd<2>"],
     "pde_bwd": ["k_pde_jet_bwd", "k_pde_tangent_bwd", "k_pde_value_bwd"],
     "pde_fwd": ["k_pde_jet_fwd", "k_pde_value_fwd", "k_pde_tangent_fwd"],
     "app_fwd": ["void k_app_fwd<true>"],
