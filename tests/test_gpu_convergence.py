@@ -102,3 +102,62 @@ def test_student_approaches_teacher():
     for p in student.parameters():
         assert torch.isfinite(p).all()
     assert after < before / 10.0, (before, after)
+
+
+def test_velocity_field_is_learned_from_images():
+    """The gradient path rgb -> composite -> density / appearance at the WARPED point -> RK2 adjoint -> velocity net, end to end: a
+    student that shares the teacher's radiance field but has forgotten its motion (velocity net re-drawn, ~zero velocity) is trained on
+    the teacher's frames at non-keyframe times; its velocity inside the object must approach the teacher's (|v| ~ 0.8)."""
+    import bench
+    import models
+    dev = torch.device("cuda", 0)
+    teacher, student = _scene(1), _scene(1)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for p in list(teacher.nvfi.app_plane_space) + list(teacher.nvfi.app_plane_time):
+            p.mul_(2.5)
+        last = [m for m in teacher.nvfi.renderModule.modules() if isinstance(m, torch.nn.Linear)][-1]
+        last.weight.mul_(4.0); last.bias.copy_(torch.tensor([0.8, -0.6, 0.2], device=dev))
+        lt = [m for m in teacher.nvfi.vel_net.weight_net.modules() if isinstance(m, torch.nn.Linear)][-1]
+        lt.weight.mul_(8.0); lt.bias.copy_(torch.tensor([0.6, -0.4, 0.3, 0.0, 0.0, 0.5], device=dev))     # a teacher that moves
+        student.load_state_dict(teacher.state_dict())
+        for m in student.nvfi.vel_net.weight_net.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.copy_((torch.randn(m.weight.shape, generator=g) / np.sqrt(m.weight.shape[1]) * 0.5).to(dev)); m.bias.zero_()
+    ren_t, ren_s = models.Renderer(teacher, 0, 0, 1024), models.Renderer(student, 0, 0, 1024)
+    focal = 0.5 * 128 / np.tan(0.5 * bench.ANGLE_X)
+    cams = [models.Camera(bench.pose_spherical(th, ph, 4.0).to(dev), 128, 128, focal, torch.zeros(128, 128, 3, device=dev), 1.0, 8.0)
+            for th, ph in ((30, -30), (120, -20), (210, -40), (300, -25))]
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    rng = np.random.default_rng(5)
+    pts = (torch.rand(20000, 3, device=dev, generator=gen) - 0.5) * 0.6          # normalised coordinates inside the object
+    tt = torch.rand(20000, 1, device=dev, generator=gen) * 0.75
+
+    def verr():
+        with torch.no_grad():
+            xt = torch.cat([pts, tt], -1)
+            vt, vs = teacher.nvfi.vel_net.get_vel(xt)[..., :3], student.nvfi.vel_net.get_vel(xt)[..., :3]
+            return float((vs - vt).norm(dim=-1).mean()), float(vt.norm(dim=-1).mean())
+
+    e0, vmag = verr()
+    opt = torch.optim.Adam(student.get_optparam_groups(0.02, 1e-3, 1e-3), betas=(0.9, 0.99))
+    for it in range(300):
+        student.train()
+        loss = 0
+        for key in (False, True):
+            i = int(rng.integers(0, 46))
+            while (i % 3 == 0) != key:
+                i = int(rng.integers(0, 46))
+            rays = cams[int(rng.integers(0, 4))].sample_rays_device(1024, generator=gen)[0]
+            with torch.no_grad():
+                tgt = ren_t.render(i / 60.0, rays, white_background=True, mode="test")[0]
+            loss = loss + torch.nn.functional.mse_loss(ren_s.render(i / 60.0, rays, white_background=True, mode="train")[0], tgt)
+        lv = student.get_vel_loss(8192)
+        if lv > 0:
+            loss = loss + lv
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    e1, _ = verr()
+    print(f"mean |v_student - v_teacher| inside the object: {e0:.3f} -> {e1:.3f} (teacher mean |v| {vmag:.3f})")
+    assert e0 > 0.7 * vmag and e1 < 0.35 * vmag, (e0, e1, vmag)
