@@ -57,6 +57,10 @@ def test_fp16band_prefilter_under_the_reference_goldens():
                         os.path.join(ROOT, "tests", "test_gpu_fullsize_chessboard.py"), os.path.join(ROOT, "tests", "test_gpu_fullsize.py"), "-k", "pde"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    # and training end to end (tests/test_gpu_convergence.py: radiance field and velocity field both learned) with the switch on
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_convergence.py")],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_engine_and_split_prefilters_agree_bit_for_bit(tmp_path):
