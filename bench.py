@@ -444,6 +444,22 @@ def _load_json(name):
         return None
 
 
+def _spawn_ranks(n, ndev, backend):
+    """Re-run this command as n ranks under torch.distributed.run (one process per GPU).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    if backend == "nccl" and ndev < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs on this node, found {ndev} (one RCCL rank per GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -463,22 +479,39 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the NVFi hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
-    dev_index = local_rank % ndev          # (ranks share a device only in the single-GPU logic test, see NVFI_BENCH_BACKEND)
+    backend = os.environ.get("NVFI_BENCH_BACKEND", "nccl")       # "nccl" = RCCL over xGMI; "gloo" only to exercise the path on one GPU
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL rendezvous on 127.0.0.1) - the same
+        # command line the driver uses with torch.distributed.run in front
+        sys.exit(_spawn_ranks(args.gpus, ndev, backend))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {ndev} (one process per GPU; two ranks cannot share "
+                         "a device in one RCCL communicator)")
+    dev_index = local_rank % ndev          # (ranks share a device only in the single-GPU logic test: NVFI_BENCH_BACKEND=gloo)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    comm_info = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("NVFI_BENCH_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" only to exercise the path on one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        # what the process group really is: ranks, backend and the distinct devices behind them (reported in the line)
+        alld = [None] * dist.get_world_size()
+        dist.all_gather_object(alld, dev_index)
+        comm_info = dict(backend=dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""), ranks=dist.get_world_size(),
+                         devices=sorted({int(x) for x in alld}),
+                         exchange="nvfi_allreduce_grads (C ABI)" if os.environ.get("NVFI_ALLREDUCE") == "abi" else "torch.distributed.all_reduce")
+        world = dist.get_world_size()
     from nvfi_amd import _lib
     L = _lib.lib()
 
@@ -586,7 +619,7 @@ def main():
 
     out = {
         "metric": "training rays/sec (fwd+bwd incl. PDE loss), 'bat' scene", "value": value, "unit": "rays/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "n_gpus": world, "process_group": comm_info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32" if os.environ.get("NVFI_PDE_PREFILTER", "fp32") != "fp16band" else "f32 (opt-in: fp16-input pre-pass of the PDE occupancy prefilter, fp32 re-evaluation band)",
         "data": "synthetic",

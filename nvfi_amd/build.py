@@ -7,7 +7,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["engine.hip", "vel.hip", "render.hip", "scatter.hip", "mask.hip", "pde.hip", "pde_jet.hip", "pre16.hip", "vel_split.hip", "regs.hip", "optim.hip", "abi.hip", "comm.hip"]
-HEADERS = ["engine.h", "common.h", "vel.h", "render.h", "scatter.h", "pde.h", os.path.join("..", "..", "include", "nvfi_hip.h")]
+# every header under csrc/ (engine16.h, ... - a header that is not listed here would leave stale objects behind) + the public ABI
+HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith(".h")) + [os.path.join("..", "..", "include", "nvfi_hip.h")]
 SO = os.environ.get("NVFI_BUILD_SO", os.path.join(CSRC, "libnvfi_hip.so"))   # experiments build a second library elsewhere
 OBJDIR = os.environ.get("NVFI_BUILD_OBJDIR", CSRC)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"] + os.environ.get("NVFI_EXTRA_FLAGS", "").split()

@@ -28,6 +28,9 @@ class RcclComm:
         have_pg = dist.is_available() and dist.is_initialized()
         self.world = world if world is not None else (dist.get_world_size() if have_pg else 1)
         self.rank = rank if rank is not None else (dist.get_rank() if have_pg else 0)
+        if self.world > 1 and not have_pg:
+            raise _lib.NvfiError("RcclComm(world>1) ships the 128-byte RCCL id from rank 0 through torch.distributed: call "
+                                 "dist.init_process_group (any backend) first, or distribute nvfi_comm_unique_id's bytes yourself")
         ident = (C.c_char * 128)()
         if self.rank == 0:
             _lib.check(L.nvfi_comm_unique_id(ident))

@@ -160,3 +160,17 @@ def test_boundary_ray_types():
     assert p.shape == (7, 6, 3) and float(p[0, 0, 0]) == pytest.approx(1.0) and float(p[0, -1, 0]) == pytest.approx(8.0)
     r.update_near_far(torch.full((7, 1), 2.0), torch.full((7, 1), 4.0))     # buffers: tensors, as in the reference
     assert float(r.near[0]) == 2.0 and float(r.far[0]) == 4.0
+
+
+def test_bench_spawn_helper_refuses_more_ranks_than_gpus(capsys):
+    """bench.py --gpus N starts N RCCL ranks itself; with fewer devices than ranks it must say so and fail (not run one process)."""
+    import bench
+    assert bench._spawn_ranks(8, 1, "nccl") == 2
+    assert "needs 8 GPUs" in capsys.readouterr().err
+
+
+def test_rccl_comm_needs_a_process_group_for_the_bootstrap():
+    from nvfi_amd import _lib
+    from nvfi_amd.dist import RcclComm
+    with pytest.raises(_lib.NvfiError, match="init_process_group"):
+        RcclComm(world=2, rank=1)

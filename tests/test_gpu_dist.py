@@ -67,12 +67,20 @@ def _local_grads(model, o, d, u, tgt, pts, tt, bucket, stage, world, streams=Fal
     bucket.all_reduce_finish(h, tail)
 
 
-def _worker(rank, world, port, out, streams):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, out, streams, backend="gloo", exchange="torch"):
+    """backend "gloo": both ranks on device 0 (the 1-GPU box); "nccl": one rank per GPU over RCCL (needs >= 2 devices).
+    exchange "abi": the gradient sum goes through nvfi_allreduce_grads (RcclComm) instead of torch.distributed.all_reduce."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from nvfi_amd.dist import GradBucket, PdeGradStage, shard_range
+    if exchange == "abi":
+        return _worker_abi(rank, world, out)
     gold = np.load(os.path.join(GOLD, "hotpath.npz"))
     model, meta = make_model("A")
     f = model.nvfi
@@ -93,13 +101,43 @@ def _worker(rank, world, port, out, streams):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("streams", [False, True])
-def test_two_ranks_on_one_gpu_match_the_union_batch(tmp_path, streams):
-    out = str(tmp_path / "g2.npz")
-    port = 29600 + (os.getpid() % 1500) + (7 if streams else 0)
-    mp.spawn(_worker, args=(2, port, out, streams), nprocs=2, join=True)
-    got = np.load(out)
-    # single process, union batch (same kernels, plain autograd accumulation)
+def _worker_abi(rank, world, out):
+    """NVFI_ALLREDUCE=abi order of bench.Step: render + PDE term accumulate locally (PDE through the stage, weighted on the device by
+    W*n_r/sum n_r), then ONE nvfi_allreduce_grads(average) of the flat buffer over the RcclComm."""
+    from nvfi_amd.dist import GradBucket, PdeGradStage, RcclComm, shard_range
+    gold = np.load(os.path.join(GOLD, "hotpath.npz"))
+    model, meta = make_model("A", f"cuda:{torch.cuda.current_device()}")
+    f = model.nvfi
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    R, P = gold["A:rays_o"].shape[0], gold["A:pde:points"].shape[0]
+    lo, hi = shard_range(R, rank, world)
+    plo, phi = shard_range(P, rank, world)
+    bucket = GradBucket([p for g in model.get_optparam_groups() for p in g["params"]])
+    stage = PdeGradStage(f._pde_params())
+    comm = RcclComm()
+    assert comm.world == world and comm.rank == rank
+    f.train(); f.accumulate_grads_inplace = True
+    bucket.zero(); stage.zero()
+    model.vel_loss_weight = W_PDE
+    model.vel_grad_targets = stage.views
+    f.jitter_override = torch.from_numpy(gold["A:train_nonkey:u"][lo:hi].copy())
+    o = f(T, cu(gold["A:rays_o"][lo:hi]), cu(gold["A:rays_d"][lo:hi]), True)
+    f.jitter_override = None
+    torch.nn.functional.mse_loss(o[0], cu(gold["A:train_nonkey:target"][lo:hi])).backward()
+    model.get_vel_loss(points=cu(gold["A:pde:points"][plo:phi]), t=cu(gold["A:pde:t"][plo:phi]))
+    stage.commit_device(f.last_pde_out)
+    bucket.all_reduce_mean(comm)
+    torch.cuda.synchronize()
+    if rank == 0:
+        g = named_grads(model)
+        np.savez(out, **{k: v for k, v in g.items() if v is not None}, n_kept=float(f.last_pde_out[1]))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+def _union_batch_reference():
+    """single process, union batch (same kernels, plain autograd accumulation)"""
     gold = np.load(os.path.join(GOLD, "hotpath.npz"))
     model, meta = make_model("A")
     f = model.nvfi
@@ -113,7 +151,11 @@ def test_two_ranks_on_one_gpu_match_the_union_batch(tmp_path, streams):
     loss = torch.nn.functional.mse_loss(o[0], cu(gold["A:train_nonkey:target"]))
     lv = model.get_vel_loss(points=cu(gold["A:pde:points"]), t=cu(gold["A:pde:t"]))
     (loss + W_PDE * lv).backward()
-    ref = named_grads(model)
+    return named_grads(model), int(f.last_pde_n_kept)
+
+
+def _assert_matches_union(got):
+    ref, n_kept = _union_batch_reference()
     n = 0
     for k, r in ref.items():
         if r is None or k == "basis_mat_density.weight":
@@ -122,7 +164,64 @@ def test_two_ranks_on_one_gpu_match_the_union_batch(tmp_path, streams):
         assert err < 5e-4, (k, err)        # fp32 sums in a different order (shard-wise, atomics)
         n += 1
     assert n >= 40, n
-    assert 0 < float(got["n_kept"]) < int(f.last_pde_n_kept)      # rank 0 kept only its share of the points
+    assert 0 < float(got["n_kept"]) < n_kept      # rank 0 kept only its share of the points
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (one RCCL rank per device); enables itself on a multi-GPU node")
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("exchange,streams", [("torch", False), ("torch", True), ("abi", False)])
+def test_two_rccl_ranks_match_the_union_batch(tmp_path, exchange, streams):
+    """One rank per GPU over RCCL ("nccl"): the split torch.distributed all-reduce (with and without the three-stream order) and the
+    C-ABI exchange nvfi_allreduce_grads (NVFI_ALLREDUCE=abi in bench.py) all reproduce the single-process gradient of the union batch."""
+    out = str(tmp_path / "g2.npz")
+    port = 29900 + (os.getpid() % 1500) + (3 if streams else 0) + (5 if exchange == "abi" else 0)
+    mp.spawn(_worker, args=(2, port, out, streams, "nccl", exchange), nprocs=2, join=True)
+    _assert_matches_union(np.load(out))
+
+
+def _run_bench(extra, env=None, timeout=900):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra
+    return subprocess.run(cmd, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher in front): on a node with >= 2 GPUs it starts 2 RCCL ranks and reports n_gpus 2 from the
+    process group; on the 1-GPU box it must refuse loudly (non-zero exit, a message that says why) instead of running one process."""
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "64", "--pts", "16384", "--prime", "1", "--no-cpu-baseline"])
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["n_gpus"] == 2 and d["process_group"]["ranks"] == 2 and len(d["process_group"]["devices"]) == 2
+        assert d["process_group"]["backend"].startswith("nccl") and d["value"] > 0
+    else:
+        assert r.returncode != 0
+        assert "needs 2 GPUs" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_gpus_flag_spawns_gloo_ranks_on_one_gpu():
+    """Same self-spawn path, exercised end to end on the 1-GPU box: NVFI_BENCH_BACKEND=gloo lets the two ranks share the device."""
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "64", "--pts", "16384", "--prime", "1", "--no-cpu-baseline"],
+                   env=dict(NVFI_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["process_group"]["ranks"] == 2 and d["process_group"]["backend"] == "gloo"
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--grid", "64", "--no-cpu-baseline"],
+                   env=dict(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29555"), timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr
+
+
+@pytest.mark.parametrize("streams", [False, True])
+def test_two_ranks_on_one_gpu_match_the_union_batch(tmp_path, streams):
+    out = str(tmp_path / "g2.npz")
+    port = 29600 + (os.getpid() % 1500) + (7 if streams else 0)
+    mp.spawn(_worker, args=(2, port, out, streams), nprocs=2, join=True)
+    got = np.load(out)
+    _assert_matches_union(got)
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong", "weak-streams"])
