@@ -49,7 +49,7 @@ class NVFi(nn.Module):
             mn, mx = f.aabb
             points = torch.rand(int(n_pts), 3, device=f.aabb.device) * (mx - mn) + mn
             t = torch.rand(int(n_pts), 1, device=f.aabb.device)
-        if f.accumulate_grads_inplace and torch.is_grad_enabled() and getattr(self, "vel_loss_weight", None) is not None:
+        if f.accumulate_grads_inplace is True and torch.is_grad_enabled() and getattr(self, "vel_loss_weight", None) is not None:
             # fused value + backward: gradients of vel_loss_weight * loss go straight into .grad
             # (sync-free: the value is a 0-dim tensor, 0.0 when no point is occupied - the reference's python `0.` would need the count on the host)
             out = f.pde_loss_backward_(points, t, self.vel_loss_weight, getattr(self, "vel_grad_targets", None))

@@ -8,6 +8,7 @@ Everything between "rays in" and "rgb/depth/acc/weights (+ gradients) out" is on
 libnvfi_hip.so through ctypes; there is no PyTorch/CPU fallback.
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -88,7 +89,14 @@ class _RenderFn(torch.autograd.Function):
         desc = field._desc(params)
         need = ctx.needs_input_grad[6:]
         inplace = field.accumulate_grads_inplace
-        if inplace:
+        if inplace == "arena":
+            # library-managed in-place accumulation (the default under a plain autograd driver): see _arena_attach
+            grads = field._arena_attach(field._render_params(), need)
+            inplace = grads is not None
+            if inplace:
+                field._wait_writers()
+                field._queue_join()
+        elif inplace:
             # kernels accumulate (+=) straight into the parameters' .grad (e.g. views of one flat GradBucket buffer):
             # no zero-fill, no AccumulateGrad add per tensor.  Autograd then sees "no gradient" for these inputs.
             cur = field._render_params()
@@ -100,7 +108,7 @@ class _RenderFn(torch.autograd.Function):
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
                 grads.append(p.grad)
-        else:
+        if not inplace:
             grads = _zero_grads(params, need)
         G = field._grads_struct(grads)
         gs = [None if g is None else g.contiguous() for g in (g_rgb, g_depth, g_acc, g_weights)]
@@ -159,10 +167,22 @@ class _PdeFn(torch.autograd.Function):
         field.last_pde_counters = counters
         ctx.save_for_backward(grads[0]._base)            # the one flat buffer behind the views
         ctx.shapes = [(p.shape, p.stride()) for p in params]
+        ctx.field = field
         return out[0].clone()
 
     @staticmethod
     def backward(ctx, g):
+        field = ctx.field
+        if field.accumulate_grads_inplace == "arena":
+            tail = field._arena_attach(field._pde_params(), [True] * 24, want_tail=True)
+            if tail is not None and tail.numel() == ctx.saved_tensors[0].numel():
+                # one launch: arena[velocity nets] += g * (gradients of the un-weighted loss); a plain read-modify-write, so the
+                # backward kernels of the renders (atomic adds from other streams) are ordered behind it (_note_writer)
+                field._wait_writers(True)
+                tail.addcmul_(ctx.saved_tensors[0], g.to(tail.dtype).expand_as(tail))
+                field._note_writer()
+                field._queue_join()
+                return (None,) * (3 + len(ctx.shapes))
         flat = ctx.saved_tensors[0] * g                  # one launch for all 24 tensors
         out, o = [], 0
         for shp, strides in ctx.shapes:
@@ -197,12 +217,20 @@ class _RegFn(torch.autograd.Function):
         grads = [None] * 9
         cur = field._render_params()[:9]
         cur = cur[:3] + cur[3:6] + cur[6:9]
-        if inplace:
+        arena = False
+        if inplace == "arena":
+            ag = field._arena_attach(field._render_params(), [k in touched for k in range(9)] + [False] * 22)
+            inplace = arena = ag is not None
+            if arena:
+                grads = ag[:9]
+                field._wait_writers(True)      # k_plane_regs adds with plain read-modify-writes: not next to another stream's kernels
+                field._queue_join()
+        elif inplace:
             for k in touched:
                 if cur[k].grad is None:
                     cur[k].grad = torch.zeros_like(cur[k])
                 grads[k] = cur[k].grad
-        else:
+        if not inplace:
             grads = _zero_grads(planes, [k in touched for k in range(9)])
         G = field._grads_struct(grads + [None] * 22)
         w3 = torch.zeros(3, device=g.device)
@@ -210,6 +238,8 @@ class _RegFn(torch.autograd.Function):
         out = torch.empty(3, device=g.device)
         desc = field._desc(list(planes) + field._render_params()[9:])
         _lib.check(L.nvfi_plane_regs_dev(C.byref(desc), _lib.ptr(w3), _lib.ptr(out), C.byref(G), _stream_ptr()))
+        if arena:
+            field._note_writer()
         if inplace:
             return (None, None) + (None,) * 9
         return (None, None) + tuple(grads)
@@ -274,7 +304,19 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         if self.contract_ray:
             raise NotImplementedError("contract_ray is out of scope")
         self.last_counters = None
-        self.accumulate_grads_inplace = False   # True: backward kernels add into p.grad directly (see nvfi_amd.dist.GradBucket)
+        # Where the backward kernels put parameter gradients:
+        #   "arena" (default)  straight into p.grad, which the field backs with ONE persistent flat buffer that it zeroes once per
+        #                      iteration (when the driver's zero_grad(set_to_none=True) left every .grad None): no fresh 38 MB gradient
+        #                      tensors and no AccumulateGrad add per parameter and backward node.  p.grad tensors are therefore re-used
+        #                      across iterations (aliasing: keep a .clone() if you need last iteration's values) and autograd hooks on
+        #                      the parameters do not fire; torch.autograd.grad() callers want False.
+        #   True               same, but the caller owns p.grad (nvfi_amd.dist.GradBucket: every .grad is a view of its flat buffer)
+        #   False              pure autograd: gradients are returned to the engine (NVFI_INPLACE_GRADS=0)
+        self.accumulate_grads_inplace = "arena" if os.environ.get("NVFI_INPLACE_GRADS", "1") != "0" else False
+        # Train-mode render / PDE calls run on the field's own side streams (the caller's stream waits for the results): under an
+        # unmodified sequential driver the two renders and the PDE term of an iteration - and their backward passes, which autograd
+        # runs on the stream of the forward - overlap on the device like in bench.py's three-stream step.  NVFI_AUTO_OVERLAP=0: off.
+        self.auto_overlap = os.environ.get("NVFI_AUTO_OVERLAP", "1") != "0"
         self.pde_debug = 0   # >0: also return the kept mask and the first n Jacobians of get_vel_loss
         self.register_load_state_dict_post_hook(lambda m, k: m.update_stepSize(m.gridSize.tolist()))
 
@@ -321,6 +363,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
+        self.__dict__.pop("_rp_cache", None); self.__dict__.pop("_pp_cache", None)
         self._fix_layout()
         self.device = self.aabb.device
         for name in ("gridSize", "aabbSize", "invaabbSize", "units", "stepSize", "aabbDiag"):
@@ -331,7 +374,24 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         return r
 
     # ------------------------------------------------------------------ parameter plumbing
+    def _param_key(self):
+        d = self.__dict__["_modules"]
+        lists = (d["density_plane_space"], d["density_plane_time"], d["app_plane_space"], d["app_plane_time"])
+        return tuple(id(p) for pl in lists for p in pl._parameters.values()) + (self.use_vel, self.shadingMode, id(d.get("vel_net")), id(d.get("renderModule")))
+
     def _render_params(self):
+        """The 31 tensors of the render path in nvfi_field_desc order.  Walking the module tree costs ~90 us of host time per call (and a
+        step makes seven of them), so the list is cached and re-validated by the identities of the plane parameters / sub-modules
+        (shrink / upsample_volume_grid replace them; `.to()` keeps them)."""
+        key = self._param_key()
+        c = self.__dict__.get("_rp_cache")
+        if c is not None and c[0] == key:
+            return list(c[1])
+        ps = self._render_params_walk()
+        self.__dict__["_rp_cache"] = (key, tuple(ps))
+        return ps
+
+    def _render_params_walk(self):
         ps = list(self.density_plane_space) + list(self.density_plane_time) + list(self.app_plane_space) + list(self.app_plane_time)
         ps.append(self.basis_mat.weight)
         if self.shadingMode == "SH":
@@ -345,6 +405,15 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         return ps
 
     def _pde_params(self):
+        c = self.__dict__.get("_pp_cache")
+        vn = self.__dict__["_modules"].get("vel_net")
+        if c is not None and c[0] == id(vn):
+            return list(c[1])
+        ps = self._pde_params_walk()
+        self.__dict__["_pp_cache"] = (id(vn), tuple(ps))
+        return ps
+
+    def _pde_params_walk(self):
         ps = []
         for net in (self.vel_net.weight_net, self.vel_net.a_weight_net):
             for lin in VelBasis.linears(net):
@@ -393,8 +462,9 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             if len(ps) >= 31:
                 for i in range(6):
                     d.vW[i] = _lib.ptr(ps[19 + 2 * i]); d.vb[i] = _lib.ptr(ps[20 + 2 * i])
-            for i, lin in enumerate(VelBasis.linears(self.vel_net.a_weight_net)):
-                d.aW[i] = _lib.ptr(lin.weight); d.ab[i] = _lib.ptr(lin.bias)
+            pp = self._pde_params()
+            for i in range(6):
+                d.aW[i] = _lib.ptr(pp[12 + 2 * i]); d.ab[i] = _lib.ptr(pp[13 + 2 * i])
         if self.alphaMask is not None:
             d.has_amask = 1
             v = self.alphaMask.alpha_volume
@@ -420,6 +490,123 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             G.vW[i] = _lib.ptr(grads[2 * i]); G.vb[i] = _lib.ptr(grads[2 * i + 1])
             G.aW[i] = _lib.ptr(grads[12 + 2 * i]); G.ab[i] = _lib.ptr(grads[13 + 2 * i])
         return G
+
+    # ------------------------------------------------------------------ gradient arena + side streams (plain-autograd drivers)
+    def _arena_params(self):
+        ps = self._render_params()
+        if self.use_vel:
+            ps = ps + self._pde_params()[12:]           # + the acceleration net: the PDE parameters are then the last 24 entries
+        return [p for p in ps if p is not None]
+
+    def _arena_attach(self, params, need, want_tail=False):
+        """Gradient targets for `params` (None where `need` is false) as views of the field's persistent flat buffer.  A parameter whose
+        .grad is None gets its (zeroed) view attached; when that is true for every parameter of the field - the state a driver's
+        `zero_grad(set_to_none=True)` leaves behind - the whole buffer is cleared with ONE fill.  A .grad the caller put there is used
+        as it is when its layout matches the parameter's; otherwise None is returned and the call falls back to pure autograd.
+        want_tail: return the flat view that covers the 24 velocity-net tensors instead (they are contiguous at the end)."""
+        ps = self._arena_params()
+        key = tuple((id(p), tuple(p.shape), p.stride()) for p in ps)
+        a = self.__dict__.get("_arena")
+        if a is None or a["key"] != key or a["flat"].device != ps[0].device:
+            offs, total = [], 0
+            for p in ps:
+                offs.append(total)
+                total += (p.numel() + 63) // 64 * 64          # 256-byte aligned views, same packing as _zero_grads
+            flat = torch.zeros(total, dtype=torch.float32, device=ps[0].device)
+            views = {id(p): flat[o:o + p.numel()].as_strided(p.shape, p.stride()) for p, o in zip(ps, offs)}
+            a = dict(key=key, flat=flat, views=views, offs=offs, params=ps, event=None, tail=flat[offs[-24]:] if (self.use_vel and len(ps) >= 24) else None)
+            self.__dict__["_arena"] = a
+        # only the parameters THIS node differentiates are attached: a parameter no term of the loss reaches keeps .grad = None and the
+        # optimiser skips it, exactly as under pure autograd
+        wanted = {id(p) for p, n in zip(params, need) if n and p is not None}
+        idx = [i for i, p in enumerate(a["params"]) if id(p) in wanted and p.requires_grad and p.grad is None]
+        if a["event"] is not None:
+            torch.cuda.current_stream().wait_event(a["event"])      # fills queued by nodes that ran on other streams
+        if idx:
+            lo, hi = idx[0], idx[-1]
+            with torch.no_grad():
+                if len(idx) == hi - lo + 1:        # a contiguous run of the buffer (the usual case): ONE fill
+                    end = a["offs"][hi + 1] if hi + 1 < len(a["offs"]) else a["flat"].numel()
+                    a["flat"][a["offs"][lo]:end].zero_()
+                else:
+                    for i in idx:
+                        a["views"][id(a["params"][i])].zero_()
+            for i in idx:
+                p = a["params"][i]
+                p.grad = a["views"][id(p)]
+            ev = torch.cuda.Event()
+            ev.record()
+            a["event"] = ev            # other streams' backward nodes order themselves behind the fill
+        out = []
+        for p, n in zip(params, need):
+            if not n or p is None:
+                out.append(None)
+                continue
+            g = p.grad
+            if g is None or g.stride() != p.stride() or g.dtype != torch.float32 or g.device != p.device:
+                return None
+            out.append(g)
+        if want_tail:
+            vs = self._pde_params()
+            ok = a["tail"] is not None and all(p.grad is a["views"].get(id(p)) for p in vs)
+            return a["tail"] if ok else None
+        return out
+
+    def _side_stream(self, kind):
+        pool = self.__dict__.get("_side_pool")
+        if pool is None:
+            dev = self.aabb.device
+            pool = dict(r=[torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)], p=torch.cuda.Stream(device=dev), k=0)
+            self.__dict__["_side_pool"] = pool
+        if kind == "p":
+            return pool["p"]
+        pool["k"] += 1
+        return pool["r"][pool["k"] & 1]
+
+    def _use_side_streams(self):
+        return (self.auto_overlap and self.accumulate_grads_inplace == "arena" and self.aabb.is_cuda and torch.is_grad_enabled()
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _note_writer(self):
+        """The current stream just queued a non-atomic read-modify-write of gradient memory: later backward nodes (any stream) wait for it."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.__dict__.setdefault("_writers", []).append(ev)
+
+    def _wait_writers(self, also_side_streams=False):
+        cur = torch.cuda.current_stream()
+        for ev in self.__dict__.get("_writers", ()):
+            cur.wait_event(ev)
+        if also_side_streams:          # a non-atomic writer must not run next to ANY other backward kernel of the field
+            pool = self.__dict__.get("_side_pool")
+            if pool is not None:
+                for st in pool["r"] + [pool["p"]]:
+                    if st != cur:
+                        cur.wait_stream(st)
+
+    def _queue_join(self):
+        """Once per backward pass: when the engine has run every node, the stream of the thread that called backward() waits for the
+        field's side streams - the optimiser step that follows then sees complete gradients (the engine itself only orders the
+        gradients it is handed, and in-place accumulation hands it none)."""
+        if self.__dict__.get("_join_pending"):
+            return
+        self.__dict__["_join_pending"] = True
+        ref = weakref.ref(self)
+
+        def join():
+            f = ref()
+            if f is None:
+                return
+            f.__dict__["_join_pending"] = False
+            f.__dict__["_writers"] = []
+            pool = f.__dict__.get("_side_pool")
+            if pool is not None:
+                cur = torch.cuda.current_stream()
+                for st in pool["r"] + [pool["p"]]:
+                    cur.wait_stream(st)
+
+        from torch.autograd import Variable
+        Variable._execution_engine.queue_callback(join)
 
     # ------------------------------------------------------------------ hot path
     def forward(self, t, ray_o, ray_d, white_bg=True, ndc_ray=False, N_samples=-1, transfer_vel=False):
@@ -449,7 +636,21 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             flags |= _lib.NVFI_WANT_MASK
         t = float(np.float32(float(t)))
         params = self._render_params()
-        if training and torch.is_grad_enabled():
+        if training and self._use_side_streams():
+            # the render runs on one of the field's two render streams (ordered behind everything queued on the caller's stream so far,
+            # e.g. the last optimiser step); the caller's stream waits for the outputs.  Autograd runs the backward on this stream too.
+            cur = torch.cuda.current_stream()
+            side = self._side_stream("r")
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                rgb, depth, acc, weights, cnt = _RenderFn.apply(self, t, ray_o, ray_d, jitter, flags, *params)
+            cur.wait_stream(side)
+            for x in (rgb, depth, acc, weights, cnt):
+                x.record_stream(cur)
+            for x in (ray_o, ray_d, jitter):
+                if x is not None:
+                    x.record_stream(side)
+        elif training and torch.is_grad_enabled():
             rgb, depth, acc, weights, _ = _RenderFn.apply(self, t, ray_o, ray_d, jitter, flags, *params)
         else:
             with torch.no_grad():
@@ -591,6 +792,16 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         """PDE regulariser on explicit collocation points (world-space (P,3), raw t (P,1)); models/nvfi.py:42-84."""
         points = points.reshape(-1, 3).contiguous().float()
         t = t.reshape(-1).contiguous().float()
+        if self._use_side_streams():
+            cur = torch.cuda.current_stream()
+            side = self._side_stream("p")
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                loss = _PdeFn.apply(self, points, t, *self._pde_params())
+            cur.wait_stream(side)
+            loss.record_stream(cur)
+            points.record_stream(side); t.record_stream(side)
+            return loss
         return _PdeFn.apply(self, points, t, *self._pde_params())
 
     @torch.no_grad()
@@ -663,8 +874,8 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         return list(self.density_plane_space) + list(self.density_plane_time) + list(self.app_plane_space)
 
     def _reg_on_device(self, reg=None):
-        from ..utils.tensorf_utils import TVLoss
-        return self.aabb.is_cuda and not self.__dict__.get("regs_torch_ops", False) and self.density_n_comp[0] % 4 == 0 and self.app_n_comp[0] % 4 == 0 and (reg is None or type(reg) is TVLoss)
+        from ..utils.tensorf_utils import is_reference_tvloss
+        return self.aabb.is_cuda and not self.__dict__.get("regs_torch_ops", False) and self.density_n_comp[0] % 4 == 0 and self.app_n_comp[0] % 4 == 0 and (reg is None or is_reference_tvloss(reg))
 
     def density_L1(self):
         if self._reg_on_device():

@@ -24,3 +24,35 @@ class TVLoss(nn.Module):
             h_tv = h_tv * 3
         w_tv = torch.pow(x[:, :, :, 1:] - x[:, :, :, :w - 1], 2).sum()
         return self.TVLoss_weight * 2 * (h_tv / count_h + w_tv / count_w) / b
+
+
+_TV_OK = {}
+
+
+def is_reference_tvloss(reg):
+    """True when `reg` computes the reference's TVLoss (utils/tensorf_utils.py:139-158) - whichever module its class came from.
+
+    train_nvfi.py builds `tvreg = TVLoss()` from the REFERENCE's own `utils` package (`from utils import *`, train_nvfi.py:17,132), so an
+    exact-type test against this module's class would push every TV term of the real driver off the fused kernel.  The test is
+    structural - class name, a numeric `TVLoss_weight`, `forward(x, t=False)` - plus a behavioural fingerprint: the module is evaluated
+    once per class on a tiny CPU tensor (space and time variants) and must reproduce the formula.  The verdict is cached per class."""
+    cls = type(reg)
+    ok = _TV_OK.get(cls)
+    if ok is None:
+        ok = False
+        try:
+            import inspect
+            params = list(inspect.signature(cls.forward).parameters.values())
+            if cls.__name__ == "TVLoss" and len(params) == 3 and params[2].default is False:
+                x = (torch.arange(24, dtype=torch.float32).reshape(1, 2, 3, 4) % 5) * 0.25 - 0.5
+                probe = cls.__new__(cls)
+                nn.Module.__init__(probe)
+                probe.TVLoss_weight = 1.0
+                mine = TVLoss(1.0)
+                with torch.no_grad():
+                    ok = all(abs(float(probe(x, t=tt)) - float(mine(x, t=tt))) <= 1e-6 * abs(float(mine(x, t=tt))) for tt in (False, True))
+        except Exception:
+            ok = False
+        _TV_OK[cls] = ok
+    w = getattr(reg, "TVLoss_weight", None)
+    return bool(ok) and isinstance(w, (int, float)) and not isinstance(w, bool)

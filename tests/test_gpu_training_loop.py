@@ -22,7 +22,7 @@ def _cu(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("driver", ["dropin", "fused"])
+@pytest.mark.parametrize("driver", ["dropin", "dropin-pure-autograd", "fused"])
 def test_three_training_iterations_match_the_reference(driver):
     import models                                  # the drop-in alias of the reference's package
     from nvfi_amd.utils import TVLoss
@@ -43,6 +43,13 @@ def test_three_training_iterations_match_the_reference(driver):
         optimizer = Adam(groups, betas=(0.9, 0.99))
         f.accumulate_grads_inplace = True
     else:
+        # "dropin": the field's defaults under a plain autograd driver (in-place gradient arena, train-mode calls on its side streams);
+        # "dropin-pure-autograd": gradients handed back to the autograd engine, everything on the caller's stream (round-2 behaviour)
+        if driver == "dropin-pure-autograd":
+            f.accumulate_grads_inplace, f.auto_overlap = False, False
+        else:
+            assert f.accumulate_grads_inplace == "arena" and f.auto_overlap
+        driver = "dropin"
         optimizer = torch.optim.Adam(groups, betas=(0.9, 0.99))
     lr_factor = 0.1 ** (1 / 30000)
     L1w, tvd, tva, vw = 8e-4, 1.0, 1.0, 1.0
@@ -84,7 +91,6 @@ def test_three_training_iterations_match_the_reference(driver):
         for g in optimizer.param_groups:
             g["lr"] = g["lr"] * lr_factor
         np.testing.assert_allclose(total, float(g2[f"A:loop:{it}:loss"].reshape(-1)[0]), rtol=2e-4, err_msg=f"iteration {it}")
-    f.accumulate_grads_inplace = False
     nvfi.vel_loss_weight = None
     assert losses[2] < losses[1] < losses[0]
     # parameters after three Adam steps.  Adam normalises every element's step by its own gradient history, so an element whose gradient

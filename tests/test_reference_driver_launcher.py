@@ -1,0 +1,138 @@
+"""tools/run_reference_driver.py: the reference's untouched training driver must import THIS repository's `models` (the script's own
+directory precedes PYTHONPATH, so a plain `python train_nvfi.py` would not), while `utils` / `datasets` stay the checkout's own; and the
+`TVLoss` object that driver builds from ITS `utils` package must stay on the fused regulariser kernel.  The checkout here is a decoy
+written by the test (a `models/` package that refuses to be imported, a `utils/` with a TVLoss look-alike, a driver script); when
+/root/reference exists (build container) the real checkout is resolved too."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+LAUNCHER = os.path.join(ROOT, "tools", "run_reference_driver.py")
+
+UTILS = '''
+import torch, torch.nn as nn
+class TVLoss(nn.Module):            # same structure as the reference's regulariser, defined in a foreign module
+    def __init__(self, TVLoss_weight=1):
+        super().__init__()
+        self.TVLoss_weight = TVLoss_weight
+    def forward(self, x, t=False):
+        b, c, h, w = x.size()
+        h_tv = ((x[:, :, 1:, :] - x[:, :, :-1, :]) ** 2).sum() * (3 if t else 1)
+        w_tv = ((x[:, :, :, 1:] - x[:, :, :, :-1]) ** 2).sum()
+        return self.TVLoss_weight * 2 * (h_tv / (c * (h - 1) * w) + w_tv / (c * h * (w - 1))) / b
+class NotTV(nn.Module):             # wrong formula under the right name elsewhere -> must NOT be taken for the reference's
+    TVLoss_weight = 1
+    def forward(self, x, t=False):
+        return x.abs().mean()
+'''
+
+
+def _decoy(tmp_path, driver_body):
+    co = tmp_path / "checkout"
+    (co / "models").mkdir(parents=True)
+    (co / "utils").mkdir()
+    (co / "models" / "__init__.py").write_text("raise ImportError('the checkout\\'s own models package was imported')\n")
+    (co / "utils" / "__init__.py").write_text(UTILS)
+    (co / "datasets").mkdir()
+    (co / "datasets" / "__init__.py").write_text("WHO = 'checkout'\n")
+    (co / "train_nvfi.py").write_text(textwrap.dedent(driver_body))
+    return co
+
+
+def test_plain_python_would_import_the_checkouts_models(tmp_path):
+    co = _decoy(tmp_path, "from models import *\n")
+    r = subprocess.run([sys.executable, str(co / "train_nvfi.py")], env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True)
+    assert r.returncode != 0 and "checkout's own models" in r.stderr        # the problem the launcher exists for
+
+
+def test_launcher_orders_the_packages(tmp_path):
+    co = _decoy(tmp_path, """
+        import json, sys
+        from models import *
+        from utils import *
+        from datasets import *
+        import models, utils, nvfi_amd.models
+        from nvfi_amd.utils.tensorf_utils import is_reference_tvloss
+        tv = TVLoss()
+        print(json.dumps(dict(models_is_ours=models.NVFi is nvfi_amd.models.NVFi, utils=utils.__file__, who=WHO, argv=sys.argv[1:],
+                              tv_module=type(tv).__module__, tv_fused=is_reference_tvloss(tv), nottv_fused=is_reference_tvloss(NotTV()))))
+    """)
+    r = subprocess.run([sys.executable, LAUNCHER, str(co / "train_nvfi.py"), "--config", "x.yaml", "--static_dynamic"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["models_is_ours"] and d["who"] == "checkout" and d["utils"].startswith(str(co))
+    assert d["argv"] == ["--config", "x.yaml", "--static_dynamic"]
+    assert d["tv_module"] == "utils" and d["tv_fused"] is True and d["nottv_fused"] is False
+
+
+def test_tvloss_check_is_structural():
+    from nvfi_amd.utils import TVLoss
+    from nvfi_amd.utils.tensorf_utils import is_reference_tvloss
+    ns = {}
+    exec(UTILS, ns)
+    assert is_reference_tvloss(TVLoss()) and is_reference_tvloss(ns["TVLoss"](0.5))
+    assert not is_reference_tvloss(ns["NotTV"]())
+    assert not is_reference_tvloss(torch.nn.Identity())
+    bad = ns["TVLoss"]()
+    bad.TVLoss_weight = torch.ones(1)           # a tensor weight would need a device read: torch-op path
+    assert not is_reference_tvloss(bad)
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/train_nvfi.py"), reason="the reference checkout exists in the build container only")
+def test_launcher_resolves_the_real_checkout():
+    r = subprocess.run([sys.executable, LAUNCHER, "--check", "--stub-missing", "/root/reference/train_nvfi.py"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["resolved"]["models"] == os.path.join(ROOT, "models")
+    assert d["resolved"]["utils"] == "/root/reference/utils" and d["resolved"]["datasets"] == "/root/reference/datasets"
+    assert d["reference_TVLoss_on_fused_kernel"] is True
+
+
+@pytest.mark.gpu
+def test_launched_driver_trains_on_the_hip_path(tmp_path):
+    """A driver in the reference's shape (models / utils from two different places, TVLoss from the checkout's utils, plain autograd,
+    torch.optim.Adam) runs two iterations through the launcher; the TV terms must have gone through the fused kernel."""
+    co = _decoy(tmp_path, f"""
+        import json, sys
+        sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+        import torch
+        from models import *
+        from utils import *
+        from helpers import make_model
+        import nvfi_amd.models.tensorf_keyframe as tk
+        calls = []
+        orig = tk._RegFn.forward
+        tk._RegFn.forward = staticmethod(lambda ctx, field, which, *p: (calls.append(which), orig(ctx, field, which, *p))[1])
+        nvfi, meta = make_model("A")
+        ren = Renderer(nvfi, 0, 0, 2048)
+        tvreg = TVLoss()
+        opt = torch.optim.Adam(nvfi.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+        o = torch.tensor([[0.0, 0.0, 4.0]]).repeat(512, 1).cuda()
+        d = torch.nn.functional.normalize(torch.randn(512, 3).cuda() * 0.15 + torch.tensor([0.0, 0.0, -1.0]).cuda(), dim=-1)
+        losses = []
+        for it in range(2):
+            nvfi.train(); ren.train()
+            rgb = ren.render(19 / 60.0, Ray(o, d, float(meta["near"]), float(meta["far"])), white_background=True, mode="train")[0]
+            loss = torch.nn.functional.mse_loss(rgb, torch.rand_like(rgb))
+            loss = loss + 8e-4 * nvfi.nvfi.density_L1() + nvfi.nvfi.TV_loss_density(tvreg) * 1.0 + nvfi.nvfi.TV_loss_app(tvreg) * 1.0
+            lv = nvfi.get_vel_loss(4096)
+            if lv > 0:
+                loss = loss + lv
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        print(json.dumps(dict(losses=losses, reg_calls=calls, tv_module=type(tvreg).__module__)))
+    """)
+    r = subprocess.run([sys.executable, LAUNCHER, str(co / "train_nvfi.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["tv_module"] == "utils" and d["reg_calls"] == [0, 1, 2, 0, 1, 2]
+    assert all(l == l and 0 < l < 10 for l in d["losses"])
