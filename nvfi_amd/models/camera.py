@@ -58,10 +58,25 @@ class Camera(object):
             raise NotImplementedError("ndc rays are out of scope (ndc: False in every shipped config)")
         self.pose, self.height, self.width, self.focal = pose, height, width, focal
         self.target, self.near, self.far, self.t, self.dpt = target, near, far, t, dpt
-        ii, jj = torch.meshgrid(torch.arange(height, device=pose.device), torch.arange(width, device=pose.device), indexing="ij")
-        self.coords = torch.stack([ii, jj], dim=-1).reshape(-1, 2)
-        ray_origins, ray_directions = self.get_ray_bundle()
-        self.rays = Ray(ray_origins, ray_directions, near, far, t)
+        self._coords = self._rays = None
+
+    # The reference builds the pixel grid and the whole H*W ray bundle in the constructor (camera.py:96-101) and train_nvfi.py constructs a
+    # Camera every iteration; both are materialised on first use here (same values), so a driver that only draws a batch through
+    # sample_rays_device pays for 2048 rays instead of 640 000.
+    @property
+    def coords(self):
+        if self._coords is None:
+            dev = self.pose.device
+            ii, jj = torch.meshgrid(torch.arange(self.height, device=dev), torch.arange(self.width, device=dev), indexing="ij")
+            self._coords = torch.stack([ii, jj], dim=-1).reshape(-1, 2)
+        return self._coords
+
+    @property
+    def rays(self):
+        if self._rays is None:
+            ray_origins, ray_directions = self.get_ray_bundle()
+            self._rays = Ray(ray_origins, ray_directions, self.near, self.far, self.t)
+        return self._rays
 
     def get_ray_bundle(self):
         X, Y = torch.meshgrid(torch.arange(self.width, dtype=self.pose.dtype, device=self.pose.device),

@@ -18,6 +18,17 @@ import torch.nn.functional as F
 
 from .. import _lib
 from .tensorf_model_utils import AlphaGridMask
+
+# per-field runtime state that must not travel with copy.deepcopy / pickle of the module (HIP streams, events, pinned buffers, the
+# gradient arena): kept beside the module, keyed weakly
+_RUNTIME = weakref.WeakKeyDictionary()
+
+
+def _rt(field):
+    d = _RUNTIME.get(field)
+    if d is None:
+        d = _RUNTIME[field] = {}
+    return d
 from .velocity_field import VelBasis, VelocityAABB, VelocityAABBSur
 
 
@@ -313,10 +324,12 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         #   True               same, but the caller owns p.grad (nvfi_amd.dist.GradBucket: every .grad is a view of its flat buffer)
         #   False              pure autograd: gradients are returned to the engine (NVFI_INPLACE_GRADS=0)
         self.accumulate_grads_inplace = "arena" if os.environ.get("NVFI_INPLACE_GRADS", "1") != "0" else False
-        # Train-mode render / PDE calls run on the field's own side streams (the caller's stream waits for the results): under an
-        # unmodified sequential driver the two renders and the PDE term of an iteration - and their backward passes, which autograd
-        # runs on the stream of the forward - overlap on the device like in bench.py's three-stream step.  NVFI_AUTO_OVERLAP=0: off.
-        self.auto_overlap = os.environ.get("NVFI_AUTO_OVERLAP", "1") != "0"
+        # Opt-in (NVFI_AUTO_OVERLAP=1): train-mode render / PDE calls run on the field's own side streams (the caller's stream waits for
+        # the results), so that the chains of an iteration - and their backward passes, which autograd runs on the stream of the forward -
+        # can overlap on the device under a sequential driver.  MEASURED SLOWER under the reference's loop (bench.py --mode dropin:
+        # 372-438 k rays/s against 481 k on one stream): that loop waits for the device three times per iteration, so it is bound by the
+        # host's issue time between the waits, and the extra cross-stream waits / record_stream bookkeeping only add to it.  Off by default.
+        self.auto_overlap = os.environ.get("NVFI_AUTO_OVERLAP", "0") == "1"
         self.pde_debug = 0   # >0: also return the kept mask and the first n Jacobians of get_vel_loss
         self.register_load_state_dict_post_hook(lambda m, k: m.update_stepSize(m.gridSize.tolist()))
 
@@ -363,7 +376,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
-        self.__dict__.pop("_rp_cache", None); self.__dict__.pop("_pp_cache", None)
+        _rt(self).pop("_rp_cache", None); _rt(self).pop("_pp_cache", None)
         self._fix_layout()
         self.device = self.aabb.device
         for name in ("gridSize", "aabbSize", "invaabbSize", "units", "stepSize", "aabbDiag"):
@@ -384,11 +397,11 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         step makes seven of them), so the list is cached and re-validated by the identities of the plane parameters / sub-modules
         (shrink / upsample_volume_grid replace them; `.to()` keeps them)."""
         key = self._param_key()
-        c = self.__dict__.get("_rp_cache")
+        c = _rt(self).get("_rp_cache")
         if c is not None and c[0] == key:
             return list(c[1])
         ps = self._render_params_walk()
-        self.__dict__["_rp_cache"] = (key, tuple(ps))
+        _rt(self)["_rp_cache"] = (key, tuple(ps))
         return ps
 
     def _render_params_walk(self):
@@ -405,12 +418,12 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         return ps
 
     def _pde_params(self):
-        c = self.__dict__.get("_pp_cache")
+        c = _rt(self).get("_pp_cache")
         vn = self.__dict__["_modules"].get("vel_net")
         if c is not None and c[0] == id(vn):
             return list(c[1])
         ps = self._pde_params_walk()
-        self.__dict__["_pp_cache"] = (id(vn), tuple(ps))
+        _rt(self)["_pp_cache"] = (id(vn), tuple(ps))
         return ps
 
     def _pde_params_walk(self):
@@ -506,7 +519,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         want_tail: return the flat view that covers the 24 velocity-net tensors instead (they are contiguous at the end)."""
         ps = self._arena_params()
         key = tuple((id(p), tuple(p.shape), p.stride()) for p in ps)
-        a = self.__dict__.get("_arena")
+        a = _rt(self).get("_arena")
         if a is None or a["key"] != key or a["flat"].device != ps[0].device:
             offs, total = [], 0
             for p in ps:
@@ -515,7 +528,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             flat = torch.zeros(total, dtype=torch.float32, device=ps[0].device)
             views = {id(p): flat[o:o + p.numel()].as_strided(p.shape, p.stride()) for p, o in zip(ps, offs)}
             a = dict(key=key, flat=flat, views=views, offs=offs, params=ps, event=None, tail=flat[offs[-24]:] if (self.use_vel and len(ps) >= 24) else None)
-            self.__dict__["_arena"] = a
+            _rt(self)["_arena"] = a
         # only the parameters THIS node differentiates are attached: a parameter no term of the loss reaches keeps .grad = None and the
         # optimiser skips it, exactly as under pure autograd
         wanted = {id(p) for p, n in zip(params, need) if n and p is not None}
@@ -553,11 +566,11 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         return out
 
     def _side_stream(self, kind):
-        pool = self.__dict__.get("_side_pool")
+        pool = _rt(self).get("_side_pool")
         if pool is None:
             dev = self.aabb.device
             pool = dict(r=[torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)], p=torch.cuda.Stream(device=dev), k=0)
-            self.__dict__["_side_pool"] = pool
+            _rt(self)["_side_pool"] = pool
         if kind == "p":
             return pool["p"]
         pool["k"] += 1
@@ -571,14 +584,14 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         """The current stream just queued a non-atomic read-modify-write of gradient memory: later backward nodes (any stream) wait for it."""
         ev = torch.cuda.Event()
         ev.record()
-        self.__dict__.setdefault("_writers", []).append(ev)
+        _rt(self).setdefault("_writers", []).append(ev)
 
     def _wait_writers(self, also_side_streams=False):
         cur = torch.cuda.current_stream()
-        for ev in self.__dict__.get("_writers", ()):
+        for ev in _rt(self).get("_writers", ()):
             cur.wait_event(ev)
         if also_side_streams:          # a non-atomic writer must not run next to ANY other backward kernel of the field
-            pool = self.__dict__.get("_side_pool")
+            pool = _rt(self).get("_side_pool")
             if pool is not None:
                 for st in pool["r"] + [pool["p"]]:
                     if st != cur:
@@ -588,18 +601,18 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         """Once per backward pass: when the engine has run every node, the stream of the thread that called backward() waits for the
         field's side streams - the optimiser step that follows then sees complete gradients (the engine itself only orders the
         gradients it is handed, and in-place accumulation hands it none)."""
-        if self.__dict__.get("_join_pending"):
+        if _rt(self).get("_join_pending"):
             return
-        self.__dict__["_join_pending"] = True
+        _rt(self)["_join_pending"] = True
         ref = weakref.ref(self)
 
         def join():
             f = ref()
             if f is None:
                 return
-            f.__dict__["_join_pending"] = False
-            f.__dict__["_writers"] = []
-            pool = f.__dict__.get("_side_pool")
+            _rt(f)["_join_pending"] = False
+            _rt(f)["_writers"] = []
+            pool = _rt(f).get("_side_pool")
             if pool is not None:
                 cur = torch.cuda.current_stream()
                 for st in pool["r"] + [pool["p"]]:
@@ -842,8 +855,8 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         ov = self.__dict__.get("jitter_override")
         if ov is not None:       # tests: explicit per-ray jitter instead of a draw
             return ov.to(device).reshape(-1).float().contiguous()
-        ring = self.__dict__.setdefault("_jit_ring", [])      # entries: [pinned buffer, event recorded after its last upload]
-        idx = self.__dict__.get("_jit_idx", 0)
+        ring = _rt(self).setdefault("_jit_ring", [])      # entries: [pinned buffer, event recorded after its last upload]
+        idx = _rt(self).get("_jit_idx", 0)
         if len(ring) < 4:
             ring.append([torch.empty(max(R, 4096), 1).pin_memory(), None])
         slot = ring[idx % len(ring)]
@@ -851,7 +864,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             slot[1].synchronize()      # the asynchronous copy that last read this buffer must have executed before it is rewritten
         if slot[0].shape[0] < R:
             slot[0] = torch.empty(R, 1).pin_memory()
-        self.__dict__["_jit_idx"] = idx + 1
+        _rt(self)["_jit_idx"] = idx + 1
         view = slot[0][:R]
         torch.rand(R, 1, out=view)
         out = view.to(device, non_blocking=True).reshape(-1)
@@ -862,7 +875,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
 
     def _scratch(self, key, nbytes, device):
         """Reusable workspace for calls whose workspace does not have to outlive the call."""
-        cache = self.__dict__.setdefault("_scratch_cache", {})
+        cache = _rt(self).setdefault("_scratch_cache", {})
         buf = cache.get(key)
         if buf is None or buf.numel() < nbytes or buf.device != device:
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

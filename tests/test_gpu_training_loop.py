@@ -22,7 +22,7 @@ def _cu(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("driver", ["dropin", "dropin-pure-autograd", "fused"])
+@pytest.mark.parametrize("driver", ["dropin", "dropin-side-streams", "dropin-pure-autograd", "fused"])
 def test_three_training_iterations_match_the_reference(driver):
     import models                                  # the drop-in alias of the reference's package
     from nvfi_amd.utils import TVLoss
@@ -43,12 +43,14 @@ def test_three_training_iterations_match_the_reference(driver):
         optimizer = Adam(groups, betas=(0.9, 0.99))
         f.accumulate_grads_inplace = True
     else:
-        # "dropin": the field's defaults under a plain autograd driver (in-place gradient arena, train-mode calls on its side streams);
+        # "dropin": the field's defaults under a plain autograd driver (in-place gradient arena);
         # "dropin-pure-autograd": gradients handed back to the autograd engine, everything on the caller's stream (round-2 behaviour)
+        # "dropin-side-streams": + the opt-in auto_overlap (train-mode calls on the field's own streams, joined at the end of backward)
         if driver == "dropin-pure-autograd":
             f.accumulate_grads_inplace, f.auto_overlap = False, False
         else:
-            assert f.accumulate_grads_inplace == "arena" and f.auto_overlap
+            assert f.accumulate_grads_inplace == "arena" and not f.auto_overlap
+            f.auto_overlap = driver == "dropin-side-streams"
         driver = "dropin"
         optimizer = torch.optim.Adam(groups, betas=(0.9, 0.99))
     lr_factor = 0.1 ** (1 / 30000)
