@@ -299,6 +299,133 @@ class Step:
         return loss
 
 
+class GraphedStep:
+    """The same iteration as Step (three streams), captured ONCE as a hipGraph and replayed: per iteration the host draws what the
+    reference draws on the host (frame index, keyframe index, the CPU-generator jitter of both renders), advances the decaying loss
+    weights / learning rates / Adam bias corrections, writes all of it into one pinned record, uploads it with one asynchronous copy and
+    launches the graph.  Everything the kernels need per iteration is read from that record in device memory:
+      rec[0] t of the non-keyframe render, rec[1] t of the keyframe render   (DeviceTime -> nvfi_render_fwd_t / _bwd_t: keyframe row,
+                                                                              RK2 step sizes and times are derived on the device)
+      rec[2:5] L1 / TV-density / TV-app weights (nvfi_plane_regs_dev), rec[5] PDE weight (nvfi_pde_loss_dev)
+      rec[16:16+1+n] Adam: 1/sqrt(1-b2^t), lr_k/(1-b1^t) per tensor (nvfi_adam_step_dev)
+      then the two per-ray jitter vectors.
+    Ray indices / targets and the collocation points are drawn on the device generators INSIDE the graph (registered with it), as in Step.
+    The host is out of the step: ~0.1 ms of Python per iteration instead of ~4 ms of launches."""
+    HEAD = 16
+
+    def __init__(self, step):
+        from nvfi_amd.models import DeviceTime
+        self.DeviceTime = DeviceTime
+        self.s = s = step
+        self.n_t = sum(1 for g in s.opt.param_groups for p in g["params"] if p.grad is not None)
+        self.n_hyper = 1 + self.n_t
+        self.renders = 2 if s.workload == "cfg3" else 1
+        self.off_jit = (self.HEAD + self.n_hyper + 63) // 64 * 64
+        self.total = self.off_jit + self.renders * s.n_rays
+        self.rec = torch.zeros(self.total, device=s.dev)
+        self.ring = [[torch.zeros(self.total).pin_memory(), None] for _ in range(4)]
+        self.k = 0
+        self.graph = None
+        self.flags = []          # counters tensors of the captured renders (entry 7: device-time plan mismatch)
+
+    def host_record(self):
+        """one iteration's host-side draws and decays, in Step._step_streams' order -> pinned record -> device (asynchronous)"""
+        s = self.s
+        slot = self.ring[self.k % len(self.ring)]
+        self.k += 1
+        if slot[1] is not None:
+            slot[1].synchronize()       # the upload that last read this pinned buffer has executed
+        buf = slot[0]
+        if s.workload == "cfg3":
+            i = int(s.rng.integers(0, 46))
+            while i % 3 == 0:
+                i = int(s.rng.integers(0, 46))
+            buf[0] = float(np.float32(i / 60.0))
+            buf[1] = float(np.float32(3 * int(s.rng.integers(0, 16)) / 60.0))
+            s.vw *= s.lr_factor
+        else:
+            buf[1] = float(np.float32(float(s.rng.integers(0, 46)) / 60.0))
+        s.L1w *= s.lr_factor; s.tvd *= s.lr_factor; s.tva *= s.lr_factor
+        buf[2], buf[3], buf[4], buf[5] = s.L1w, s.tvd, s.tva, s.vw
+        h = s.opt.next_hyper()
+        buf[self.HEAD:self.HEAD + self.n_hyper] = torch.tensor(h, dtype=torch.float32)
+        for g in s.opt.param_groups:
+            g["lr"] = g["lr"] * s.lr_factor
+        # the per-ray jitter of the renders: the reference's CPU-generator draw (tensorf_base.py:302-306), non-keyframe render first
+        for k in range(self.renders):
+            torch.rand(s.n_rays, 1, out=buf[self.off_jit + k * s.n_rays: self.off_jit + (k + 1) * s.n_rays].view(s.n_rays, 1))
+        self.rec.copy_(buf, non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record()
+
+    def body(self):
+        """the device side of one iteration; every per-iteration scalar is a view of self.rec"""
+        s, rec, DT = self.s, self.rec, self.DeviceTime
+        m, f = s.m, s.m.nvfi
+        R = s.n_rays
+        jit = [rec[self.off_jit + k * R: self.off_jit + (k + 1) * R] for k in range(self.renders)]
+        main = torch.cuda.current_stream()
+        if s.workload == "cfg3":
+            s_pde, s_r1 = s.streams if s.streams is not None else (main, main)
+            start = torch.cuda.Event(); start.record(main)
+            with torch.cuda.stream(s_pde):
+                s_pde.wait_event(start)
+                m.vel_loss_weight = rec[5:6]
+                s.last_lv = m.get_vel_loss(s.n_pts)
+            with torch.cuda.stream(s_r1):
+                s_r1.wait_event(start)
+                rays, target = s.rays()
+                f.jitter_override = jit[0]
+                out = s.ren.render(DT(19.0 / 60.0, rec[0:1]), rays, white_background=True, mode="train")      # plan: a non-keyframe time (1 RK2 step)
+                self.flags.append(f.last_counters)
+                torch.nn.functional.mse_loss(out[0], target).backward()
+        rays, target = s.rays()
+        f.jitter_override = jit[-1]
+        out = s.ren.render(DT(0.05 if s.workload == "cfg3" else 0.3, rec[1:2]), rays, white_background=True, mode="train")   # plan: a keyframe time / any time without a velocity field
+        f.jitter_override = None
+        self.flags.append(f.last_counters)
+        loss = torch.nn.functional.mse_loss(out[0], target)
+        loss.backward()
+        if s.workload == "cfg3":
+            main.wait_stream(s_pde); main.wait_stream(s_r1)
+        s.last_regs = f.regularizers_backward_(rec[2:5])
+        s.opt.step(zero_grad=True, hyper_dev=rec[self.HEAD:self.HEAD + self.n_hyper])
+        self.loss = loss
+
+    def capture(self):
+        s = self.s
+        self.host_record()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        g.register_generator_state(s.gen)
+        cap = torch.cuda.Stream(device=s.dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            self.body()                 # eager once on the capture stream: first-touch of this stream's allocator pools
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        self.flags.clear()
+        self.host_record()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=cap):
+            self.body()
+        self.graph = g
+        g.replay()                      # the captured iteration itself (its record was uploaded above)
+        torch.cuda.synchronize()
+
+    def __call__(self):
+        self.host_record()
+        self.graph.replay()
+        return self.loss
+
+    def check(self):
+        """after the run: did any replayed render see a time outside its captured plan class?"""
+        bad = sum(int(c[7].item()) for c in self.flags)
+        if bad:
+            raise SystemExit("GraphedStep: a device-side frame time did not match the captured RK2 plan (counters[7])")
+
+
 class DropinStep:
     """The reference's loop body (train_nvfi.py:139-249, --static_dynamic) on the `models` alias package, unchanged in structure:
     plain autograd through `renderer.render`, `nvfi.get_vel_loss` + `if loss_vel > 0`, the torch-op regularisers, torch.optim.Adam with
@@ -480,6 +607,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the separate profiled pass (default: min(steps, 5); 0: none)")
     ap.add_argument("--prime", type=int, default=8, help="setup iterations before the W warm-up steps (first-touch of the workspaces, allocator pools of the three streams, clocks): the first ~5 iterations of a process run 5-10 %% slower than steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the whole iteration as one captured hipGraph with a device-side time schedule (auto: on for the single-GPU fused driver)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -538,14 +667,23 @@ def main():
 
     for _ in range(args.prime):          # setup
         step()
+    use_graph = args.mode == "fused" and (args.graph == "on" or (args.graph == "auto" and world == 1 and not os.environ.get("NVFI_TORCH_ADAM")))
+    run = step
+    if use_graph:
+        if world > 1:
+            raise SystemExit("--graph on: the captured step is single-GPU (the multi-rank step keeps its eager three-stream order around the RCCL exchange)")
+        run = GraphedStep(step)
+        run.capture()
     for _ in range(args.warmup):         # the contract's W untimed warm-up steps
-        step()
+        run()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     barrier()
     dt = time.perf_counter() - t0
+    if use_graph:
+        run.check()
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -632,7 +770,10 @@ def main():
                                 "bat.yaml radiance-only (configs[1]): 199^3 grid, 128 samples/ray, 2048-ray batches of the 800x800 frame"),
                    "rays_per_step_per_gpu": n_rays * renders, "pde_points_per_gpu": n_pts if args.workload == "cfg3" else 0,
                    "grid": args.grid, "samples_per_ray": args.samples, "parallelism": f"ray-sharded x{world}",
-                   "driver": args.mode, "field": "live (updated by the optimiser)" if args.live else "stationary (optimiser steps a shadow copy)"},
+                   "driver": args.mode,
+                   "launch": ("one hipGraph replay per iteration (three captured streams; frame times, loss weights, learning rates and jitter read from a device record uploaded per iteration)"
+                              if use_graph else "eager launches"),
+                   "field": "live (updated by the optimiser)" if args.live else "stationary (optimiser steps a shadow copy)"},
         "work_per_step": work,
         "roofline": roof,
     }

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NVFI_ABI_VERSION 2
+#define NVFI_ABI_VERSION 3
 
 /* Field description: TensorVMKeyframeTimeKplane state that reaches the hot path
  * (reference models/tensorf_keyframe.py:37-134, models/tensorf_base.py:133-227). */
@@ -69,7 +69,7 @@ typedef struct nvfi_grads {
 #define NVFI_WANT_MASK 8  /* plan workspace room for nvfi_render_mask (mask_field attached) */
 
 /* counters written by nvfi_render_fwd (device int64[8]):
- * 0 valid samples V, 1 warped samples N, 2 appearance-masked samples M, 3 velocity-net evaluations */
+ * 0 valid samples V, 1 warped samples N, 2 appearance-masked samples M, 3 velocity-net evaluations, 7 device-time plan mismatch (nvfi_render_fwd_t) */
 #define NVFI_NCOUNTERS 8
 
 const char* nvfi_last_error(void);
@@ -98,6 +98,20 @@ int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R,
                     const nvfi_grads* grads,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- the same two calls with the frame time in DEVICE memory (ABI v3), so that a training iteration can be captured once as a hipGraph and
+ *      replayed with a new time every iteration (train_nvfi.py:150-158 draws a new frame per iteration): `t` still fixes the launch plan
+ *      on the host - how many RK2 steps the warp takes, hence which kernels run and how the workspace is laid out - while the kernels
+ *      take the time itself from *t_dev (keyframe row, step sizes and step times are derived on the device, same arithmetic).  *t_dev
+ *      must lie in the same plan class as `t` (same number of RK2 steps back to its keyframe: true for all non-keyframe frame times of
+ *      the shipped configs, and for all keyframe times); if it does not, the call renders `t` and sets counters[7] = 1.
+ *      t_dev == NULL / t_on_device == 0: exactly nvfi_render_fwd / nvfi_render_bwd. */
+int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d, const float* jitter,
+                      float t, const float* t_dev, int flags, float* rgb, float* depth, float* acc, float* weights,
+                      void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream);
+int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d, float t, int t_on_device, int flags,
+                      const float* weights, const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_weights,
+                      const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- PDE regulariser: replaces NVFi.get_vel_loss (models/nvfi.py:42-84) with explicit collocation
  *      points (world space (P,3)) and raw times (P).  out (device float[4]): loss, n_kept, sum div^2,
  *      sum transport^2.  grads: vW,vb,aW,ab are accumulated scaled by `loss_scale` when non-NULL. */
@@ -115,6 +129,10 @@ int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float* points, c
                      float loss_scale, float* out, const nvfi_grads* grads,
                      void* workspace, int64_t workspace_bytes, int64_t* counters,
                      uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream);
+
+/* nvfi_pde_loss with the loss scale (train_nvfi.py:229-234: vel_reg_weight, decayed every iteration) read from device memory */
+int nvfi_pde_loss_dev(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, const float* loss_scale_dev,
+                      float* out, const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream);
 
 /* ---- mask branch of render_pts (models/tensorf_keyframe.py:673-676, 749-753) with the MaskField as train_segm.py:97-102
  *      builds it: 3 -> n_dim x n_layer (ReLU) -> mask_dim, softmax.  Call after nvfi_render_fwd with the same workspace:
@@ -165,6 +183,10 @@ int nvfi_plane_regs_dev(const nvfi_field_desc* f, const float* w3_dev, float* ou
  *      n elements each, lr the tensor's learning rate; `step` counts from 1 (bias corrections); zero_grad != 0 clears g in the same pass. */
 typedef struct nvfi_adam_tensor { float* p; float* g; float* m; float* v; int64_t n; float lr; } nvfi_adam_tensor;
 int nvfi_adam_step(const nvfi_adam_tensor* t, int n_tensors, float beta1, float beta2, float eps, int64_t step, int zero_grad, void* stream);
+
+/* same step with the per-iteration scalars in DEVICE memory (hipGraph replay): hyper_dev[0] = 1/sqrt(1-beta2^step),
+ * hyper_dev[1+k] = lr_k / (1-beta1^step) for tensor k of the table (the values nvfi_adam_step derives on the host; no tensor may be empty) */
+int nvfi_adam_step_dev(const nvfi_adam_tensor* t, int n_tensors, float beta1, float beta2, float eps, const float* hyper_dev, int zero_grad, void* stream);
 
 /* ---- building blocks used by train_segm-style callers and by the parity tests */
 /* VelBasis.forward (velocity_field.py:69-75): xt (N,4) -> u (N,6)=(v,a); gated!=0: VelocityAABB[Sur].forward -> (N,3) in u (stride 6) */

@@ -36,6 +36,21 @@ struct Bump {
     }
 };
 
+// ---------------------------------------------------------------- device-side time schedule
+// A render normally gets its frame time as a host scalar, from which the host derives the keyframe time row (tn), the RK2 step
+// sequence (dt, t) and passes them by value.  For hipGraph replay the same quantities can instead be produced ON THE DEVICE from a
+// time held in device memory (k_sched, render.hip) into a small record in the call's workspace; every kernel argument block carries
+// an optional pointer to that record and prefers it over its by-value copy.  Layout (floats):
+//   [0] tn   [1] y0 (int bits: first time row of the LDS scatter variants)   [2] nsteps (int bits)   [3] mismatch flag (int bits)
+//   [8 + s] dt of RK2 step s     [8 + 64 + s] start time of step s
+#define SCHED_DT 8
+#define SCHED_TC (8 + 64)
+#define SCHED_FLOATS (8 + 2 * 64)
+#define SCHED_TN(a) ((a).sched ? (a).sched[0] : (a).tn)
+#define SCHED_Y0(a) ((a).sched ? __float_as_int((a).sched[1]) : (a).y0)
+#define RK_DT(a, s) ((a).sched ? (a).sched[SCHED_DT + (s)] : (a).dt[s])
+#define RK_TC(a, s) ((a).sched ? (a).sched[SCHED_TC + (s)] : (a).tcur[s])
+
 // ---------------------------------------------------------------- field math (device)
 #define XPRE_INVALID (-1.0e30f)
 

@@ -7,11 +7,13 @@
 
 #define ADAM_MAX_T 48
 struct AdamT { float* p; float* g; float* m; float* v; int64_t n; float step_size; int vec; };
-struct AdamArgs { AdamT t[ADAM_MAX_T]; int n; float b1, b2, eps, inv_sqrt_bc2; int zero_grad; };
+struct AdamArgs { AdamT t[ADAM_MAX_T]; int n; float b1, b2, eps, inv_sqrt_bc2; int zero_grad;
+                  const float* hyper; int hyper_base; };   // hyper (device, optional): [0] 1/sqrt(1-b2^t), [1+k] lr_k/(1-b1^t) of tensor k
 
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const AdamT& T = a.t[blockIdx.y];
-    const float b1 = a.b1, b2 = a.b2, eps = a.eps, isb = a.inv_sqrt_bc2, ss = T.step_size;
+    const float b1 = a.b1, b2 = a.b2, eps = a.eps;
+    const float isb = a.hyper ? a.hyper[0] : a.inv_sqrt_bc2, ss = a.hyper ? a.hyper[1 + a.hyper_base + blockIdx.y] : T.step_size;
     const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
     if (T.vec) {
         const int64_t n4 = T.n >> 2;
@@ -43,14 +45,28 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     }
 }
 
+static int adam_impl(const nvfi_adam_tensor* t, int n_tensors, float beta1, float beta2, float eps, int64_t step, const float* hyper, int zero_grad, void* stream);
+
 extern "C" int nvfi_adam_step(const nvfi_adam_tensor* t, int n_tensors, float beta1, float beta2, float eps, int64_t step, int zero_grad,
                               void* stream) {
+    if (step < 1) return nvfi_fail(2, "nvfi_adam_step: step counts from 1");
+    return adam_impl(t, n_tensors, beta1, beta2, eps, step, nullptr, zero_grad, stream);
+}
+
+extern "C" int nvfi_adam_step_dev(const nvfi_adam_tensor* t, int n_tensors, float beta1, float beta2, float eps, const float* hyper_dev,
+                                  int zero_grad, void* stream) {
+    if (!hyper_dev) return nvfi_fail(2, "nvfi_adam_step_dev: hyper_dev is NULL");
+    for (int k = 0; k < n_tensors; ++k) if (t[k].n <= 0) return nvfi_fail(2, "nvfi_adam_step_dev: tensor %d is empty (hyper_dev is indexed by table position)", k);
+    return adam_impl(t, n_tensors, beta1, beta2, eps, 1, hyper_dev, zero_grad, stream);
+}
+
+static int adam_impl(const nvfi_adam_tensor* t, int n_tensors, float beta1, float beta2, float eps, int64_t step, const float* hyper, int zero_grad, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n_tensors <= 0) return 0;
-    if (step < 1) return nvfi_fail(2, "nvfi_adam_step: step counts from 1");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     for (int base = 0; base < n_tensors;) {
         AdamArgs a; memset(&a, 0, sizeof(a));
+        a.hyper = hyper; a.hyper_base = base;
         a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.zero_grad = zero_grad;
         int64_t nmax = 0;
         int k = base;

@@ -42,7 +42,7 @@ struct PdeJetArgs {
     const float4* qorig; const int* klist;
     int64_t first; const int* kcount; int64_t cap; int wgs;     // kcount: DEVICE count of kept points; this pass handles [first, first + cap)
     float* stash; float* seeds; float* wout; double* sums;
-    float scale;
+    float scale; const float* scale_dev;   // loss scale by value, or (non-NULL) read from device memory (hipGraph replay: a weight that decays every iteration)
     float* jac; int64_t n_jac;
 };
 

@@ -438,10 +438,11 @@ __global__ __launch_bounds__(256) void k_pde_seeds(PdeJetArgs a) {
         float* sp = a.seeds + i;
         if (active) {
             sd = div * div; st = tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2];
-            const float gdiv = a.scale * 10.f * div * inv_n;
+            const float lscale = a.scale_dev ? *a.scale_dev : a.scale;
+            const float gdiv = lscale * 10.f * div * inv_n;
             float gtr[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) gtr[c] = a.scale * 0.2f * tr[c] * inv_n / 3.f;
+            for (int c = 0; c < 3; ++c) gtr[c] = lscale * 0.2f * tr[c] * inv_n / 3.f;
             float gJ[3][4], gv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -612,9 +613,25 @@ static int ensure_pde_attrs() {
     return 0;
 }
 
+static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, float loss_scale, const float* loss_scale_dev,
+                         float* out, const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters,
+                         uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream);
+
 extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, float loss_scale,
                                 float* out, const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters,
                                 uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream) {
+    return pde_loss_impl(f, P, points, t, loss_scale, nullptr, out, grads, workspace, workspace_bytes, counters, kept_out, jac_out, n_jac, host_info, stream);
+}
+
+extern "C" int nvfi_pde_loss_dev(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, const float* loss_scale_dev,
+                                 float* out, const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream) {
+    if (!loss_scale_dev) return nvfi_fail(2, "nvfi_pde_loss_dev: loss_scale_dev is NULL");
+    return pde_loss_impl(f, P, points, t, 1.f, loss_scale_dev, out, grads, workspace, workspace_bytes, counters, nullptr, nullptr, 0, nullptr, stream);
+}
+
+static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, float loss_scale, const float* loss_scale_dev,
+                         float* out, const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters,
+                         uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (P <= 0) return nvfi_fail(2, "P must be positive");
     if (P >= (1ll << 31) - 256) return nvfi_fail(2, "P too large");
@@ -719,7 +736,7 @@ extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float
         const int64_t cap = P - first < L.chunk ? (P - first + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES : L.chunk;
         PdeJetArgs ja; memset(&ja, 0, sizeof(ja));
         ja.Wv = VW; ja.Wa = AW; ja.qorig = L.qorig; ja.klist = L.klist; ja.first = first; ja.kcount = L.kcount; ja.cap = cap;
-        ja.stash = L.stash; ja.seeds = L.seeds; ja.sums = L.sums; ja.scale = loss_scale; ja.jac = jac_out; ja.n_jac = n_jac;
+        ja.stash = L.stash; ja.seeds = L.seeds; ja.sums = L.sums; ja.scale = loss_scale; ja.scale_dev = loss_scale_dev; ja.jac = jac_out; ja.n_jac = n_jac;
         const unsigned wgs = (unsigned)(cap / WG_SAMPLES);
         ja.wgs = (int)wgs;
         ja.wout = L.wout;

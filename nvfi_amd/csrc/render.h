@@ -20,6 +20,7 @@ struct DensityArgs {
     const int* list;
     const float4* xw;
     float tn; int per_point_t;
+    const float* sched;       // optional device-side schedule record (common.h); NULL: the by-value tn
     float* xpre; float* feat_out; float* sigma_out;
     // backward
     const float* gxpre;
@@ -54,6 +55,7 @@ struct AppArgs {
     const int* list;
     const float4* xw;
     float tn; int per_point_t; int S;
+    const float* sched;
     const float* rays_d; const float* view_per_point;
     float4* rgbs; int rgb_dense;
     float* stash_f; float* stash_b;
@@ -69,6 +71,7 @@ struct ScatterArgs {
     nvfi_field_desc f;
     const int* count; const int* list;
     const float4* xw; float tn;
+    const float* sched;
     const float* gxpre;   // density: one upstream gradient per sample
     const float* gg;      // appearance: (M,48)
     nvfi_grads g;
@@ -76,7 +79,7 @@ struct ScatterArgs {
     int plane_mask;       // debug: bit p enables scattering into plane p (default 63)
 };
 
-__global__ void k_counters(const int* c, int nsteps, int64_t* out);
+__global__ void k_counters(const int* c, int nsteps, int64_t* out, const float* sched = nullptr);
 __global__ void k_unpack_rgb(const float4* in, float* out, int64_t N);
 int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, const int* count, int cap_tiles, int nrep,
                      int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st);

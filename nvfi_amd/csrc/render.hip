@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_density_bwd(DensityArgs a) {
     const float4 q = a.xw[n];
     const float gf = a.gxpre[n];
     Bl b[6];
-    plane_setups(f, q.x, q.y, q.z, a.tn, b);
+    plane_setups(f, q.x, q.y, q.z, SCHED_TN(a), b);
     float gx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gy[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* pl[6] = {f.dps[0], f.dps[1], f.dps[2], f.dpt[0], f.dpt[1], f.dpt[2]};
     float* gp[6] = {a.g.dps[0], a.g.dps[1], a.g.dps[2], a.g.dpt[0], a.g.dpt[1], a.g.dpt[2]};
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
     const bool active = i < count;
     const int n = active ? (a.list ? a.list[i] : i) : 0;
     float4 q = active ? a.xw[n] : zero4();
-    const float tn = a.per_point_t ? q.w : a.tn;
+    const float tn = a.per_point_t ? q.w : SCHED_TN(a);
     float vd[3] = {0.f, 0.f, 0.f};
     if (active) {
         const float* vp = a.view_per_point ? a.view_per_point + 3 * (size_t)n : a.rays_d + 3 * (size_t)(n / a.S);
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
     }
     float4 q = active ? a.xw[n] : zero4();
     Bl b[6];
-    plane_setups(f, q.x, q.y, q.z, a.tn, b);
+    plane_setups(f, q.x, q.y, q.z, SCHED_TN(a), b);
     float gx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gy[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int a6 = 0; a6 < 6; ++a6) {
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void k_plane_scatter(ScatterArgs a) {
         const int n = __builtin_amdgcn_readfirstlane(a.list[i]);
         const float4 q = a.xw[n];
         Bl b[6];
-        plane_setups(f, q.x, q.y, q.z, a.tn, b);
+        plane_setups(f, q.x, q.y, q.z, SCHED_TN(a), b);
         float gch;
         if (C == 24) gch = a.gxpre[n];
         else gch = lane_on ? a.gg[(size_t)i * 48 + ch] : 0.f;
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(1024) void k_plane_scatter_lds(ScatterArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             Bl b[6];
-            plane_setups(f, q[u].x, q[u].y, q[u].z, a.tn, b);
+            plane_setups(f, q[u].x, q[u].y, q[u].z, SCHED_TN(a), b);
             float val[6];
 #pragma unroll
             for (int p = 0; p < 6; ++p) {
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(1024) void k_plane_scatter_lds(ScatterArgs a) {
         for (int u = 0; u < U; ++u) {
             if (!(lane_on && on[u])) continue;
             Bl b[6];
-            plane_setups(f, q[u].x, q[u].y, q[u].z, a.tn, b);
+            plane_setups(f, q[u].x, q[u].y, q[u].z, SCHED_TN(a), b);
 #pragma unroll
             for (int p = 0; p < 3; ++p) {       // space planes: coalesced global atomics
                 if (!gp[p]) continue;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(1024) void k_plane_scatter_lds(ScatterArgs a) {
             for (int p = 3; p < 6; ++p) {       // time planes: workgroup-private LDS rows (y0, y0+1 are call constants)
                 const bool my0 = dx0 ? b[p].m1 : b[p].m0, my1 = dx0 ? b[p].m3 : b[p].m2;
                 const float wx = dx0 ? b[p].w : b[p].e;
-                const int x = b[p].base - a.y0 * b[p].W + dx0;        // column inside the row
+                const int x = b[p].base - SCHED_Y0(a) * b[p].W + dx0;        // column inside the row
                 float* r0 = acc_lds + ((size_t)((p - 3) * 2 + 0) * gmax + x) * 24 + ch;
                 if (my0) atomicAdd(r0, (wx * b[p].s) * o[u][p]);
                 if (my1) atomicAdd(r0 + (size_t)gmax * 24, (wx * b[p].n) * o[u][p]);
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(1024) void k_plane_scatter_lds(ScatterArgs a) {
         float* g = CT == 24 ? a.g.dpt[p] : a.g.apt[p];
         if (!g) continue;
         for (int dy = 0; dy < 2; ++dy) {
-            const int y = a.y0 + dy;
+            const int y = SCHED_Y0(a) + dy;
             if (y < 0 || y >= f.K) continue;
             for (int k = threadIdx.x; k < Gc[p] * 24; k += blockDim.x) {
                 const int x = k / 24, c = k - 24 * x;
@@ -995,9 +995,50 @@ static int rk_schedule(const nvfi_field_desc* f, float t, int flags, float* base
     return n;
 }
 
+// Device-side schedule (hipGraph replay): same arithmetic as rk_schedule / norm_time / the y0 of the LDS scatter variants, from a time
+// held in device memory.  The launch plan (number of RK2 steps -> which kernels run, stash sizes) was fixed on the host from `t_plan`;
+// if the device time implies a different step count the record falls back to the plan's schedule and raises sched[3] (mirrored into
+// counters[7] by k_counters) - results are then those of t_plan, never undefined.
+struct SchedArgs {
+    nvfi_field_desc f; const float* t_dev; int flags; int nsteps_plan; float tn_plan; float dt_plan[4]; float tc_plan[4]; float* sched;
+};
+__global__ void k_sched(SchedArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const nvfi_field_desc& f = a.f;
+    float* S = a.sched;
+    const float t = *a.t_dev;
+    const float base = (a.flags & NVFI_TRANSFER) ? 0.f : snap_base(f, t);
+    int n = 0;
+    bool bad = false;
+    if (f.use_vel && !is_close(t, base)) {
+        const float dtm = dt_max_of(f);
+        float off = t - base, tc = t;
+        while (fabsf(off) > 0.f) {
+            if (n >= MAX_RK_STEPS) { bad = true; break; }
+            const float m = fabsf(off) < dtm ? fabsf(off) : dtm;
+            const float dt = off > 0.f ? m : -m;
+            S[SCHED_DT + n] = dt; S[SCHED_TC + n] = tc;
+            off = off - dt; tc = tc - dt;
+            ++n;
+        }
+    }
+    float tn = f.use_vel ? norm_time(f, base) : norm_time(f, t);
+    if (bad || n != a.nsteps_plan) {          // not the planned launch shape: render the planned time instead, and say so
+        bad = true;
+        n = a.nsteps_plan;
+        for (int s = 0; s < n && s < 4; ++s) { S[SCHED_DT + s] = a.dt_plan[s]; S[SCHED_TC + s] = a.tc_plan[s]; }
+        tn = a.tn_plan;
+    }
+    const float y = (tn + 1.f) * ((float)(f.K - 1) / 2.f);
+    float yf = floorf(y);
+    yf = fminf(fmaxf(yf, -4.f), (float)f.K + 2.f);
+    S[0] = tn; S[1] = __int_as_float((int)yf); S[2] = __int_as_float(n); S[3] = __int_as_float(bad ? 1 : 0);
+}
+
 struct RenderPlan {
     int64_t N, cap_tiles;
     int nsteps;
+    float* sched;       // device-side schedule record (SCHED_FLOATS), written by k_sched when the call passes a device time
     int* counters;      // [0] V, [1] M, [2] inside flag
     int *cnt_v, *off_v, *cnt_m, *off_m, *vlist, *mlist, *cnt_r, *off_r, *rlist;
     uint8_t *valid, *mflag, *rflag;
@@ -1023,6 +1064,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->N = N; P->nsteps = nsteps;
     P->cap_tiles = (N + WG_SAMPLES - 1) / WG_SAMPLES * 4;   // whole workgroups: every wave of an active workgroup owns a stash tile
     P->counters = B.take<int>(16);
+    P->sched = B.take<float>(SCHED_FLOATS);
     P->cnt_v = B.take<int>(R); P->off_v = B.take<int>(R + 1);
     P->cnt_m = B.take<int>(R); P->off_m = B.take<int>(R + 1);
     P->vlist = B.take<int>(N); P->mlist = B.take<int>(N);
@@ -1093,6 +1135,12 @@ static int ensure_render_attrs() {
 extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d,
                                const float* jitter, float t, int flags, float* rgb, float* depth, float* acc,
                                float* weights, void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream) {
+    return nvfi_render_fwd_t(f, R, rays_o, rays_d, jitter, t, nullptr, flags, rgb, depth, acc, weights, workspace, workspace_bytes, counters, stream);
+}
+
+extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d,
+                                 const float* jitter, float t, const float* t_dev, int flags, float* rgb, float* depth, float* acc,
+                                 float* weights, void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (check_desc(f)) return 2;
     if (R <= 0) return 0;
@@ -1109,6 +1157,15 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
     const int64_t N = P.N;
     const float tn = f->use_vel ? norm_time(*f, base) : norm_time(*f, t);
     HIPCK(hipMemsetAsync(P.counters, 0, 16 * sizeof(int), st));
+    const float* sched = nullptr;
+    if (t_dev) {
+        if (nsteps > 4) return nvfi_fail(2, "a device-side time supports plans of up to 4 RK2 steps (t=%g needs %d)", t, nsteps);
+        SchedArgs sc; memset(&sc, 0, sizeof(sc));
+        sc.f = *f; sc.t_dev = t_dev; sc.flags = flags; sc.nsteps_plan = nsteps; sc.tn_plan = tn; sc.sched = P.sched;
+        for (int s = 0; s < nsteps; ++s) { sc.dt_plan[s] = dts[s]; sc.tc_plan[s] = tcs[s]; }
+        hipLaunchKernelGGL(k_sched, dim3(1), dim3(64), 0, st, sc);
+        sched = P.sched;
+    }
     // fragments (weights change every optimiser step: repack per call, ~0.3 MB)
     PackJobs jobs; jobs.n = 0;
     VelFrags VW; RenderFrags RW;
@@ -1132,7 +1189,7 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
     if (nsteps > 0) {
         Rk2Args ra; memset(&ra, 0, sizeof(ra));
         ra.f = *f; ra.Wv = VW; ra.count = P.counters + 3; ra.list = P.rlist; ra.xw = P.xw; ra.xout = nullptr;
-        ra.nsteps = nsteps;
+        ra.nsteps = nsteps; ra.sched = sched;
         for (int s = 0; s < nsteps; ++s) { ra.dt[s] = dts[s]; ra.tcur[s] = tcs[s]; }
         ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles;
         // the feature-split layout of vel_split.hip (NVFI_RK2_SPLIT=0: k_rk2_fwd of vel.hip; same stash, same numbers bit for bit)
@@ -1147,7 +1204,7 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
     }
     // density
     DensityArgs da; memset(&da, 0, sizeof(da));
-    da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn;
+    da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn; da.sched = sched;
     { ProfScope ps(PK_DENSITY_FWD, st); if (launch_density_q(da, N, st)) return 1; }
     // weights
     WeightArgs wa; memset(&wa, 0, sizeof(wa));
@@ -1159,7 +1216,7 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
     LAUNCHCK();
     // appearance
     AppArgs aa; memset(&aa, 0, sizeof(aa));
-    aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S;
+    aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S; aa.sched = sched;
     aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f;
     const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
     {
@@ -1173,7 +1230,7 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
     hipLaunchKernelGGL(k_final_fwd, dim3(ray_blocks), dim3(256), 0, st, fa);
     LAUNCHCK();
     if (counters) {
-        hipLaunchKernelGGL(k_counters, dim3(1), dim3(64), 0, st, P.counters, nsteps, counters);
+        hipLaunchKernelGGL(k_counters, dim3(1), dim3(64), 0, st, P.counters, nsteps, counters, sched);
         LAUNCHCK();
     }
     return 0;
@@ -1183,6 +1240,13 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
                                int flags, const float* weights, const float* g_rgb, const float* g_depth,
                                const float* g_acc, const float* g_weights, const nvfi_grads* grads, void* workspace,
                                int64_t workspace_bytes, void* stream) {
+    return nvfi_render_bwd_t(f, R, rays_o, rays_d, t, 0, flags, weights, g_rgb, g_depth, g_acc, g_weights, grads, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d, float t, int t_on_device,
+                                 int flags, const float* weights, const float* g_rgb, const float* g_depth,
+                                 const float* g_acc, const float* g_weights, const nvfi_grads* grads, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (check_desc(f)) return 2;
     if (R <= 0) return 0;
@@ -1196,6 +1260,7 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     const int S = f->n_samples;
     const int64_t N = P.N;
     const float tn = f->use_vel ? norm_time(*f, base) : norm_time(*f, t);
+    const float* sched = t_on_device ? P.sched : nullptr;     // the record the forward's k_sched left in the workspace
     const unsigned ray_blocks = (unsigned)((R + 3) / 4);
     const bool side = g_side.get() != 0 && !P.tiles && !det_mode();   // the tile scatter reuses one og buffer for both branches: same stream
     // deterministic mode: the scatters add fixed-point integers into int64 shadow planes; k_det_finish folds them into the gradients
@@ -1219,7 +1284,7 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     bool forked = false;
     // appearance branch
     AppArgs aa; memset(&aa, 0, sizeof(aa));
-    aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S;
+    aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S; aa.sched = sched;
     aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f; aa.stash_b = P.app_b; aa.g = *grads;
     aa.g_rgb = g_rgb; aa.rgb_pre = P.rgb_pre; aa.weight = weights; aa.gxw = P.gxw; aa.gg = P.gg;
     aa.plane_tail = P.tiles ? 0 : 1;
@@ -1232,17 +1297,17 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
             // the plane part of the coordinate gradients (they only feed the RK2 adjoint)
             ProfScope ps(PK_APP_SCATTER, st);
             OgArgs oa; memset(&oa, 0, sizeof(oa));
-            oa.f = *f; oa.count = P.counters + 1; oa.list = P.mlist; oa.xw = P.xw; oa.tn = tn; oa.gg = P.gg; oa.og = want_aplanes ? P.tw.og : nullptr;
+            oa.f = *f; oa.count = P.counters + 1; oa.list = P.mlist; oa.xw = P.xw; oa.tn = tn; oa.sched = sched; oa.gg = P.gg; oa.og = want_aplanes ? P.tw.og : nullptr;
             oa.gxw_acc = nsteps > 0 ? P.gxw : nullptr;
             if (launch_og(f, oa, 48, nsteps > 0, N, st)) return 1;
             if (want_aplanes) {
                 if (tile_work_init(P.tw, st)) return 1;
-                if (launch_tile_scatter(f, P.tw, P.counters + 1, P.mlist, P.xw, tn, *grads, 48, N, st)) return 1;
+                if (launch_tile_scatter(f, P.tw, P.counters + 1, P.mlist, P.xw, tn, *grads, 48, N, st, sched)) return 1;
             }
         }
     } else if (want_aplanes) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
-        sa.f = *f; sa.count = P.counters + 1; sa.list = P.mlist; sa.xw = P.xw; sa.tn = tn; sa.gg = P.gg; sa.g = det_mode() ? gdet : *grads; sa.plane_mask = scatter_mask();
+        sa.f = *f; sa.count = P.counters + 1; sa.list = P.mlist; sa.xw = P.xw; sa.tn = tn; sa.sched = sched; sa.gg = P.gg; sa.g = det_mode() ? gdet : *grads; sa.plane_mask = scatter_mask();
         hipStream_t ss = st;
         if (side) { HIPCK(hipEventRecord(g_side.fork[0], st)); HIPCK(hipStreamWaitEvent(g_side.s, g_side.fork[0], 0)); ss = g_side.s; forked = true; }
         ProfScope ps(PK_APP_SCATTER, ss);
@@ -1280,7 +1345,7 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     hipLaunchKernelGGL(k_weights_bwd, dim3(ray_blocks), dim3(256), 0, st, wa);
     // density planes + coordinate grads
     DensityArgs da; memset(&da, 0, sizeof(da));
-    da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn;
+    da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn; da.sched = sched;
     da.gxpre = P.gxpre; memset(&da.g, 0, sizeof(da.g)); da.mflag = P.mflag; da.gxw = P.gxw; da.gxk = nsteps > 0 ? P.gxk : nullptr;
     const bool want_dplanes = grads->dps[0] || grads->dpt[0];
     if (P.tiles) {
@@ -1288,19 +1353,19 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
         if (nsteps > 0 || want_dplanes) {
             ProfScope ps(PK_DENSITY_BWD, st);
             OgArgs oa; memset(&oa, 0, sizeof(oa));
-            oa.f = *f; oa.count = P.counters + 0; oa.list = P.vlist; oa.xw = P.xw; oa.tn = tn; oa.gxpre = P.gxpre; oa.og = want_dplanes ? P.tw.og : nullptr;
+            oa.f = *f; oa.count = P.counters + 0; oa.list = P.vlist; oa.xw = P.xw; oa.tn = tn; oa.sched = sched; oa.gxpre = P.gxpre; oa.og = want_dplanes ? P.tw.og : nullptr;
             oa.mflag = P.mflag; oa.gxw = P.gxw; oa.gxk = nsteps > 0 ? P.gxk : nullptr;
             if (launch_og(f, oa, 24, nsteps > 0, N, st)) return 1;
         }
         if (want_dplanes) {
             ProfScope ps(PK_DENSITY_SCATTER, st);
             if (!want_aplanes && tile_work_init(P.tw, st)) return 1;
-            if (launch_tile_scatter(f, P.tw, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, st)) return 1;
+            if (launch_tile_scatter(f, P.tw, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, st, sched)) return 1;
         }
     } else if (nsteps > 0) { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
     if (!P.tiles && want_dplanes) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
-        sa.f = *f; sa.count = P.counters + 0; sa.list = P.vlist; sa.xw = P.xw; sa.tn = tn; sa.gxpre = P.gxpre; sa.g = det_mode() ? gdet : *grads; sa.plane_mask = scatter_mask();
+        sa.f = *f; sa.count = P.counters + 0; sa.list = P.vlist; sa.xw = P.xw; sa.tn = tn; sa.sched = sched; sa.gxpre = P.gxpre; sa.g = det_mode() ? gdet : *grads; sa.plane_mask = scatter_mask();
         hipStream_t ss = st;
         if (side) { HIPCK(hipEventRecord(g_side.fork[1], st)); HIPCK(hipStreamWaitEvent(g_side.s, g_side.fork[1], 0)); ss = g_side.s; forked = true; }
         ProfScope ps(PK_DENSITY_SCATTER, ss);
@@ -1321,7 +1386,7 @@ extern "C" int nvfi_render_bwd(const nvfi_field_desc* f, int64_t R, const float*
     if (nsteps > 0) {
         Rk2Args ra; memset(&ra, 0, sizeof(ra));
         ra.f = *f; ra.Wv = VW; ra.count = P.counters + 3; ra.list = P.rlist; ra.xw = P.xw;
-        ra.nsteps = nsteps;
+        ra.nsteps = nsteps; ra.sched = sched;
         for (int s = 0; s < nsteps; ++s) { ra.dt[s] = dts[s]; ra.tcur[s] = tcs[s]; }
         ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles; ra.gxk = P.gxk;
         static int split = -1;
@@ -1360,13 +1425,14 @@ int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, cons
     return launch_wgrad(wj, rj, st);
 }
 
-__global__ void k_counters(const int* c, int nsteps, int64_t* out) {
+__global__ void k_counters(const int* c, int nsteps, int64_t* out, const float* sched) {
     if (threadIdx.x == 0) {
         out[0] = c[0];
         out[1] = nsteps > 0 ? c[3] : 0;
         out[2] = c[1];
         out[3] = (int64_t)(nsteps > 0 ? c[3] : 0) * 2 * nsteps;
-        out[4] = out[5] = out[6] = out[7] = 0;
+        out[4] = out[5] = out[6] = 0;
+        out[7] = sched ? __float_as_int(sched[3]) : 0;      // 1: the device-side time did not fit the planned RK2 step count (the planned time was rendered)
     }
 }
 

@@ -21,6 +21,7 @@ struct TileWork {              // device buffers inside the caller's workspace
 struct OgArgs {
     nvfi_field_desc f;
     const int* count; const int* list; const float4* xw; float tn;
+    const float* sched;
     const float* gxpre;        // density: one upstream gradient per sample (dense)
     const float* gg;           // appearance: (M,48) per-sample channel gradients (compact)
     float* og;                 // [i][6][C]
@@ -39,6 +40,7 @@ struct TileScatterArgs {
     TileGeom geo;
     const int4* items; const int* nitems; const float4* sorted; const int* list; const float4* xw; const float* og;
     float tn; int y0;
+    const float* sched;
     nvfi_grads g;
 };
 
@@ -47,5 +49,5 @@ void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w
 int tile_work_init(const TileWork& w, hipStream_t st);
 int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int64_t N, hipStream_t st);
 int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* count, const int* list, const float4* xw, float tn,
-                        const nvfi_grads& g, int C, int64_t N, hipStream_t st);
+                        const nvfi_grads& g, int C, int64_t N, hipStream_t st, const float* sched = nullptr);
 int launch_density_q(const DensityArgs& da, int64_t N, hipStream_t st);   // Cd == 24 only

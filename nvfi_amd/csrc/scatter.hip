@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_og(OgArgs a) {
     if (C == 24) { const float g = a.gxpre[n]; g4 = make_float4(g, g, g, g); }
     else g4 = *reinterpret_cast<const float4*>(a.gg + (size_t)ic * 48 + 4 * qd);
     Bl b[6];
-    plane_setups(f, q.x, q.y, q.z, a.tn, b);
+    plane_setups(f, q.x, q.y, q.z, SCHED_TN(a), b);
     const float* pl[6];
 #pragma unroll
     for (int p = 0; p < 3; ++p) { pl[p] = C == 24 ? f.dps[p] : f.aps[p]; pl[3 + p] = C == 24 ? f.dpt[p] : f.apt[p]; }
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_density_q(DensityArgs a) {
     const int ic = in ? i : count - 1;
     const int n = a.list ? a.list[ic] : ic;
     const float4 q = a.xw[n];
-    const float tn = a.per_point_t ? q.w : a.tn;
+    const float tn = a.per_point_t ? q.w : SCHED_TN(a);
     const int qd = sub < 6 ? sub : 0;
     Bl b[6];
     plane_setups(f, q.x, q.y, q.z, tn, b);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_scatter(TileScatterArgs 
         Bl b, bt;
         int x0, y0, xt, yt;
         bl_setup_xy(uu, vv, W, H, b, x0, y0);
-        bl_setup_xy(t_on_u ? uu : vv, a.tn, Wt, f.K, bt, xt, yt);
+        bl_setup_xy(t_on_u ? uu : vv, SCHED_TN(a), Wt, f.K, bt, xt, yt);
         ws[0] = b.e * b.s; ws[1] = b.w * b.s; ws[2] = b.e * b.n; ws[3] = b.w * b.n;
         wt[0] = bt.e * bt.s; wt[1] = bt.w * bt.s; wt[2] = bt.e * bt.n; wt[3] = bt.w * bt.n;
         const int ms = (b.m0 ? 1 : 0) | (b.m1 ? 2 : 0) | (b.m2 ? 4 : 0) | (b.m3 ? 8 : 0);
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_scatter(TileScatterArgs 
             for (int w = 0; w < TS_WAVES; ++w) v += sp_all[w][TS_SP + k];
             if (v != 0.f) {
                 const int c = k % 24, tx2 = (k / 24) % TW, r = k / (24 * TW);
-                const int X = ot + tx2, Y = a.y0 + r;
+                const int X = ot + tx2, Y = SCHED_Y0(a) + r;
                 if (X < Wt && Y >= 0 && Y < f.K) atomicAdd(gtm + ((size_t)Y * Wt + X) * CT + c0 + c, v);
             }
         }
@@ -460,7 +460,7 @@ int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int
 }
 
 int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* count, const int* list, const float4* xw, float tn,
-                        const nvfi_grads& g, int C, int64_t N, hipStream_t st) {
+                        const nvfi_grads& g, int C, int64_t N, hipStream_t st, const float* sched) {
     TileSortArgs sa; memset(&sa, 0, sizeof(sa));
     sa.g = w.g; sa.count = count; sa.list = list; sa.xw = xw; sa.hist = w.hist; sa.cursor = w.cursor; sa.items = w.items; sa.nitems = w.nitems; sa.sorted = w.sorted;
     const int nb = w.g.nbins;
@@ -470,7 +470,7 @@ int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* 
     hipLaunchKernelGGL(k_tile_fill, dim3((unsigned)((N + 511) / 512)), dim3(512), sizeof(int) * 2 * nb, st, sa);
     TileScatterArgs ta; memset(&ta, 0, sizeof(ta));
     ta.f = *f; ta.geo = w.g; ta.items = w.items; ta.nitems = w.nitems; ta.sorted = w.sorted; ta.list = list; ta.xw = xw; ta.og = w.og; ta.tn = tn;
-    ta.g = g;
+    ta.g = g; ta.sched = sched;
     const float y = (tn + 1.f) * ((float)(f->K - 1) / 2.f);
     float yf = floorf(y);
     yf = fminf(fmaxf(yf, -4.f), (float)f->K + 2.f);

@@ -5,6 +5,7 @@
 #define RK_NF 19                       // per (step, sample) record fields: x3 pmid3 w1[6] w2[6] flags
 #define VEL_G_REGS (5 * 64 + 16)       // adjoint stash rows per (eval, tile): gz[5][64] + gw[16]
 #define MAX_RK_STEPS 64
+static_assert(MAX_RK_STEPS == 64, "SCHED_* offsets in common.h assume 64 RK2 steps");
 
 struct VelEvalArgs {
     nvfi_field_desc f;
@@ -27,6 +28,7 @@ struct Rk2Args {
     int nsteps;
     float dt[MAX_RK_STEPS];
     float tcur[MAX_RK_STEPS];
+    const float* sched;    // optional device-side schedule record (common.h): dt / tcur are read from it instead
     // per-point mode
     const float* pt_t; const float* pt_base; float dt_max; int max_steps;
     int pt_by_list;        // pt_t / pt_base are indexed by the dense index list[i] instead of the compact index i

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_fwd(Rk2Args a) {
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
         float dt;
-        if (UNIFORM) { dt = a.dt[s]; tcur = a.tcur[s]; }
+        if (UNIFORM) { dt = RK_DT(a, s); tcur = RK_TC(a, s); }
         else {
             bool unfinished = fabsf(off) > 0.f;
             if (!__syncthreads_or(unfinished)) break;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_bwd(Rk2Args a) {
     float g3[3] = {gin.x, gin.y, gin.z};
 #pragma unroll 1
     for (int s = a.nsteps - 1; s >= 0; --s) {
-        const float dt = a.dt[s], tcur = a.tcur[s];
+        const float dt = RK_DT(a, s), tcur = RK_TC(a, s);
         const float* rc = a.rec + (size_t)s * RK_NF * a.cap + (active ? i : 0);
         const int flags = active ? __float_as_int(rc[18 * a.cap]) : 7;
         const bool g1 = flags & 1, g2 = flags & 2, rej = flags & 4;

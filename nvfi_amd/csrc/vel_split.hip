@@ -231,7 +231,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split_uni(SplitUniArgs a)
     __syncthreads();
 #pragma unroll 1
     for (int s = 0; s < ra.nsteps; ++s) {
-        const float dt = ra.dt[s], tcur = ra.tcur[s], hdt = 0.5f * dt;
+        const float dt = RK_DT(ra, s), tcur = RK_TC(ra, s), hdt = 0.5f * dt;
         float* z1[NT]; float* z2[NT]; float* x1[NT]; float* x2[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split_bwd(SplitBwdArgs a)
     float4 wq[16];
 #pragma unroll 1
     for (int s = ra.nsteps - 1; s >= 0; --s) {
-        const float dt = ra.dt[s], tcur = ra.tcur[s];
+        const float dt = RK_DT(ra, s), tcur = RK_TC(ra, s);
         float gacc[NT][3], gup[NT][3];
         bool g1[NT], g2[NT], rej[NT];
 #pragma unroll

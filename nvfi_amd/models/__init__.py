@@ -5,4 +5,4 @@ from .nvfi import NVFi
 from .tensorf_model_utils import AlphaGridMask
 from .mask_field import MaskField
 from .velocity_field import VelBasis, VelocityAABB, VelocityAABBSur, N_to_reso
-from .tensorf_keyframe import TensorVMKeyframeTimeKplane
+from .tensorf_keyframe import TensorVMKeyframeTimeKplane, DeviceTime

@@ -53,6 +53,20 @@ def SHRender(xyz_sampled, viewdirs, features, kwargs=None):
     return TensorVMKeyframeTimeKplane.sh_render(viewdirs, features)
 
 
+class DeviceTime(float):
+    """A frame time whose VALUE lives in device memory: `DeviceTime(t_plan, dev)` is a float (t_plan - it fixes the launch plan: keyframe or
+    not, number of RK2 steps, workspace layout) that carries a 1-element fp32 CUDA tensor `dev` the kernels read the time from
+    (nvfi_render_fwd_t).  Passing it as `t` to Renderer.render / NVFi.render_ray lets a captured hipGraph of a training iteration be
+    replayed with a new time every iteration.  dev[0] must be in the same plan class as t_plan (counters[7] reports a mismatch)."""
+
+    def __new__(cls, t_plan, dev):
+        x = super().__new__(cls, float(t_plan))
+        if not (isinstance(dev, torch.Tensor) and dev.is_cuda and dev.dtype == torch.float32 and dev.numel() == 1):
+            raise _lib.NvfiError("DeviceTime needs a 1-element fp32 CUDA tensor")
+        x.dev = dev
+        return x
+
+
 def _cl(t):
     return t.contiguous(memory_format=torch.channels_last)
 
@@ -69,6 +83,8 @@ class _RenderFn(torch.autograd.Function):
         L = _lib.lib()
         R = rays_o.shape[0]
         dev = rays_o.device
+        t_dev = getattr(t, "dev", None)        # DeviceTime: the kernels read the time from device memory; float(t) is the launch plan
+        t = float(t)
         desc = field._desc()
         S = desc.n_samples
         nbytes = C.c_int64(0)
@@ -79,14 +95,14 @@ class _RenderFn(torch.autograd.Function):
         acc = torch.empty(R, device=dev)
         weights = torch.empty(R, S, device=dev)
         counters = torch.empty(_lib.NCOUNTERS, dtype=torch.int64, device=dev)      # all 8 entries are written by the call
-        _lib.check(L.nvfi_render_fwd(C.byref(desc), C.c_int64(R), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(jitter),
-                                     C.c_float(t), C.c_int(flags), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc),
-                                     _lib.ptr(weights), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
+        _lib.check(L.nvfi_render_fwd_t(C.byref(desc), C.c_int64(R), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(jitter),
+                                       C.c_float(t), _lib.ptr(t_dev), C.c_int(flags), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc),
+                                       _lib.ptr(weights), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
         field.last_counters = counters
         field._last_ws = ws if (flags & _lib.NVFI_WANT_MASK) else None
         field._last_call = (R, t, flags)
         if flags & _lib.NVFI_TRAIN:
-            ctx.field, ctx.t, ctx.flags, ctx.ws = field, t, flags, ws
+            ctx.field, ctx.t, ctx.flags, ctx.ws, ctx.t_on_device = field, t, flags, ws, t_dev is not None
             ctx.save_for_backward(rays_o, rays_d, weights, *params)
         ctx.mark_non_differentiable(counters)
         ctx.set_materialize_grads(False)     # unused outputs (depth, acc, the R x S weights) arrive as None, not as zero tensors
@@ -124,7 +140,7 @@ class _RenderFn(torch.autograd.Function):
         G = field._grads_struct(grads)
         gs = [None if g is None else g.contiguous() for g in (g_rgb, g_depth, g_acc, g_weights)]
         R = rays_o.shape[0]
-        _lib.check(L.nvfi_render_bwd(C.byref(desc), C.c_int64(R), _lib.ptr(rays_o), _lib.ptr(rays_d), C.c_float(ctx.t),
+        _lib.check(L.nvfi_render_bwd_t(C.byref(desc), C.c_int64(R), _lib.ptr(rays_o), _lib.ptr(rays_d), C.c_float(ctx.t), C.c_int(int(ctx.t_on_device)),
                                      C.c_int(ctx.flags), _lib.ptr(weights), _lib.ptr(gs[0]), _lib.ptr(gs[1]), _lib.ptr(gs[2]),
                                      _lib.ptr(gs[3]), C.byref(G), _lib.ptr(ctx.ws), C.c_int64(ctx.ws.numel()), _stream_ptr()))
         ctx.ws = None
@@ -647,7 +663,12 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             flags |= _lib.NVFI_TRANSFER
         if self.mask_field is not None:
             flags |= _lib.NVFI_WANT_MASK
+        t_dev = getattr(t, "dev", None)
         t = float(np.float32(float(t)))
+        if t_dev is not None:
+            if self.mask_field is not None:
+                raise NotImplementedError("DeviceTime renders do not support the mask branch")
+            t = DeviceTime(t, t_dev)
         params = self._render_params()
         if training and self._use_side_streams():
             # the render runs on one of the field's two render streams (ordered behind everything queued on the caller's stream so far,
@@ -842,9 +863,15 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         G = self._grads_struct_vel(grads)
         counters = torch.empty(_lib.NCOUNTERS, dtype=torch.int64, device=points.device)
         # no host_info: the call does not wait for the device; the kept count is out[1] / counters[4] (device side)
-        _lib.check(L.nvfi_pde_loss_ex(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(float(weight)), _lib.ptr(out),
-                                      C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), None, None, C.c_int64(0), None,
-                                      _stream_ptr()))
+        if isinstance(weight, torch.Tensor):     # the weight lives in device memory (hipGraph replay: it decays every iteration)
+            if not (weight.is_cuda and weight.dtype == torch.float32 and weight.numel() == 1):
+                raise _lib.NvfiError("a device-side PDE weight must be a 1-element fp32 CUDA tensor")
+            _lib.check(L.nvfi_pde_loss_dev(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), _lib.ptr(weight), _lib.ptr(out),
+                                           C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), _stream_ptr()))
+        else:
+            _lib.check(L.nvfi_pde_loss_ex(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(float(weight)), _lib.ptr(out),
+                                          C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters), None, None, C.c_int64(0), None,
+                                          _stream_ptr()))
         self.last_pde_out, self.last_pde_counters = out, counters
         self.last_pde_n_kept = None
         return out
@@ -915,7 +942,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         return total
 
     @torch.no_grad()
-    def regularizers_backward_(self, w_l1, w_tv_density, w_tv_app):
+    def regularizers_backward_(self, w_l1, w_tv_density=None, w_tv_app=None):
         """Fused form of `loss += w_l1*density_L1() + w_tv_density*TV_loss_density(reg) + w_tv_app*TV_loss_app(reg)`
         followed by backward: one pass per plane that ACCUMULATES the weighted gradients into p.grad and returns the
         three un-weighted loss values (device tensor [L1, TVd, TVa]).  Call it next to loss.backward()."""
@@ -932,6 +959,11 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         G = self._grads_struct(grads + [None] * 22)
         out = torch.empty(3, device=ps[0].device)
         desc = self._desc()
+        if isinstance(w_l1, torch.Tensor):       # the three weights as one fp32[3] CUDA tensor (hipGraph replay: they decay every iteration)
+            if not (w_l1.is_cuda and w_l1.dtype == torch.float32 and w_l1.numel() == 3 and w_l1.is_contiguous()):
+                raise _lib.NvfiError("device-side regulariser weights must be a contiguous fp32[3] CUDA tensor")
+            _lib.check(L.nvfi_plane_regs_dev(C.byref(desc), _lib.ptr(w_l1), _lib.ptr(out), C.byref(G), _stream_ptr()))
+            return out
         _lib.check(L.nvfi_plane_regs(C.byref(desc), C.c_float(w_l1), C.c_float(w_tv_density), C.c_float(w_tv_app), _lib.ptr(out),
                                      C.byref(G), _stream_ptr()))
         return out

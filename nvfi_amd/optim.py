@@ -17,8 +17,36 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
 
+    def next_hyper(self):
+        """Advance the step counters by one iteration and return the per-iteration scalars of that step as a list of floats -
+        [1/sqrt(1-beta2^t)] + [lr_k/(1-beta1^t) for every tensor k in table order] - for `step(hyper_dev=...)`: the caller uploads them
+        and the (possibly hipGraph-captured) launch reads them from device memory.  Same values nvfi_adam_step derives on the host."""
+        import numpy as np
+        out, head = [], None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    raise _lib.NvfiError("next_hyper() needs initialised state: run one ordinary step() first")
+                st["step"] = int(st["step"]) + 1
+                # nvfi_adam_step's arithmetic: betas and lr arrive there as C floats, the corrections are formed in double
+                b1f, b2f = float(np.float32(b1)), float(np.float32(b2))
+                bc1, bc2 = 1.0 - b1f ** float(st["step"]), 1.0 - b2f ** float(st["step"])
+                h = float(np.float32(1.0 / np.sqrt(bc2)))
+                if head is None:
+                    head = (h, st["step"], float(b1), float(b2))
+                elif head[1:] != (st["step"], float(b1), float(b2)):
+                    raise _lib.NvfiError("step(hyper_dev=...) needs one (betas, step count) for all tensors")
+                out.append(float(np.float32(float(np.float32(group["lr"])) / bc1)))
+        return [head[0]] + out
+
     @torch.no_grad()
-    def step(self, closure=None, zero_grad=False):
+    def step(self, closure=None, zero_grad=False, hyper_dev=None):
+        """hyper_dev (fp32 CUDA tensor holding next_hyper()'s values): the launch takes step size and bias correction from device memory and
+        this call leaves the step counters alone (next_hyper() advanced them)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -47,7 +75,8 @@ class Adam(torch.optim.Optimizer):
                     for k in ("exp_avg", "exp_avg_sq"):
                         if st[k].stride() != p.stride() or st[k].device != p.device:
                             st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[k])
-                st["step"] += 1
+                if hyper_dev is None:
+                    st["step"] += 1
                 # elementwise update: any dense memory layout works as long as p, g, m, v share it
                 if g.stride() != p.stride():
                     g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
@@ -70,6 +99,12 @@ class Adam(torch.optim.Optimizer):
             arr = ent[1]
             for i, it in enumerate(items):
                 arr[i].lr = it[3]
+            if hyper_dev is not None:
+                if len(batches) != 1 or hyper_dev.numel() < 1 + len(items) or not hyper_dev.is_cuda or hyper_dev.dtype != torch.float32:
+                    raise _lib.NvfiError("step(hyper_dev=...) needs one batch and an fp32 CUDA tensor of 1 + n_tensors values")
+                _lib.check(L.nvfi_adam_step_dev(arr, C.c_int(len(items)), C.c_float(b1), C.c_float(b2), C.c_float(eps), _lib.ptr(hyper_dev),
+                                                C.c_int(1 if zero_grad else 0), stream))
+                continue
             _lib.check(L.nvfi_adam_step(arr, C.c_int(len(items)), C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_int64(step),
                                         C.c_int(1 if zero_grad else 0), stream))
         return loss

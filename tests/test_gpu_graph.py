@@ -1,0 +1,181 @@
+"""Device-side time schedule and hipGraph replay (ABI v3): a render whose frame time is read from device memory must equal the render that
+got the same time as a host scalar (bit for bit forward - same kernels, same arithmetic -, gradients to the order of the atomics), the
+device-side loss weights / Adam scalars must reproduce their host-scalar calls, and a whole training iteration captured once and replayed
+with a new time, new weights and new jitter every iteration must follow the eager iteration."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, ROOT, relerr
+from helpers import make_model, named_grads
+
+pytestmark = pytest.mark.gpu
+
+
+def _cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _train_render(model, t, o, d, u, tgt):
+    f = model.nvfi
+    model.zero_grad(set_to_none=True)
+    f.train()
+    f.jitter_override = u
+    try:
+        out = f(t, o, d, True)
+    finally:
+        f.jitter_override = None
+    torch.nn.functional.mse_loss(out[0], tgt).backward()
+    return [x.detach().clone() for x in out[:4]], f.last_counters.clone(), named_grads(model)
+
+
+@pytest.mark.parametrize("kind", ["A", "B"])
+def test_device_time_render_matches_host_time(kind):
+    from nvfi_amd.models import DeviceTime
+    gold = np.load(os.path.join(GOLD, "hotpath.npz"))
+    model, meta = make_model(kind)
+    f = model.nvfi
+    o, d = _cu(gold[f"{kind}:rays_o"]), _cu(gold[f"{kind}:rays_d"])
+    u = torch.from_numpy(gold[f"{kind}:train_nonkey:u"].copy())
+    tgt = _cu(gold[f"{kind}:train_nonkey:target"])
+    ts = f.tmax / (f.num_keyframes - 1)
+    # (plan time, actual time): two non-keyframe times of one plan class, two keyframe times
+    t_a, t_b = 0.38 * ts, 1.31 * ts
+    for plan, actual in ((t_a, t_b), (ts * 1, ts * 2), (t_b, t_b)):
+        ref_out, ref_c, ref_g = _train_render(model, actual, o, d, u, tgt)
+        tdev = torch.tensor([actual], dtype=torch.float32, device="cuda")
+        out, c, g = _train_render(model, DeviceTime(plan, tdev), o, d, u, tgt)
+        assert int(c[7]) == 0 and torch.equal(c[:4], ref_c[:4])
+        for a, b in zip(out, ref_out):
+            assert torch.equal(a, b)                      # same kernels, same operands: bit-identical
+        n = 0
+        for k, r in ref_g.items():
+            if r is None:
+                assert g[k] is None
+                continue
+            assert relerr(g[k], r) < 2e-5, (k, relerr(g[k], r))      # atomics in a different order
+            n += 1
+        assert n >= 19
+    # a device time outside the captured plan class: the planned time is rendered and counters[7] says so
+    ref_out, _, _ = _train_render(model, t_a, o, d, u, tgt)
+    out, c, _ = _train_render(model, DeviceTime(t_a, torch.tensor([ts * 2], dtype=torch.float32, device="cuda")), o, d, u, tgt)
+    assert int(c[7]) == 1
+    for a, b in zip(out, ref_out):
+        assert torch.equal(a, b)
+    # eval mode takes the same path
+    f.eval()
+    with torch.no_grad():
+        a = f(DeviceTime(t_a, torch.tensor([t_b], dtype=torch.float32, device="cuda")), o, d, True)
+        b = f(t_b, o, d, True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_device_side_weights_match_host_scalars():
+    gold = np.load(os.path.join(GOLD, "hotpath.npz"))
+    model, meta = make_model("A")
+    f = model.nvfi
+    pts, tt = _cu(gold["A:pde:points"]), _cu(gold["A:pde:t"])
+    res = []
+    for w in (0.37, torch.tensor([0.37], dtype=torch.float32, device="cuda")):
+        model.zero_grad(set_to_none=True)
+        out = f.pde_loss_backward_(pts, tt, w).clone()
+        res.append((out, named_grads(model)))
+    assert torch.equal(res[0][0], res[1][0])
+    for k, r in res[0][1].items():
+        if r is not None and "vel_net" in k:
+            assert relerr(res[1][1][k], r) < 2e-5, k
+    regs = []
+    for w in ((8e-4, 0.7, 1.3), (torch.tensor([8e-4, 0.7, 1.3], dtype=torch.float32, device="cuda"),)):
+        model.zero_grad(set_to_none=True)
+        out = f.regularizers_backward_(*w).clone()
+        regs.append((out, named_grads(model)))
+    assert torch.equal(regs[0][0], regs[1][0])
+    for k, r in regs[0][1].items():
+        if r is not None and "plane" in k:
+            assert np.array_equal(regs[1][1][k], r), k
+
+
+def test_adam_with_device_side_scalars_is_bit_identical():
+    from nvfi_amd.optim import Adam
+    torch.manual_seed(0)
+    shapes = [(1, 24, 9, 11), (128, 28), (128,), (6, 128)]
+    def make():
+        torch.manual_seed(1)
+        ps = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+        return ps, Adam([dict(params=ps[:1], lr=0.02), dict(params=ps[1:], lr=1e-3)], betas=(0.9, 0.99))
+    pa, oa = make()
+    pb, ob = make()
+    hyper = torch.zeros(1 + len(shapes), device="cuda")
+    for it in range(5):
+        gs = [torch.randn(*s, device="cuda") for s in shapes]
+        for p, q, g in zip(pa, pb, gs):
+            p.grad = g.clone(); q.grad = g.clone()
+        oa.step(zero_grad=True)
+        if it == 0:
+            ob.step(zero_grad=True)            # state initialisation
+        else:
+            hyper.copy_(torch.tensor(ob.next_hyper()))
+            ob.step(zero_grad=True, hyper_dev=hyper)
+        for g in oa.param_groups + ob.param_groups:
+            g["lr"] *= 0.999
+        for p, q in zip(pa, pb):
+            assert torch.equal(p, q), it
+            assert float(q.grad.abs().max()) == 0.0
+    assert [oa.state[p]["step"] for p in pa] == [ob.state[q]["step"] for q in pb] == [5] * 4
+
+
+@pytest.mark.parametrize("workload", ["cfg3", "cfg2"])
+def test_graph_replay_follows_the_eager_iteration(workload):
+    """bench.Step (live field, eager launches) against bench.GraphedStep (the same iteration captured once, replayed): same seeds, same
+    host draws in the same order -> the loss of every iteration agrees and so do the parameters after 5 iterations."""
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+
+    def run(graphed):
+        torch.manual_seed(7); torch.cuda.manual_seed(7)
+        model = bench.build_scene(dev, 64, 64, True)
+        if workload == "cfg2":
+            model.nvfi.use_vel = False
+        step = bench.Step(model, dev, 1024, 16384, 1, 0, workload, live=True)
+        step()                                   # optimiser state, workspaces
+        torch.manual_seed(11); torch.cuda.manual_seed(11)
+        step.gen.manual_seed(5); step.rng = np.random.default_rng(5)
+        losses = []
+        if graphed:
+            gs = bench.GraphedStep(step)
+            gs.host_record(); gs.body(); losses.append(float(gs.loss))      # iteration 1 eagerly through the record (what capture() does first)
+            gs.host_record()
+            g = torch.cuda.CUDAGraph(); g.register_generator_state(step.gen)
+            cap = torch.cuda.Stream(); cap.wait_stream(torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=cap):
+                gs.body()
+            gs.graph = g
+            g.replay(); losses.append(float(gs.loss))
+            for _ in range(3):
+                gs(); losses.append(float(gs.loss))
+            gs.check()
+        else:
+            for _ in range(5):
+                losses.append(float(step()))
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().cpu().contiguous().numpy().copy() for k, v in model.state_dict().items()}
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    print("eager", le, "graph", lg)
+    np.testing.assert_allclose(lg, le, rtol=2e-3)
+    moved = 0
+    for k, r in pe.items():
+        if not np.issubdtype(r.dtype, np.floating) or r.size < 2:
+            continue
+        lr = 0.02 if "plane" in k else 1e-3
+        assert np.abs(pg[k] - r).max() <= 5.1 * lr, k
+        frac_bad = np.mean(np.abs(pg[k] - r) > 2e-2 * 5 * lr)
+        assert frac_bad < 0.02, (k, frac_bad)
+        moved += 1
+    assert moved >= 19
