@@ -31,6 +31,11 @@ import os
 import sys
 import time
 
+# ROCm 7's hipGraph "packet capture" fast path (AQL packets of a single-branch graph pre-built at instantiation) faults on the second
+# replay of the captured radiance-only iteration at full size (Memory access fault, reproducible with tools/graph_debug.py cfg2); the
+# ordinary graph launch path is unaffected and just as fast for these graphs.  Must be set before the HIP runtime starts.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import numpy as np
 import torch
 
@@ -619,6 +624,19 @@ def main():
         # `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL rendezvous on 127.0.0.1) - the same
         # command line the driver uses with torch.distributed.run in front
         sys.exit(_spawn_ranks(args.gpus, ndev, backend))
+    if (args.graph == "auto" and args.mode == "fused" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("NVFI_TORCH_ADAM")
+            and not os.environ.get("NVFI_BENCH_CHILD")):
+        # The captured-graph run happens in a child process: a fault inside a graph replay (a runtime bug, see above) kills the process
+        # and cannot be caught - if the child does not deliver its line, this process measures the eager three-stream step instead.
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--graph", "on"], env=dict(os.environ, NVFI_BENCH_CHILD="1"),
+                           stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            print(lines[-1])
+            return
+        print(f"bench.py: the hipGraph run failed (exit code {r.returncode}); measuring the eager step instead", file=sys.stderr)
+        args.graph = "off"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -667,7 +685,7 @@ def main():
 
     for _ in range(args.prime):          # setup
         step()
-    use_graph = args.mode == "fused" and (args.graph == "on" or (args.graph == "auto" and world == 1 and not os.environ.get("NVFI_TORCH_ADAM")))
+    use_graph = args.mode == "fused" and args.graph == "on"
     run = step
     if use_graph:
         if world > 1:

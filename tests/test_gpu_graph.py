@@ -92,10 +92,10 @@ def test_device_side_weights_match_host_scalars():
         model.zero_grad(set_to_none=True)
         out = f.regularizers_backward_(*w).clone()
         regs.append((out, named_grads(model)))
-    assert torch.equal(regs[0][0], regs[1][0])
+    np.testing.assert_allclose(regs[1][0].cpu().numpy(), regs[0][0].cpu().numpy(), rtol=1e-6)     # the three sums are formed by atomics
     for k, r in regs[0][1].items():
         if r is not None and "plane" in k:
-            assert np.array_equal(regs[1][1][k], r), k
+            assert relerr(regs[1][1][k], r) < 1e-6, k
 
 
 def test_adam_with_device_side_scalars_is_bit_identical():
