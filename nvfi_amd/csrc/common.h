@@ -222,4 +222,5 @@ int pack_render_frags(const nvfi_field_desc* f, float* buf, RenderFrags* out, Pa
 int launch_pack(const PackJobs& jobs, hipStream_t st);
 int launch_scan_fill(const int* cnt, int* off, int64_t ngroups, int* total, const uint8_t* flags, int* list, hipStream_t st);
 int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st);
+int launch_wgrad_ring(WgradJobs& bj, ReduceJobs& br, hipStream_t st);   // wgrad_ring.hip
 int ensure_lds_attrs();

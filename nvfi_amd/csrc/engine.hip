@@ -2,6 +2,7 @@
 #include "engine.h"
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 __global__ void k_pack(PackJobs jobs) {
     const PackJob& J = jobs.j[blockIdx.x];
@@ -257,6 +258,16 @@ int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st) {
         resident = (e && atoi(e) > 0) ? atoi(e) : (1 << 28);
     }
     WgradJobs bj = wj; ReduceJobs br = rj;
+    // default: the LDS-ring kernel (wgrad_ring.hip); NVFI_WGRAD=engine keeps the register-operand kernel of rounds 1-2
+    static int ring = -1;
+    if (ring < 0) { const char* e = getenv("NVFI_WGRAD"); ring = (e && !strcmp(e, "engine")) ? 0 : 1; }
+    if (ring) {
+        ProfScope ps(PK_WGRAD, st);
+        if (launch_wgrad_ring(bj, br, st)) return 1;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(260, br.n), dim3(256), 0, st, br);
+        LAUNCHCK();
+        return 0;
+    }
     double cost[MAX_WGRAD_JOBS], total = 0.0; int wps[MAX_WGRAD_JOBS];
     for (int i = 0; i < bj.n; ++i) {
         const WgradJob& J = bj.j[i];

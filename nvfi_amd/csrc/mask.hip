@@ -11,7 +11,7 @@
 
 #define MK_F_ROWS (16 + 4 * 64 + 16)   // forward stash per tile: x0 (16) | h1..h4 (64 each) | softmax (16)
 #define MK_B_ROWS (16 + 4 * 64)        // backward stash per tile: g_logits (16) | g_z4, g_z3, g_z2, g_z1 (64 each)
-#define MK_NSLAB 128
+#define MK_NSLAB 256
 #define MK_SLAB_FLOATS (128 * 128 + 128)
 #define MK_F0 (4 * 2 * 64)
 #define MK_FH (4 * 64 * 64)

@@ -6,7 +6,7 @@
 #define PDE_MAX_CLASS 64           // RK2 step-count buckets
 #define PDE_CHUNK 262144           // kept points processed per pass (bounds the stash: 42 KB per point -> 11 GB of address space, touched only up to the kept count; sized for 288 GB of HBM)
 #ifndef PDE_NSLAB
-#define PDE_NSLAB 128
+#define PDE_NSLAB 256
 #endif
 
 // per-tile stash rows (each row = 64 floats)
