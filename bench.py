@@ -172,8 +172,14 @@ class Step:
         #  against side streams, so there it needs NVFI_OVERLAP=1)
         ov = os.environ.get("NVFI_OVERLAP")
         gloo = world > 1 and os.environ.get("NVFI_BENCH_BACKEND", "nccl") != "nccl"
+        self.s_r2 = None
         if workload == "cfg3" and (ov == "1" or (ov is None and not gloo)):
-            self.streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+            # (experiment switches: NVFI_PRIO_PDE / NVFI_PRIO_R1 / NVFI_PRIO_R2 = HIP stream priorities, -1 = high; with NVFI_PRIO_R2 set the
+            #  keyframe render runs on a third side stream of that priority instead of the current stream)
+            pr = [int(os.environ.get(k, "0")) for k in ("NVFI_PRIO_PDE", "NVFI_PRIO_R1")]
+            self.streams = [torch.cuda.Stream(device=device, priority=p) for p in pr]
+            if os.environ.get("NVFI_PRIO_R2") is not None:
+                self.s_r2 = torch.cuda.Stream(device=device, priority=int(os.environ["NVFI_PRIO_R2"]))
 
     def rays(self):
         from nvfi_amd.models import Ray
@@ -275,11 +281,21 @@ class Step:
             out = self.ren.render(i / 60.0, rays, white_background=True, mode="train")
             c1 = f.last_counters
             torch.nn.functional.mse_loss(out[0], target).backward()
-        rays, target = self.rays()
-        out = self.ren.render(t_key, rays, white_background=True, mode="train")
-        c2 = f.last_counters
-        loss = torch.nn.functional.mse_loss(out[0], target)
-        loss.backward()
+        if self.s_r2 is not None:
+            with torch.cuda.stream(self.s_r2):
+                self.s_r2.wait_event(start)
+                rays, target = self.rays()
+                out = self.ren.render(t_key, rays, white_background=True, mode="train")
+                c2 = f.last_counters
+                loss = torch.nn.functional.mse_loss(out[0], target)
+                loss.backward()
+            main.wait_stream(self.s_r2)
+        else:
+            rays, target = self.rays()
+            out = self.ren.render(t_key, rays, white_background=True, mode="train")
+            c2 = f.last_counters
+            loss = torch.nn.functional.mse_loss(out[0], target)
+            loss.backward()
         self.counters += [c1, c2]
         self.L1w *= self.lr_factor; self.tvd *= self.lr_factor; self.tva *= self.lr_factor
         if not multi:

@@ -7,10 +7,24 @@
 // nvfi_comm_init.  One process per GPU; the communicator is bound to the device that is current at init time.
 #include <dlfcn.h>
 #include <string.h>
-#include <rccl/rccl.h>
 #include "common.h"
 
-struct nvfi_comm { ncclComm_t comm; int world, rank; };
+// The handful of NCCL / RCCL ABI items this file needs, declared here instead of #include <rccl/rccl.h>: the library is found with
+// dlopen at run time, so a host without the RCCL development headers can still build libnvfi_hip.so (values as in nccl.h since 2.10:
+// the enums are part of the stable ABI).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclInvalidArgument = 4 } ncclResult_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclAvg = 4 } ncclRedOp_t;
+}
+
+struct nvfi_comm { ncclComm_t comm; int world, rank; int no_avg; };
+
+__global__ void k_scale_inplace(float* p, int64_t n, float s) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] *= s;
+}
 
 namespace {
 struct Rccl {
@@ -49,7 +63,7 @@ extern "C" int nvfi_comm_init(nvfi_comm** out, int world, int rank, const void* 
     if (load_rccl()) return 6;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
-    nvfi_comm* c = new nvfi_comm{nullptr, world, rank};
+    nvfi_comm* c = new nvfi_comm{nullptr, world, rank, 0};
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) { delete c; return nvfi_fail(200 + (int)r, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
     *out = c;
@@ -59,7 +73,17 @@ extern "C" int nvfi_comm_init(nvfi_comm** out, int world, int rank, const void* 
 extern "C" int nvfi_allreduce_grads(nvfi_comm* c, float* flat, int64_t count, int average, void* stream) {
     if (!c) return nvfi_fail(2, "nvfi_allreduce_grads: NULL communicator");
     if (count <= 0) return 0;
-    RCCLCK(g_rccl.AllReduce(flat, flat, (size_t)count, ncclFloat32, average ? ncclAvg : ncclSum, c->comm, (hipStream_t)stream));
+    if (average && !c->no_avg) {
+        const ncclResult_t r = g_rccl.AllReduce(flat, flat, (size_t)count, ncclFloat32, ncclAvg, c->comm, (hipStream_t)stream);
+        if (r == ncclSuccess) return 0;
+        if (r != ncclInvalidArgument) return nvfi_fail(200 + (int)r, "ncclAllReduce(avg) failed: %s", g_rccl.GetErrorString(r));
+        c->no_avg = 1;      // an RCCL older than 2.10 has no ncclAvg: sum, then scale
+    }
+    RCCLCK(g_rccl.AllReduce(flat, flat, (size_t)count, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream));
+    if (average) {
+        hipLaunchKernelGGL(k_scale_inplace, dim3((unsigned)((count / 4 + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, flat, count, 1.f / (float)c->world);
+        LAUNCHCK();
+    }
     return 0;
 }
 extern "C" int nvfi_comm_destroy(nvfi_comm* c) {

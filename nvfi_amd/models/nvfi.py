@@ -7,6 +7,10 @@ from .tensorf_keyframe import TensorVMKeyframeTimeKplane
 _MODELS = {"TensorVMKeyframeTimeKplane": TensorVMKeyframeTimeKplane}
 
 
+def _aslist(v):
+    return list(v) if isinstance(v, (list, tuple)) else [v]
+
+
 class NVFi(nn.Module):
     def __init__(self, config, device, aabb, res_cur, near_far):
         super().__init__()
@@ -34,6 +38,13 @@ class NVFi(nn.Module):
         """models/nvfi.py:33-35 writes every checkpoint kwarg into the field's __dict__.  Same effect here, except that the two
         entries the C-ABI descriptor caches on the host (aabb, gridSize) go through the buffer / update_stepSize."""
         f = self.nvfi
+        # the reference only rewrites __dict__ entries: a checkpoint whose STRUCTURAL kwargs differ from the constructed module (render
+        # module kind, feature widths) would leave its renderModule / basis_mat as built and silently disagree with the descriptor the
+        # kernels read, so such a checkpoint is refused here instead (build the model from the checkpoint's own config, train_nvfi.py:372-377)
+        for k in ("shadingMode", "app_dim", "pos_pe", "view_pe", "fea_pe", "featureC", "density_n_comp", "appearance_n_comp", "num_keyframes"):
+            have = getattr(f, "app_n_comp" if k == "appearance_n_comp" else k, None)
+            if k in kwargs and have is not None and list(_aslist(kwargs[k])) != list(_aslist(have)):
+                raise ValueError(f"update_nvfi_kwargs: checkpoint {k}={kwargs[k]!r} but the module was built with {have!r}")
         for k, v in kwargs.items():
             if k == "aabb":
                 f.aabb.copy_(torch.as_tensor(v).to(f.aabb.device))

@@ -106,3 +106,34 @@ def assert_contract(got, ref, what, rtol=1e-4, max_frac=0.005, band=None, label=
     print(f"[contract] {label}:{what}: max rel err {max_rel:.3e}, rays outside pure rtol={rtol:g}: {n_bad}/{n}, max abs err {err.max():.3e}")
     assert n_bad <= max(1, int(max_frac * n)), f"{label}:{what}: {n_bad}/{n} rays outside rtol={rtol:g} (max rel {max_rel:.3e})"
     assert err.max() <= band + rtol * np.abs(ref).max(), f"{label}:{what}: max abs err {err.max():.3e} leaves the threshold-flip band {band:.1e}"
+
+
+def maskfield_fp16_oracle(params, pts, g=None, round16=True):
+    """numpy restatement of MaskField (reference models/mask_field.py:68-83 as train_segm.py:97-102 builds it: Linear + ReLU x n_layer,
+    Linear -> softmax) in the arithmetic of the fp16-input MFMA mode (mask.hip: k_maskfield_fwd16 / _bwd16): every MFMA operand -
+    weights, layer inputs, and in the backward the adjoints - is rounded to fp16 (round-to-nearest-even), products accumulate in fp32,
+    bias / ReLU / softmax and every stash stay fp32, weight gradients are fp32 products of the UNROUNDED fp32 stashes.
+    round16=False gives the plain fp32 network (sanity check against the reference goldens).
+    params: [W0, b0, W1, b1, ...] (out, in) row-major.  Returns mask (N, K) and, with g (N, K) = d loss / d mask, the parameter grads."""
+    r = (lambda a: a.astype(np.float16).astype(np.float32)) if round16 else (lambda a: a.astype(np.float32))
+    Ws, bs = params[0::2], params[1::2]
+    h = [np.asarray(pts, np.float32)]
+    for l, (W, b) in enumerate(zip(Ws, bs)):
+        z = r(h[-1]) @ r(np.asarray(W, np.float32)).T + np.asarray(b, np.float32)
+        if l + 1 < len(Ws):
+            h.append(np.maximum(z, 0.0).astype(np.float32))
+    z = z - z.max(axis=1, keepdims=True)
+    e = np.exp(z)
+    mask = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+    if g is None:
+        return mask
+    g = np.asarray(g, np.float32)
+    gz = (mask * (g - (mask * g).sum(axis=1, keepdims=True))).astype(np.float32)      # softmax backward of sum(mask * g)
+    grads = [None] * len(params)
+    for l in range(len(Ws) - 1, -1, -1):
+        grads[2 * l] = (gz.T @ h[l]).astype(np.float32)          # fp32 weight gradient from the fp32 stashes
+        grads[2 * l + 1] = gz.sum(axis=0).astype(np.float32)
+        if l > 0:
+            gh = r(gz) @ r(np.asarray(Ws[l], np.float32))        # dgrad on the fp16-input MFMA
+            gz = (gh * (h[l] > 0)).astype(np.float32)
+    return mask, grads

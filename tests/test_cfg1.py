@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLD, relerr
+from conftest import GOLD, assert_grad, relerr
 from helpers import assert_contract
 
 PATH = os.path.join(GOLD, "cfg1.npz")
@@ -58,7 +58,7 @@ def test_oracle_cfg1_matches_reference(g1):
             name = k[len("train:grad:nvfi."):]
             if name == "basis_mat_density.weight":
                 continue
-            assert relerr(grads[name], g1[k]) < 5e-4, name   # fp32 sums over 131 072 samples in a different order
+            assert_grad(grads[name], g1[k], 5e-4, name)   # fp32 sums over 131 072 samples in a different order
             n += 1
     assert n >= 19
     _check_planes(g1, grads, 5e-4)
@@ -106,7 +106,7 @@ def test_gpu_cfg1_matches_reference(g1, model1):
             name = k[len("train:grad:nvfi."):]
             if name == "basis_mat_density.weight":
                 continue
-            assert relerr(grads[name], g1[k]) < 5e-4, name
+            assert_grad(grads[name], g1[k], 5e-4, name)
             n += 1
     assert n >= 19
     _check_planes(g1, grads, 5e-4)

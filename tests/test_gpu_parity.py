@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import relerr
+from conftest import assert_grad, relerr
 from helpers import make_model, named_grads, assert_contract
 
 pytestmark = pytest.mark.gpu
@@ -135,8 +135,7 @@ def test_render_train_grads(gold, models, kind, name):
         if ref.size == 0:
             assert g[pn] is None or not np.any(g[pn]), pn
             continue
-        e = relerr(g[pn], ref)
-        assert e < 5e-4, (pn, e)   # max-norm relative; fp32 atomics + different summation order
+        assert_grad(g[pn], ref, 5e-4, pn)   # max-norm AND L2 relative, element-wise outliers bounded; fp32 atomics + different summation order
         checked += 1
     assert checked >= 3
 
@@ -197,8 +196,12 @@ def test_pde_loss(gold, models, kind):
     kept = f.last_pde_kept.cpu().numpy().astype(bool)
     ref_kept = gold[f"{kind}:pde:kept"]
     assert np.mean(kept != ref_kept) < 2e-3      # alpha within rounding of the 1e-4 threshold may flip
-    if np.array_equal(kept, ref_kept):
-        np.testing.assert_allclose(f.last_pde_jac.cpu().numpy()[:, :3], gold[f"{kind}:pde:jac64"][:, :3], rtol=2e-4, atol=5e-5)
+    # functorch Jacobians of the first 64 kept points of each side, compared on the points BOTH kept (a borderline point may flip
+    # the kept set; until round 3 a single flip skipped this check altogether)
+    ours_ids, ref_ids = np.nonzero(kept)[0][:64], np.nonzero(ref_kept)[0][:64]
+    common, io, ir = np.intersect1d(ours_ids, ref_ids, return_indices=True)
+    assert len(common) >= 56, len(common)
+    np.testing.assert_allclose(f.last_pde_jac.cpu().numpy()[io, :3], gold[f"{kind}:pde:jac64"][ir, :3], rtol=2e-4, atol=5e-5)
     np.testing.assert_allclose(float(loss.detach()), gold[f"{kind}:pde:loss"][0], rtol=5e-4)
     (loss * 1.0).backward()
     g = named_grads(model)
@@ -206,8 +209,7 @@ def test_pde_loss(gold, models, kind):
     for k in gold.files:
         pre = f"{kind}:pde:grad:"
         if k.startswith(pre):
-            e = relerr(g["vel_net." + k[len(pre):]], gold[k])
-            assert e < 1e-3, (k, e)
+            assert_grad(g["vel_net." + k[len(pre):]], gold[k], 1e-3, k)
             n += 1
     assert n >= 8
 

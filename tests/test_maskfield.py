@@ -43,6 +43,17 @@ def test_oracle_maskfield_forward_only(mgold):
     np.testing.assert_allclose(out, mgold["K8:mask"][:7], rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["K8", "K3"])
+def test_fp16_oracle_without_rounding_is_the_reference(mgold, tag):
+    """the numpy restatement used as the fp16-mode oracle, with its rounding switched off, is the reference network (pins its structure)"""
+    from helpers import maskfield_fp16_oracle
+    out, grads = maskfield_fp16_oracle(_params(mgold, tag), mgold[f"{tag}:pts"], mgold[f"{tag}:g"], round16=False)
+    np.testing.assert_allclose(out, mgold[f"{tag}:mask"], rtol=2e-5, atol=1e-6)
+    for i, n in enumerate(NAMES):
+        for j, s in enumerate(["weight", "bias"]):
+            assert relerr(grads[2 * i + j], mgold[f"{tag}:grad:{n}.{s}"]) < 2e-5, (n, s)
+
+
 def _model(g, tag, K):
     from nvfi_amd.models import MaskField
     mf = MaskField(n_layer=4, n_dim=128, input_dim=3, skips=[], mask_dim=K, mask_act="softmax")
@@ -135,5 +146,14 @@ def test_gpu_maskfield_fp16_mfma_mode(mgold, tag, K):
         a, b = p.grad.cpu().numpy().ravel().astype(np.float64), mgold[f"{tag}:grad:{n}"].ravel().astype(np.float64)
         assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.995, n
         assert relerr(p.grad.cpu().numpy(), mgold[f"{tag}:grad:{n}"]) < 0.2, n
+    # digit-level check against an oracle in the SAME arithmetic (fp16-rounded MFMA operands, fp32 accumulation, fp32 stashes and weight
+    # gradients): what is left is the fp32 summation order and a ReLU gate whose pre-activation is within rounding of zero
+    from helpers import maskfield_fp16_oracle
+    omask, ograds = maskfield_fp16_oracle(_params(mgold, tag), mgold[f"{tag}:pts"], mgold[f"{tag}:g"])
+    np.testing.assert_allclose(mask.detach().cpu().numpy(), omask, rtol=2e-4, atol=2e-6)
+    for i, n in enumerate(NAMES):
+        for j, sfx in enumerate(["weight", "bias"]):
+            e = relerr(mf.get_parameter(f"{n}.{sfx}").grad.cpu().numpy(), ograds[2 * i + j])
+            assert e < 1e-3, (n, sfx, e)
     mf.mfma_fp16 = False
     assert np.abs(mf(pts).detach().cpu().numpy() - ref).max() < 1e-5          # and back to the exact path

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLD, relerr
+from conftest import GOLD, assert_grad, relerr
 from helpers import assert_contract, load_meta
 
 T_NONKEY, T_KEY = 19.0 / 60.0, 0.25
@@ -32,8 +32,7 @@ def _check_grads(g2, grads, tol=5e-4):
         if not k.startswith("D:train:grad:nvfi."):
             continue
         name = k[len("D:train:grad:nvfi."):]
-        e = relerr(grads[name], g2[k])
-        assert e < tol, (name, e)
+        assert_grad(grads[name], g2[k], tol, name)
         n += 1
     assert n == 25, n       # 12 planes + basis_mat + 12 velocity tensors
 
