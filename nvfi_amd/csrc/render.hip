@@ -105,38 +105,29 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     if (lane == 0) { a.cnt[r] = cnt; if (a.cnt_r) a.cnt_r[r] = cntr; }
 }
 
-// exclusive scan of n int32 counts (single workgroup), off[n] = total, *total_out = total
-__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ cnt, int* __restrict__ off, int64_t n, int* total_out) {
-    __shared__ int wsum[16];
-    __shared__ int carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        int64_t i = base + tid;
-        int v = i < n ? cnt[i] : 0;
-        int incl = v;
+// ordered fill of the compact list: list[off[r] + rank] = dense index.  The exclusive scan of the per-group counts rides in the same
+// launch: a workgroup (4 groups) sums the counts of every group before its own - n <= a few thousand ints out of L2 - instead of reading
+// the result of a separate one-workgroup scan kernel (one launch less per compaction: 3 per render, 2 per PDE call); it also writes
+// off[] for its groups (k_final_fwd / k_weights_bwd read the per-ray offsets of the masked list), the last one off[n] and *total_out.
+__global__ __launch_bounds__(256) void k_fill(int64_t R, int S, const uint8_t* __restrict__ flags, const int* __restrict__ cnt, int* __restrict__ off,
+                                              int* __restrict__ list, int* total_out) {
+    __shared__ int part[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * 4;
+    int s = 0;
+    for (int64_t i = threadIdx.x; i < r0; i += 256) s += cnt[i];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-        if (lane == 63) wsum[w] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < w; ++k) woff += wsum[k];
-        int carry = carry_s;
-        if (i < n) off[i] = carry + woff + incl - v;
-        __syncthreads();
-        if (tid == 1023) carry_s = carry + woff + incl;
-        __syncthreads();
-    }
-    if (tid == 0) { off[n] = carry_s; *total_out = carry_s; }
-}
-
-// ordered fill of the compact list: list[off[r] + rank] = dense index
-__global__ __launch_bounds__(256) void k_fill(int64_t R, int S, const uint8_t* __restrict__ flags, const int* __restrict__ off, int* __restrict__ list) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) part[w] = s;
+    __syncthreads();
+    int base = (part[0] + part[1]) + (part[2] + part[3]);
+    const int64_t r = r0 + w;
+    for (int k = 0; k < w; ++k) base += (r0 + k < R) ? cnt[r0 + k] : 0;
     if (r >= R) return;
-    int base = off[r];
+    if (lane == 0) {
+        off[r] = base;
+        if (r == R - 1) { const int tot = base + cnt[r]; off[R] = tot; *total_out = tot; }
+    }
     for (int j0 = 0; j0 < S; j0 += 64) {
         const int j = j0 + lane;
         bool ok = j < S && flags[r * S + j];
@@ -148,8 +139,8 @@ __global__ __launch_bounds__(256) void k_fill(int64_t R, int S, const uint8_t* _
 
 // scan + ordered fill for n_groups groups of 64 flags (used by the PDE prefilter)
 int launch_scan_fill(const int* cnt, int* off, int64_t ngroups, int* total, const uint8_t* flags, int* list, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, cnt, off, ngroups, total);
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, st, ngroups, 64, flags, off, list);
+    if (ngroups <= 0) { HIPCK(hipMemsetAsync(total, 0, sizeof(int), st)); return 0; }
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, st, ngroups, 64, flags, cnt, off, list, total);
     LAUNCHCK();
     return 0;
 }
@@ -1178,11 +1169,9 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
     SampleArgs sa; sa.f = *f; sa.R = R; sa.o = rays_o; sa.d = rays_d; sa.u = jitter; sa.train = train; sa.inside = P.counters + 2;
     sa.xw = P.xw; sa.xpre = P.xpre; sa.valid = P.valid; sa.cnt = P.cnt_v; sa.rflag = P.rflag; sa.cnt_r = P.cnt_r;
     hipLaunchKernelGGL(k_sample, dim3(ray_blocks), dim3(256), 0, st, sa);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P.cnt_v, P.off_v, R, P.counters + 0);
-    hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.valid, P.off_v, P.vlist);
+    hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.valid, P.cnt_v, P.off_v, P.vlist, P.counters + 0);
     if (nsteps > 0) {   // second compact list: the valid samples inside the velocity gate (counters[3])
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P.cnt_r, P.off_r, R, P.counters + 3);
-        hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.rflag, P.off_r, P.rlist);
+        hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.rflag, P.cnt_r, P.off_r, P.rlist, P.counters + 3);
     }
     LAUNCHCK();
     // velocity warp back to the keyframe
@@ -1211,8 +1200,7 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
     wa.R = R; wa.S = S; wa.xpre = P.xpre; wa.xw = P.xw; wa.distance_scale = f->distance_scale; wa.weight_thres = f->weight_thres;
     wa.far_ = f->far_; wa.weight = weights; wa.mflag = P.mflag; wa.acc = acc; wa.depth = depth; wa.cnt_m = P.cnt_m;
     hipLaunchKernelGGL(k_weights_fwd, dim3(ray_blocks), dim3(256), 0, st, wa);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P.cnt_m, P.off_m, R, P.counters + 1);
-    hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.mflag, P.off_m, P.mlist);
+    hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.mflag, P.cnt_m, P.off_m, P.mlist, P.counters + 1);
     LAUNCHCK();
     // appearance
     AppArgs aa; memset(&aa, 0, sizeof(aa));
