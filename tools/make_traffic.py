@@ -7,7 +7,7 @@ import json
 import sys
 
 CLASSES = {
-    "wgrad": ["k_wgrad"],
+    "wgrad": ["k_wgrad", "k_wgrad_ring8"],
     "pde_prefilter": ["void k_rk2_fwd<false, false>", "void k_rk2_split<2>", "void k_rk2_split<1>", "void k_rk2_split<4>", "k_rk2_pre16"],
     "rk2_fwd": ["void k_rk2_fwd<true, true>", "void k_rk2_split_uni<2, true>"],
     "rk2_bwd": ["k_rk2_bwd", "void k_rk2_split_bwd<2>"],
