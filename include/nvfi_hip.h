@@ -202,6 +202,11 @@ int nvfi_density_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, floa
 int nvfi_app_workspace_bytes(const nvfi_field_desc* f, int64_t N, int64_t* bytes);
 int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyzt, const float* view, float* rgb,
                 void* workspace, int64_t workspace_bytes, void* stream);
+/* renderModule(pts, viewdirs, features) as a stand-alone call - MLPRender_PE.forward (tensorf_base.py:88-98) or, with shading = 1,
+ * SHRender (tensorf_model_utils.py:292-296): xyz (N,3) normalised positions, view (N,3), features (N, app_dim) -> rgb (N,3).
+ * Workspace: 2 x nvfi_app_workspace_bytes(f, N) is enough.  Forward only (inside a render the module is differentiated by nvfi_render_bwd). */
+int nvfi_render_mlp(const nvfi_field_desc* f, int64_t N, const float* xyz, const float* view, const float* features, float* rgb,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 /* ---- multi-GPU: rays and collocation points shard over one process per GPU; the ONLY data-path exchange is the sum of the
  *      flat fp32 gradient buffer (the reference has no distributed code: models/ is single-device).  RCCL over xGMI,
  *      loaded lazily with dlopen.  Bootstrap: rank 0 gets a 128-byte id, the host program distributes it, every rank inits.

@@ -58,6 +58,7 @@ struct AppArgs {
     const float* sched;
     const float* rays_d; const float* view_per_point;
     float4* rgbs; int rgb_dense;
+    const float* feat_in;  // (N, app_dim) appearance features given by the caller (renderModule as a stand-alone call): no plane gather, no basis_mat
     float* stash_f; float* stash_b;
     // backward
     nvfi_grads g;
@@ -81,5 +82,6 @@ struct ScatterArgs {
 
 __global__ void k_counters(const int* c, int nsteps, int64_t* out, const float* sched = nullptr);
 __global__ void k_unpack_rgb(const float4* in, float* out, int64_t N);
+__global__ void k_pack_xyz4(const float* in, float4* out, int64_t N);
 int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, const int* count, int cap_tiles, int nrep,
                      int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st);

@@ -379,13 +379,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
     }
     float x[64];
     float* scr = lds_w + SCR_OFF;
-    {
+    if (!a.feat_in) {
         Bl b[6];
         plane_setups(f, q.x, q.y, q.z, tn, b);
         app_gather_to_scratch(f, b, h, scr);
     }
 #pragma unroll
-    for (int s = 0; s < 24; ++s) x[s] = scr[s * 256 + threadIdx.x];
+    for (int s = 0; s < 24; ++s) x[s] = a.feat_in ? 0.f : scr[s * 256 + threadIdx.x];
     float* st = STASH ? a.stash_f + (size_t)tile * (APP_F_ROWS * REGF) : nullptr;
     if (STASH) {
 #pragma unroll
@@ -407,7 +407,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
     __syncthreads();
     f32x16 o1[1];
     acc_init<1>(o1, lds_b, h, false);
-    layer_mfma<1, 24>(lds_w, lane, x, o1);
+    if (!a.feat_in) layer_mfma<1, 24>(lds_w, lane, x, o1);
+    else {      // features from the caller, in the D layout of the basis tile: register r of lane (n, h) is feature (r&3) + 8(r>>2) + 4h
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            o1[0][r] = (active && row < f.app_dim) ? a.feat_in[(size_t)n * f.app_dim + row] : 0.f;
+        }
+    }
     if (f.shading == 1) {
         // SHRender (tensorf_model_utils.py:292-296, sh.py:87-110): the 27 features are rows (r&3)+8(r>>2)+4h of the basis tile, split over the
         // lane pair (l, l+32); colour c = relu(sum_k SH_k(viewdir) feat[9c + k] + 0.5).  No MLP, no positional encodings.
@@ -1462,6 +1469,35 @@ extern "C" int nvfi_app_at(const nvfi_field_desc* f, int64_t N, const float* xyz
     hipLaunchKernelGGL(k_unpack_rgb, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, out4, rgb, N);
     LAUNCHCK();
     return 0;
+}
+// renderModule(pts, viewdirs, features) as a stand-alone call (tensorf_base.py:88-98 / tensorf_model_utils.py:292-296): the appearance
+// features are the caller's, only the positional encodings + MLP (or the SH epilogue) of k_app_fwd run.  xyz: (N,3) normalised positions.
+extern "C" int nvfi_render_mlp(const nvfi_field_desc* f, int64_t N, const float* xyz, const float* view, const float* features, float* rgb,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (check_desc(f)) return 2;
+    if (N <= 0) return 0;
+    if (ensure_render_attrs()) return 1;
+    Bump B{(char*)workspace, 0, 0};
+    float* frag = B.take<float>(RENDER_FRAG_FLOATS);
+    float4* out4 = B.take<float4>(N);
+    float4* xw = B.take<float4>(N);
+    if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
+    PackJobs jobs; jobs.n = 0; RenderFrags RW;
+    if (pack_render_frags(f, frag, &RW, &jobs)) return 3;
+    if (launch_pack(jobs, st)) return 1;
+    hipLaunchKernelGGL(k_pack_xyz4, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xyz, xw, N);
+    AppArgs aa; memset(&aa, 0, sizeof(aa));
+    aa.f = *f; aa.W = RW; aa.count = nullptr; aa.n_direct = N; aa.list = nullptr; aa.xw = xw;
+    aa.per_point_t = 1; aa.S = 1; aa.view_per_point = view; aa.rgbs = out4; aa.rgb_dense = 1; aa.feat_in = features;
+    hipLaunchKernelGGL(k_app_fwd<false>, dim3((unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES)), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa);
+    hipLaunchKernelGGL(k_unpack_rgb, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, out4, rgb, N);
+    LAUNCHCK();
+    return 0;
+}
+__global__ void k_pack_xyz4(const float* in, float4* out, int64_t N) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < N) out[i] = make_float4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 0.f);
 }
 __global__ void k_unpack_rgb(const float4* in, float* out, int64_t N) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;

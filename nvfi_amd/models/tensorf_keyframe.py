@@ -45,7 +45,16 @@ class MLPRender_PE(nn.Module):
         self._owner = None
 
     def forward(self, pts, viewdirs, features, kwargs=None):
-        raise NotImplementedError("MLPRender_PE is evaluated inside the fused appearance kernel; use field.app_at(xyzt, viewdirs)")
+        """renderModule(pts, viewdirs, features) as the reference's module can be called (tensorf_base.py:88-98): the positional encodings and
+        the MLP of the fused appearance kernel on the caller's features (nvfi_render_mlp).  Forward only - inside a render the module is
+        differentiated by nvfi_render_bwd; a stand-alone call that needs gradients is refused rather than silently detached."""
+        field = self._owner() if callable(self._owner) else self._owner
+        if field is None:
+            raise _lib.NvfiError("MLPRender_PE.forward needs the field it belongs to (it is created by TensorVMKeyframeTimeKplane)")
+        if torch.is_grad_enabled() and (features.requires_grad or pts.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("stand-alone MLPRender_PE.forward is forward-only: call it under torch.no_grad() "
+                                      "(gradients of the render module flow through Renderer.render / NVFi.render_ray)")
+        return field._render_module_call(pts, viewdirs, features)
 
 
 def SHRender(xyz_sampled, viewdirs, features, kwargs=None):
@@ -314,6 +323,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             if self.pos_pe != 6 or self.view_pe != 6 or self.featureC != 128 or self.app_dim != 32:
                 raise NotImplementedError("shadingMode=MLP_PE is built for pos_pe=view_pe=6, featureC=128, app_dim=32 (every shipped config)")
             self.renderModule = MLPRender_PE(self.app_dim, self.view_pe, self.pos_pe, self.featureC).to(device)
+            self.renderModule._owner = weakref.ref(self)      # renderModule(pts, viewdirs, features) evaluates on this field's kernels
         else:
             raise NotImplementedError("shadingMode must be MLP_PE or SH (MLP_Fea / MLP / RGB* are not on the hot path: no shipped config uses them)")
         self.use_vel = bool(cfg.use_vel)
@@ -459,6 +469,20 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             return 1, self._sur_host[0], self._sur_host[1]
         eps = float(self.vel.eps)
         return 0, [float(np.float32(-1 + eps))] * 3, [float(np.float32(1 - eps))] * 3
+
+    def __deepcopy__(self, memo):
+        """a copy's sub-modules (vel_net, renderModule) must evaluate on the COPY's kernels / descriptor, not on the original's:
+        the weak back-references are re-pointed after the default deep copy"""
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        for child in (getattr(new, "vel_net", None), getattr(new, "renderModule", None)):
+            if isinstance(child, nn.Module) and "_owner" in child.__dict__:
+                child.__dict__["_owner"] = weakref.ref(new)
+        return new
 
     def _desc(self, params=None):
         """nvfi_field_desc for the current parameters (or for the tensors saved by autograd)."""
@@ -820,6 +844,23 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         ws = torch.empty(nb.value, dtype=torch.uint8, device=q.device)
         _lib.check(L.nvfi_app_at(C.byref(desc), C.c_int64(N), _lib.ptr(q), _lib.ptr(v), _lib.ptr(rgb), _lib.ptr(ws),
                                  C.c_int64(ws.numel()), _stream_ptr()))
+        return rgb
+
+    def _render_module_call(self, pts, viewdirs, features):
+        L = _lib.lib()
+        if not features.is_cuda:
+            raise _lib.NvfiError("NVFi HIP kernels need CUDA tensors (no CPU fallback exists)")
+        x = pts.reshape(-1, 3).contiguous().float()
+        v = viewdirs.reshape(-1, 3).contiguous().float()
+        fe = features.reshape(-1, self.app_dim).contiguous().float()
+        N = x.shape[0]
+        rgb = torch.empty(N, 3, device=x.device)
+        desc = self._desc()
+        nb = C.c_int64(0)
+        _lib.check(L.nvfi_app_workspace_bytes(C.byref(desc), C.c_int64(N), C.byref(nb)))
+        ws = torch.empty(2 * nb.value, dtype=torch.uint8, device=x.device)
+        _lib.check(L.nvfi_render_mlp(C.byref(desc), C.c_int64(N), _lib.ptr(x), _lib.ptr(v), _lib.ptr(fe), _lib.ptr(rgb), _lib.ptr(ws),
+                                     C.c_int64(ws.numel()), _stream_ptr()))
         return rgb
 
     def pde_loss(self, points, t):

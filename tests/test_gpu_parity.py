@@ -184,6 +184,18 @@ def test_render_vs_oracle_bigger(fields, models, kind):
 
 
 @pytest.mark.parametrize("kind", KINDS)
+def test_render_module_is_callable_like_the_reference(gold, models, kind):
+    """field.renderModule(pts, viewdirs, features) (tensorf_base.py:88-98) against the reference's own outputs for given features"""
+    model, meta = models[kind]
+    f = model.nvfi
+    with torch.no_grad():
+        rgb = f.renderModule(_cuda(gold[f"{kind}:mlp:pts"]), _cuda(gold[f"{kind}:mlp:view"]), _cuda(gold[f"{kind}:mlp:feat"]), {})
+    np.testing.assert_allclose(rgb.cpu().numpy(), gold[f"{kind}:mlp:rgb"], rtol=1e-4, atol=2e-6)
+    with pytest.raises(NotImplementedError):       # forward only: a stand-alone call that wants gradients is refused, not detached
+        f.renderModule(_cuda(gold[f"{kind}:mlp:pts"]), _cuda(gold[f"{kind}:mlp:view"]), _cuda(gold[f"{kind}:mlp:feat"]).requires_grad_(), {})
+
+
+@pytest.mark.parametrize("kind", KINDS)
 def test_pde_loss(gold, models, kind):
     model, meta = models[kind]
     f = model.nvfi
