@@ -418,8 +418,6 @@ class GraphedStep:
         s = self.s
         self.host_record()
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        g.register_generator_state(s.gen)
         cap = torch.cuda.Stream(device=s.dev)
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
@@ -427,17 +425,26 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         self.flags.clear()
-        self.host_record()
-        torch.cuda.synchronize()
-        with torch.cuda.graph(g, stream=cap):
-            self.body()
-        self.graph = g
-        g.replay()                      # the captured iteration itself (its record was uploaded above)
-        torch.cuda.synchronize()
+        # NVFI_GRAPH_EXECS executable graphs of the same iteration, replayed in turn (experiment: does a replay wait for the previous launch
+        # of the SAME executable graph on the host?)
+        self.graphs = []
+        for _ in range(max(1, int(os.environ.get("NVFI_GRAPH_EXECS", "1")))):
+            self.host_record()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            g.register_generator_state(s.gen)
+            with torch.cuda.graph(g, stream=cap):
+                self.body()
+            self.graphs.append(g)
+            g.replay()                  # the captured iteration itself (its record was uploaded above)
+            torch.cuda.synchronize()
+        self.graph = self.graphs[0]
+        self.turn = 0
 
     def __call__(self):
         self.host_record()
-        self.graph.replay()
+        self.graphs[self.turn % len(self.graphs)].replay()
+        self.turn += 1
         return self.loss
 
     def check(self):

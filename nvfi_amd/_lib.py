@@ -14,7 +14,7 @@ NCOUNTERS = 8
 class FieldDesc(C.Structure):
     _fields_ = [
         ("G", C.c_int32 * 3), ("K", C.c_int32), ("Cd", C.c_int32), ("Ca", C.c_int32), ("app_dim", C.c_int32),
-        ("n_samples", C.c_int32), ("use_vel", C.c_int32), ("gate_sur", C.c_int32), ("has_amask", C.c_int32), ("shading", C.c_int32),
+        ("n_samples", C.c_int32), ("use_vel", C.c_int32), ("gate_sur", C.c_int32), ("has_amask", C.c_int32), ("shading", C.c_int32), ("vel_fp16", C.c_int32),
         ("am_dims", C.c_int32 * 3),
         ("aabb", C.c_float * 6), ("near_", C.c_float), ("far_", C.c_float), ("step_size", C.c_float),
         ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float),

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "common.h"
+#include "pde.h"
 #include "scatter.h"
 #include "vel.h"
 
@@ -55,9 +56,17 @@ extern "C" int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const flo
     if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
     PackJobs jobs; jobs.n = 0;
     Rk2Args a; memset(&a, 0, sizeof(a));
-    if (pack_vel_frags(f->vW, f->vb, fv, &a.Wv, &jobs)) return 3;
-    if (launch_pack(jobs, st)) return 1;
+    if (!f->vel_fp16) {
+        if (pack_vel_frags(f->vW, f->vb, fv, &a.Wv, &jobs)) return 3;
+        if (launch_pack(jobs, st)) return 1;
+    }
     hipLaunchKernelGGL(k_pack_xt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, x, xw);
+    if (f->vel_fp16) {      // opt-in fp16-input inference mode (pre16.hip): the fragment region of the workspace holds the fp16 image
+        static_assert(VEL_FRAG_FLOATS * 4 >= PRE16_IMAGE_BYTES, "fragment region holds the fp16 image");
+        Rk16Args h; memset(&h, 0, sizeof(h));
+        h.img = fv; h.P = N; h.xw = xw; h.xout3 = xk; h.pt_t = t; h.pt_base = base; h.dt_max = dt_max_of(*f); h.max_steps = 4096;
+        return launch_rk2_inf16(f, h, false, st);
+    }
     a.f = *f; a.count = nullptr; a.n_direct = N; a.list = nullptr; a.xw = xw; a.xout = xk;
     a.pt_t = t; a.pt_base = base; a.dt_max = dt_max_of(*f); a.max_steps = 4096;
     return launch_rk2_fwd(a, N, false, false, st);
@@ -112,11 +121,18 @@ extern "C" int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const flo
             a.dt[n] = dt; a.tcur[n] = tc;
             off = off - dt; tc = tc - dt; ++n;
         }
+        if (f->vel_fp16) {  // opt-in fp16-input inference mode (pre16.hip)
+            Rk16Args h; memset(&h, 0, sizeof(h));
+            h.img = fv; h.P = N; h.xw = xw; h.xout = xw; h.nsteps = n;
+            for (int k = 0; k < n; ++k) { h.dt[k] = a.dt[k]; h.tcur[k] = a.tcur[k]; }
+            if (launch_rk2_inf16(f, h, true, st)) return 1;
+        } else {
         PackJobs jobs; jobs.n = 0;
         if (pack_vel_frags(f->vW, f->vb, fv, &a.Wv, &jobs)) return 3;
         if (launch_pack(jobs, st)) return 1;
         a.f = *f; a.count = nullptr; a.n_direct = N; a.list = nullptr; a.xw = xw; a.xout = nullptr; a.nsteps = n;
         if (launch_rk2_fwd(a, N, true, false, st)) return 1;
+        }
     }
     {   // density at the (warped) points with the quad-lane gather kernel (scatter.hip), then alpha = 1 - exp(-sigma * length)
         DensityArgs da; memset(&da, 0, sizeof(da));

@@ -85,6 +85,17 @@ struct Pre16Args {
     const float* pt_t; const float* pt_base; float dt_max; int max_steps; float eps_gate;
 };
 int launch_pre16(const nvfi_field_desc* f, Pre16Args a, hipStream_t st);
+// fp16-input inference back-advection (nvfi_field_desc.vel_fp16): P = capacity, count = optional device-side count, list = optional
+// compact -> dense map; per-point mode reads pt_t / pt_base at the compact index, uniform mode the step schedule (by value or `sched`)
+struct Rk16Args {
+    nvfi_field_desc f;
+    void* img;                     // PRE16_IMAGE_BYTES of workspace
+    int64_t P; const int* count; const int* list;
+    const float4* xw; float4* xout; float* xout3;
+    const float* pt_t; const float* pt_base; float dt_max; int max_steps;
+    int nsteps; float dt[64]; float tcur[64]; const float* sched;
+};
+int launch_rk2_inf16(const nvfi_field_desc* f, Rk16Args a, bool uniform, hipStream_t st);
 int launch_pde_band(const nvfi_field_desc* f, int64_t P, const int* perm, const float* sig, const uint8_t* near, float band, uint8_t* flags,
                     int* cnt, hipStream_t st);
 int launch_pde_band_map(int64_t P, const int* bcount, const int* perm, int* blist, hipStream_t st);

@@ -161,6 +161,95 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_pre16(Pre16Args a) {
     if (active && h == 0) { a.xout[n] = make_float4(x, y, z, q0.w); a.near[n] = near ? 1 : 0; }
 }
 
+// ---------------------------------------------------------------- opt-in fp16-input INFERENCE mode of the velocity field
+// nvfi_field_desc.vel_fp16 (off by default; the reference's counterpart is its autocast switch --disable_fp32, train_nvfi.py:96,144):
+// every no-grad back-advection - integrate_pos (train_segm.py:150-166 walks up to 30 RK2 steps per point), the render warp of
+// eval-mode renders, getDenseAlpha's 60 frame times - evaluates VelBasis on v_mfma_f32_32x32x16_f16 (weights and layer inputs rounded
+// to binary16, fp32 accumulation; encoder, SiLU, basis combination, gates and the RK2 recurrence in fp32).  Same wave-per-tile kernel
+// as the prefilter pre-pass above, with the two time modes of k_rk2_fwd: per-point (t, base) or a uniform step schedule.
+// Training renders, the PDE regulariser and every gradient stay fp32.  tests/test_gpu_vel_fp16.py checks it against a CPU restatement
+// in the same arithmetic (binary16-rounded operands, fp32 accumulation).
+template <bool UNI>
+__global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_inf16(Rk16Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.img);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < PRE16_IMAGE_BYTES / 16; i += P16_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const h8_t* W = reinterpret_cast<const h8_t*>(lds);
+    const float* bias = lds + P16_H8 * 4;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    int64_t P = a.P;
+    if (a.count) { const int64_t c = *a.count; P = c < P ? c : P; }
+    const int64_t tile = (int64_t)blockIdx.x * (P16_THREADS / 64) + (threadIdx.x >> 6);
+    const int64_t i = tile * TILE + (lane & 31);
+    if (tile * TILE >= P) return;                       // wave-uniform; no barrier follows
+    const bool active = i < P;
+    const int64_t n = active ? (a.list ? (int64_t)a.list[i] : i) : 0;
+    const float4 q0 = active ? a.xw[n] : zero4();
+    float x = q0.x, y = q0.y, z = q0.z;
+    float tcur = (!UNI && active) ? a.pt_t[i] : 0.f;
+    float off = (!UNI && active) ? tcur - a.pt_base[i] : 0.f;
+    const int nsteps = UNI ? (a.sched ? __float_as_int(a.sched[2]) : a.nsteps) : a.max_steps;
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+        float dt;
+        bool live;
+        if (UNI) { dt = RK_DT(a, s); tcur = RK_TC(a, s); live = active; }
+        else {
+            live = fabsf(off) > 0.f;
+            if (!__any(live)) break;
+            const float m = fminf(fabsf(off), a.dt_max);
+            dt = off > 0.f ? m : (off < 0.f ? -m : 0.f);
+        }
+        float o4[4], w1[6], w2[6], v1[3], v2[3];
+        velnet16(W, bias, lane, h, make_float4(x, y, z, tcur), o4);
+        gather6(o4, h, w1);
+        vel_from_w(w1, x, y, z, v1);
+        if (gated_out(a.f, x, y, z)) { v1[0] = v1[1] = v1[2] = 0.f; }
+        const float hdt = 0.5f * dt;
+        const float px = x - hdt * v1[0], py = y - hdt * v1[1], pz = z - hdt * v1[2];
+        velnet16(W, bias, lane, h, make_float4(px, py, pz, tcur - hdt), o4);
+        gather6(o4, h, w2);
+        vel_from_w(w2, px, py, pz, v2);
+        if (gated_out(a.f, px, py, pz)) { v2[0] = v2[1] = v2[2] = 0.f; }
+        const float nx = x - dt * v2[0], ny = y - dt * v2[1], nz = z - dt * v2[2];
+        const bool rej = a.f.gate_sur && gated_out(a.f, nx, ny, nz);
+        if (live) {
+            if (!rej) { x = nx; y = ny; z = nz; }
+            if (!UNI) { off = off - dt; tcur = tcur - dt; }
+        }
+    }
+    if (active && h == 0) {
+        if (a.xout3) { a.xout3[3 * n] = x; a.xout3[3 * n + 1] = y; a.xout3[3 * n + 2] = z; }
+        else a.xout[n] = make_float4(x, y, z, q0.w);
+    }
+}
+
+int launch_rk2_inf16(const nvfi_field_desc* f, Rk16Args a, bool uniform, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
+        attr = true;
+    }
+    if (a.P <= 0) return 0;
+    Pack16VelArgs pk;
+    for (int l = 0; l < 6; ++l) { pk.W[l] = f->vW[l]; pk.b[l] = f->vb[l]; }
+    pk.img = reinterpret_cast<h8_t*>(a.img);
+    hipLaunchKernelGGL(k_pack_vel16, dim3((P16_H8 + 255) / 256), dim3(256), 0, st, pk);
+    a.f = *f;
+    const int64_t tiles = (a.P + TILE - 1) / TILE;
+    const unsigned wgs = (unsigned)((tiles + P16_THREADS / 64 - 1) / (P16_THREADS / 64));
+    ProfScope ps(PK_RK2_FWD, st);
+    if (uniform) hipLaunchKernelGGL(k_rk2_inf16<true>, dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+    else hipLaunchKernelGGL(k_rk2_inf16<false>, dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+    LAUNCHCK();
+    return 0;
+}
+
 // alpha at the fp16-warped point: flags = 1 for the points whose decision is left to the fp32 pass.  Walks the points in BUCKET
 // order (perm: most RK2 steps first), so the compacted list keeps the workgroups of the fp32 pass homogeneous in step count.
 __global__ __launch_bounds__(256) void k_pde_band(nvfi_field_desc f, int64_t P, const int* perm, const float* sig, const uint8_t* near,

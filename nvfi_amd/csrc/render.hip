@@ -1191,7 +1191,14 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
         // the feature-split layout of vel_split.hip (NVFI_RK2_SPLIT=0: k_rk2_fwd of vel.hip; same stash, same numbers bit for bit)
         static int split = -1;
         if (split < 0) { const char* e = getenv("NVFI_RK2_SPLIT"); split = e ? atoi(e) : 1; }
-        if (split) {
+        if (f->vel_fp16 && !train) {
+            // opt-in fp16-input inference mode (pre16.hip): eval-mode renders only; the x4 fragment region holds the fp16 image
+            static_assert(VEL_X4F_FLOATS * 4 >= PRE16_IMAGE_BYTES, "x4 fragment region holds the fp16 image");
+            Rk16Args h; memset(&h, 0, sizeof(h));
+            h.img = P.vel_x4; h.P = N; h.count = P.counters + 3; h.list = P.rlist; h.xw = P.xw; h.xout = P.xw; h.nsteps = nsteps; h.sched = sched;
+            for (int s = 0; s < nsteps; ++s) { h.dt[s] = dts[s]; h.tcur[s] = tcs[s]; }
+            if (launch_rk2_inf16(f, h, true, st)) return 1;
+        } else if (split) {
             SplitUniArgs ua; ua.r = ra;
             if (pack_vel_x4_fwd(VW, P.vel_x4, ua.f4, st)) return 1;
             for (int l = 0; l < 6; ++l) ua.bv[l] = VW.b[l];

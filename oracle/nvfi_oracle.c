@@ -310,17 +310,59 @@ static inline void linear(const float* W, const float* b, int out, int in, const
         y[o] = s;
     }
 }
+/* IEEE binary16 round-to-nearest-even of an fp32 value, returned as fp32 (subnormals kept, overflow -> inf): what v_cvt_f16_f32 does
+ * to an MFMA operand of the product's opt-in fp16-input inference mode (nvfi_field_desc.vel_fp16, pre16.hip). */
+static inline float f16_round(float x) {
+    union { float f; uint32_t u; } v; v.f = x;
+    const uint32_t sign = v.u & 0x80000000u;
+    const int32_t ex = (int32_t)((v.u >> 23) & 0xff);
+    uint32_t man = v.u & 0x7fffffu;
+    if (ex == 255) return x;                                  /* inf / nan */
+    const int32_t e = ex - 127;                               /* unbiased */
+    if (e > 15) { v.u = sign | 0x7f800000u; return v.f; }
+    int drop;                                                 /* low mantissa bits that binary16 cannot hold */
+    if (e >= -14) drop = 13;
+    else {
+        if (e < -25) { v.u = sign; return v.f; }              /* below half of the smallest subnormal */
+        drop = 13 + (-14 - e);
+    }
+    uint32_t full = (ex ? 0x800000u : 0u) | man;              /* 24-bit significand */
+    const uint32_t half = 1u << (drop - 1), mask = (1u << drop) - 1u;
+    const uint32_t rem = full & mask;
+    full &= ~mask;
+    if (rem > half || (rem == half && (full & (1u << drop)))) full += (1u << drop);
+    /* back to fp32: value = full * 2^(e - 23) */
+    const float r = ldexpf((float)full, e - 23);
+    if (r >= 65520.f) { v.u = sign | 0x7f800000u; return v.f; }
+    v.f = r; v.u |= sign;
+    return v.f;
+}
+static int g_vel_fp16 = 0;      /* test switch: the velocity nets' FORWARD in the arithmetic of the fp16-input MFMA mode */
+void orc_set_vel_fp16(int on) { g_vel_fp16 = on; }
+float orc_f16_round(float x) { return f16_round(x); }
+/* a Linear layer whose weights and inputs are rounded to binary16 before the product; fp32 accumulation from the bias */
+static inline void linear16(const float* W, const float* b, int out, int in, const float* x, float* y) {
+    float xr[HID];
+    for (int k = 0; k < in; ++k) xr[k] = f16_round(x[k]);
+    for (int o = 0; o < out; ++o) {
+        float s = b ? b[o] : 0.f;
+        const float* w = W + (size_t)o * in;
+        for (int k = 0; k < in; ++k) s += f16_round(w[k]) * xr[k];
+        y[o] = s;
+    }
+}
 /* weight_net / a_weight_net forward. zs: 5*HID pre-activations (optional). act: 1 SiLU, 0 ReLU */
 static void velnet_fwd(const float* const* W, const float* const* b, int act, const float* q, float* zs, float* out6) {
     float e[ENC], h[HID], z[HID];
+    void (*lin)(const float*, const float*, int, int, const float*, float*) = g_vel_fp16 ? linear16 : linear;
     vel_encode(q, e);
-    linear(W[0], b[0], HID, ENC, e, z);
+    lin(W[0], b[0], HID, ENC, e, z);
     for (int l = 0; l < 5; ++l) {
         if (zs) memcpy(zs + l * HID, z, sizeof(z));
         for (int i = 0; i < HID; ++i) h[i] = act ? siluf_(z[i]) : (z[i] > 0.f ? z[i] : 0.f);
-        if (l < 4) linear(W[l + 1], b[l + 1], HID, HID, h, z);
+        if (l < 4) lin(W[l + 1], b[l + 1], HID, HID, h, z);
     }
-    linear(W[5], b[5], 6, HID, h, out6);
+    lin(W[5], b[5], 6, HID, h, out6);
 }
 static inline float act_f(int act, float z) { return act ? siluf_(z) : (z > 0.f ? z : 0.f); }
 static inline float act_d1(int act, float z) {

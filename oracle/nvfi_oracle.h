@@ -111,6 +111,9 @@ float orc_density_L1(const orc_field_t* f);
 float orc_tv_density(const orc_field_t* f);
 float orc_tv_app(const orc_field_t* f);
 
+/* test switch: velocity-net forward with weights / layer inputs rounded to binary16 (the product's vel_fp16 inference mode) */
+void orc_set_vel_fp16(int on);
+float orc_f16_round(float x);
 #ifdef __cplusplus
 }
 #endif

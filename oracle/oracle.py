@@ -191,6 +191,18 @@ def set_threads(n):
     lib().orc_set_num_threads(int(n))
 
 
+def set_vel_fp16(on):
+    """velocity-net forward with weights / layer inputs rounded to binary16, fp32 accumulation (checker of the product's vel_fp16 mode)"""
+    lib().orc_set_vel_fp16(int(bool(on)))
+
+
+def f16_round(x):
+    L = lib()
+    L.orc_f16_round.restype = C.c_float
+    L.orc_f16_round.argtypes = [C.c_float]
+    return np.array([L.orc_f16_round(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32).reshape(np.shape(x))
+
+
 def sample_ray(fs, o, d, u=None, **kw):
     f = fs.c_field(**kw)
     o, d = _f32(o), _f32(d)

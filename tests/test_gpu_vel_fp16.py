@@ -1,0 +1,133 @@
+"""Opt-in fp16-input MFMA inference mode of the velocity field (nvfi_field_desc.vel_fp16; the reference's counterpart is its autocast
+switch --disable_fp32, train_nvfi.py:96,144).  Every no-grad back-advection - integrate_pos (tensorf_keyframe.py:575-611, as
+train_segm.py:150-166 uses it), the warp of eval-mode renders, getDenseAlpha - evaluates VelBasis with weights and layer inputs rounded to
+binary16 and fp32 accumulation.  Checked against the oracle switched to the SAME arithmetic (orc.set_vel_fp16), so the comparison is
+digit-level; training renders and gradients must not change at all."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD
+from helpers import assert_contract, make_model, named_grads
+
+
+def test_oracle_f16_round_is_ieee_binary16():
+    from oracle import oracle as orc
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(500).astype(np.float32) * s for s in (1e-8, 1e-6, 1e-4, 1e-2, 1, 100, 70000)]
+                       + [np.array([0, 65504, 65519.9, 65520, 6.1e-5, 5.96e-8, 2.98e-8, 8.9e-8, -1.5, 1 + 2 ** -11, 1 + 3 * 2 ** -11], np.float32)])
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).astype(np.float32)
+    assert np.array_equal(orc.f16_round(x), ref)
+
+
+def test_oracle_fp16_mode_is_a_small_perturbation_of_fp32(fields):
+    """the oracle's fp16 arithmetic switch changes integrate_pos by fp16-sized amounts and is off again afterwards"""
+    from oracle import oracle as orc
+    fs = fields["A"]
+    rng = np.random.default_rng(1)
+    x = (rng.random((512, 3), dtype=np.float32) * 1.6 - 0.8)
+    t = rng.random((512, 1), dtype=np.float32) * 0.7
+    base = np.zeros_like(t)
+    ref = orc.integrate_pos(fs, x, t, base)
+    orc.set_vel_fp16(True)
+    try:
+        h = orc.integrate_pos(fs, x, t, base)
+    finally:
+        orc.set_vel_fp16(False)
+    d = np.abs(h - ref).max()
+    assert 1e-7 < d < 2e-2, d
+    assert np.array_equal(orc.integrate_pos(fs, x, t, base), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["A", "B"])
+def test_gpu_integrate_pos_fp16_matches_the_fp16_oracle(fields, kind):
+    from oracle import oracle as orc
+    model, meta = make_model(kind)
+    f = model.nvfi
+    f.eval()
+    rng = np.random.default_rng(7)
+    N = 3000
+    x = (rng.random((N, 3), dtype=np.float32) * 2.1 - 1.05)            # some points outside the velocity gate / the surround box
+    t = rng.random((N, 1), dtype=np.float32) * float(f.tmax) * 1.3     # up to ~20 RK2 steps, extrapolation included
+    base = np.where(rng.random((N, 1)) < 0.5, 0.0, np.round(t / (float(f.tmax) / (f.num_keyframes - 1))) * (float(f.tmax) / (f.num_keyframes - 1))).astype(np.float32)
+    xg, tg, bg = (torch.from_numpy(a).cuda() for a in (x, t, base))
+    with torch.no_grad():
+        ref32 = f.integrate_pos(xg.clone(), tg.clone(), bg).cpu().numpy()
+        f.vel_fp16 = True
+        got = f.integrate_pos(xg.clone(), tg.clone(), bg).cpu().numpy()
+        f.vel_fp16 = False
+    orc.set_vel_fp16(True)
+    try:
+        ref16 = orc.integrate_pos(fields[kind], x, t, base)
+    finally:
+        orc.set_vel_fp16(False)
+    # same arithmetic: what is left is the fp32 summation order (and a gate decision within rounding of a face: counted, bounded)
+    err = np.abs(got - ref16).max(axis=1)
+    assert np.mean(err > 2e-5) < 2e-3, (np.mean(err > 2e-5), err.max())
+    assert np.median(err) < 2e-6
+    # and it IS a different arithmetic from the fp32 path, by fp16-sized amounts
+    d = np.abs(got - ref32).max(axis=1)
+    assert d.max() > 1e-6 and np.median(d) < 1e-3
+    print(f"[{kind}] fp16 integrate_pos vs fp16 oracle: median {np.median(err):.2e}, max {err.max():.2e}; vs the fp32 path: median {np.median(d):.2e}, max {d.max():.2e}")
+
+
+@pytest.mark.gpu
+def test_gpu_eval_render_fp16_matches_the_fp16_oracle(gold, fields):
+    """eval-mode renders at a non-keyframe and an extrapolated time with the fp16 warp against the oracle in the same arithmetic; a
+    training render with the switch on is bit-identical to the switch off (training stays fp32)"""
+    from oracle import oracle as orc
+    from nvfi_amd.models import Ray, Renderer
+    model, meta = make_model("A")
+    f = model.nvfi
+    ren = Renderer(model, 0, 0, 2048)
+    o, d = gold["A:rays_o"], gold["A:rays_d"]
+    rays = Ray(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), 0, 1)
+    for t in (19.0 / 60.0, 50.0 / 60.0):
+        f.vel_fp16 = True
+        out = ren.render(t, rays, white_background=True, mode="test")
+        f.vel_fp16 = False
+        out32 = ren.render(t, rays, white_background=True, mode="test")
+        orc.set_vel_fp16(True)
+        try:
+            ref = orc.render(fields["A"], o, d, t, train=False, white_bg=True)
+        finally:
+            orc.set_vel_fp16(False)
+        assert_contract(out[0].cpu().numpy(), ref.rgb, "rgb", label=f"fp16 eval t={t:.3f}")
+        assert_contract(out[1].cpu().numpy(), ref.depth, "depth", label=f"fp16 eval t={t:.3f}")
+        assert not torch.equal(out[0], out32[0])          # the switch does something ...
+        assert (out[0] - out32[0]).abs().max() < 2e-2     # ... of fp16 size
+    # training: unaffected
+    torch.manual_seed(3)
+    u = torch.rand(o.shape[0], 1)
+    res = []
+    for sw in (False, True):
+        f.vel_fp16 = sw
+        f.jitter_override = u
+        model.zero_grad(set_to_none=True)
+        out = ren.render(19.0 / 60.0, rays, white_background=True, mode="train")
+        out[0].square().mean().backward()
+        res.append((out[0].detach().clone(), f.vel_net.weight_net[1].weight.grad.detach().clone()))
+    f.vel_fp16 = False
+    f.jitter_override = None
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-9)      # (atomics: order, not arithmetic)
+
+
+@pytest.mark.gpu
+def test_gpu_dense_alpha_fp16_is_close_to_fp32():
+    """getDenseAlpha (60 frame times x G^3 points through the RK2 warp) with the fp16 switch: the occupancy volume moves by fp16-sized amounts"""
+    model, meta = make_model("A")
+    f = model.nvfi
+    f.eval()
+    with torch.no_grad():
+        a32, _ = f.getDenseAlpha((20, 18, 16))
+        f.vel_fp16 = True
+        a16, _ = f.getDenseAlpha((20, 18, 16))
+        f.vel_fp16 = False
+    d = (a32 - a16).abs()
+    assert float(d.max()) < 5e-2 and float(d.mean()) < 1e-3
+    assert float(((a32 > f.alphaMask_thres) != (a16 > f.alphaMask_thres)).float().mean()) < 5e-3
