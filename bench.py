@@ -635,6 +635,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the separate profiled pass (default: min(steps, 5); 0: none)")
     ap.add_argument("--prime", type=int, default=8, help="setup iterations before the W warm-up steps (first-touch of the workspaces, allocator pools of the three streams, clocks): the first ~5 iterations of a process run 5-10 %% slower than steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short extra runs whose results are attached to the default line under `extras` "
+                    "(the reference's loop body verbatim, the radiance-only workload, the opt-in prefilter)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the whole iteration as one captured hipGraph with a device-side time schedule (auto: on for the single-GPU fused driver)")
     args = ap.parse_args()
@@ -835,11 +837,36 @@ def main():
         if ref and "reference" in ref:      # the reference itself (PyTorch CPU) on that same sample, measured in the build container
             out["reference_cpu"] = dict(ref["reference"], host=ref.get("host"), oracle_on_that_host=ref.get("oracle", {}).get("value"),
                                         source=f"profiles/{PROFILE_TAG}_cpu_bridge.json (tools/cpu_bridge.py; /root/reference cannot run on the GPU box)")
+    # Other lines of the same build, measured here so that they are recorded with the headline (each in its own process, same K / W, no
+    # roofline pass); none of them is `value`.
+    default_invocation = (rank == 0 and world == 1 and args.mode == "fused" and args.workload == "cfg3" and not args.live and not args.no_extras
+                          and not os.environ.get("NVFI_BENCH_CHILD") and os.environ.get("NVFI_PDE_PREFILTER", "fp32") == "fp32")
+    if default_invocation:
+        import subprocess
+        def extra(extra_args, env=None):
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
+                   "--profile-steps", "0", "--no-extras", "--rays", str(args.rays), "--pts", str(args.pts), "--grid", str(args.grid),
+                   "--samples", str(args.samples)] + extra_args
+            try:
+                r = subprocess.run(cmd, env=dict(os.environ, NVFI_BENCH_CHILD="1", **(env or {})), stdout=subprocess.PIPE, text=True, timeout=300)
+                ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
+                d = json.loads(ln[-1])
+                return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "launch": d["config"]["launch"].split(" (")[0]}
+            except Exception as e:
+                return {"error": repr(e)}
+        out["extras"] = {
+            "dropin": dict(extra(["--mode", "dropin"]), what="the loop body of the reference's train_nvfi.py:139-249 verbatim on the `models` alias (plain autograd, "
+                           "torch.optim.Adam, reference-signature regularisers, the per-iteration .item() waits): what tools/run_reference_driver.py gets"),
+            "cfg2_radiance_only": dict(extra(["--workload", "cfg2", "--graph", "off"]), what="BASELINE configs[1]: bat.yaml radiance-only, 2048-ray batches, HBM-bound (gathers / scatters)"),
+            "optin_fp16band_prefilter": dict(extra(["--graph", "off"], {"NVFI_PDE_PREFILTER": "fp16band"}),
+                                             what="opt-in (NOT the headline): fp16-input pre-pass of the PDE occupancy prefilter with an fp32 re-evaluation band; "
+                                                  "identical kept set on every test field, no proof"),
+        }
     if graph_line is not None:
         modes = {"hipgraph_replay": {"value": graph_line["value"], "ms_per_step": graph_line["ms_per_step"]},
                  "eager_three_streams": {"value": out["value"], "ms_per_step": out["ms_per_step"]}}
         if graph_line["value"] > out["value"]:      # the child's line carries its own roofline pass; the CPU baseline was measured here
-            for k in ("cpu_baseline", "reference_cpu"):
+            for k in ("cpu_baseline", "reference_cpu", "extras"):
                 if k in out:
                     graph_line[k] = out[k]
             out = graph_line
