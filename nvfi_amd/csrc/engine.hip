@@ -201,6 +201,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_wgrad(WgradJobs jobs) {
     else if (J.a_regs == 16 && J.b_regs == 32) wgrad_worker<1, 2, BM_RAW>(J, worker, lane);
 }
 
+#ifndef REDUCE_BLOCKS
+#define REDUCE_BLOCKS 260
+#endif
 // 64 G entries per workgroup; 4 threads per entry each sum a quarter of the slabs
 __global__ __launch_bounds__(256) void k_wgrad_reduce(ReduceJobs jobs) {
     __shared__ float part[4][64];
@@ -264,7 +267,7 @@ int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st) {
     if (ring) {
         ProfScope ps(PK_WGRAD, st);
         if (launch_wgrad_ring(bj, br, st)) return 1;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3(260, br.n), dim3(256), 0, st, br);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(REDUCE_BLOCKS, br.n), dim3(256), 0, st, br);
         LAUNCHCK();
         return 0;
     }
@@ -296,7 +299,7 @@ int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st) {
     }
     ProfScope ps(PK_WGRAD, st);
     hipLaunchKernelGGL(k_wgrad, dim3((nworkers + 3) / 4, bj.n), dim3(WG_THREADS), 0, st, bj);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(260, br.n), dim3(256), 0, st, br);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(REDUCE_BLOCKS, br.n), dim3(256), 0, st, br);
     LAUNCHCK();
     return 0;
 }
