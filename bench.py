@@ -711,13 +711,16 @@ def main():
         # a child process: a fault inside a graph replay (a runtime bug, see above) kills the process and cannot be caught.
         import subprocess
         child_args = [a for a in sys.argv[1:] if a != "--no-cpu-baseline"] + ["--graph", "on", "--no-cpu-baseline"]
-        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + child_args, env=dict(os.environ, NVFI_BENCH_CHILD="1"),
-                           stdout=subprocess.PIPE, text=True)
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if r.returncode == 0 and lines:
-            graph_line = json.loads(lines[-1])
-        else:
-            print(f"bench.py: the hipGraph run failed (exit code {r.returncode}); measuring the eager step only", file=sys.stderr)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + child_args, env=dict(os.environ, NVFI_BENCH_CHILD="1"),
+                               stdout=subprocess.PIPE, text=True, timeout=900)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                graph_line = json.loads(lines[-1])
+            else:
+                print(f"bench.py: the hipGraph run failed (exit code {r.returncode}); measuring the eager step only", file=sys.stderr)
+        except subprocess.TimeoutExpired:
+            print("bench.py: the hipGraph run did not finish in 900 s; measuring the eager step only", file=sys.stderr)
         args.graph = "off"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
