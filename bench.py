@@ -827,7 +827,7 @@ def main():
         flops = {"rk2_fwd": E * VEL_FLOP, "rk2_bwd": E * VEL_FLOP, "app_fwd": M * APP_FLOP, "app_bwd": M * APP_FLOP,
                  "wgrad": E * VEL_FLOP + M * APP_FLOP + kept * 6 * VEL_FLOP, "pde_fwd": kept * 6 * VEL_FLOP,
                  "pde_bwd": kept * 6 * VEL_FLOP, "pde_prefilter": pre_evals * VEL_FLOP}
-        if pre_mode == "fp16band":      # opt-in: the class is an fp16-input pass + a short fp32 list; no fp32-MFMA figure applies to it
+        if pre_mode in ("fp16band", "split16band"):      # opt-in: the class is an fp16-MFMA pass + a short fp32 list; no fp32-MFMA figure applies to it
             del flops["pde_prefilter"]
         times = {CLASSES[i]: (tot[i], cnt[i]) for i in range(min(ncls, len(CLASSES)))}
         # per step: what the kernels counted (V valid samples, N samples warped by RK2, M appearance-masked samples, E velocity-net
@@ -869,7 +869,9 @@ def main():
         "metric": "training rays/sec (fwd+bwd incl. PDE loss), 'bat' scene", "value": value, "unit": "rays/s",
         "n_gpus": world, "process_group": comm_info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32" if os.environ.get("NVFI_PDE_PREFILTER", "fp32") != "fp16band" else "f32 (opt-in: fp16-input pre-pass of the PDE occupancy prefilter, fp32 re-evaluation band)",
+        "dtype": {"fp16band": "f32 (opt-in: fp16-input pre-pass of the PDE occupancy prefilter, fp32 re-evaluation band)",
+                  "split16band": "f32 (opt-in: PDE occupancy prefilter with fp32 products emulated by two binary16 terms per operand on the fp16 MFMA, fp32 re-evaluation band)"
+                  }.get(os.environ.get("NVFI_PDE_PREFILTER", "fp32"), "f32"),
         "data": "synthetic",
         "config": {"workload": ("bat.yaml + velocity field + PDE divergence loss (configs[2]): 199^3 grid, K=16, 128 samples/ray, "
                                 "2 renders x 2048 rays + PDE on 262144 collocation points + plane regularisers + Adam, per GPU"
@@ -916,6 +918,10 @@ def main():
             "dropin": dict(extra(["--mode", "dropin"]), what="the loop body of the reference's train_nvfi.py:139-249 verbatim on the `models` alias (plain autograd, "
                            "torch.optim.Adam, reference-signature regularisers, the per-iteration .item() waits): what tools/run_reference_driver.py gets"),
             "cfg2_radiance_only": dict(extra(["--workload", "cfg2", "--graph", "off"]), what="BASELINE configs[1]: bat.yaml radiance-only, 2048-ray batches, HBM-bound (gathers / scatters)"),
+            "optin_split16band_prefilter": dict(extra(["--graph", "off"], {"NVFI_PDE_PREFILTER": "split16band"}),
+                                                what="opt-in (NOT the headline): the PDE occupancy prefilter with fp32 products emulated on the fp16 matrix pipe (two binary16 "
+                                                     "terms per operand, three MFMAs, fp32 accumulation: ~2^-21 relative per product) + an fp32 re-evaluation band of 0.1 %; "
+                                                     "identical kept set on every test field"),
             "optin_fp16band_prefilter": dict(extra(["--graph", "off"], {"NVFI_PDE_PREFILTER": "fp16band"}),
                                              what="opt-in (NOT the headline): fp16-input pre-pass of the PDE occupancy prefilter with an fp32 re-evaluation band; "
                                                   "identical kept set on every test field, no proof"),

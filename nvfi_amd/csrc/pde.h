@@ -80,6 +80,7 @@ int pack_vel_x4_fwd(const VelFrags& W, float* buf, const float4** f4, hipStream_
 struct Pre16Args {
     nvfi_field_desc f;
     void* img;                     // PRE16_IMAGE_BYTES of workspace
+    void* img_lo;                  // split mode (split16band): PRE16_IMAGE_BYTES more for the second binary16 term of the weights; NULL otherwise
     int64_t P; const int* list;    // bucket order -> point index
     const float4* xw; float4* xout; uint8_t* near;
     const float* pt_t; const float* pt_base; float dt_max; int max_steps; float eps_gate;

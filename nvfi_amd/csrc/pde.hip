@@ -568,7 +568,7 @@ struct PdePlan {
     int *cls, *rank, *cls_count, *perm, *cnt, *off, *klist, *kcount, *dcount;
     uint8_t* flags;
     float* sig;     // density at the warped points (prefilter)
-    float4* xw16; uint8_t* near; int* blist; int* bcount; void* img16;   // fp16 pre-pass (pre16.hip)
+    float4* xw16; uint8_t* near; int* blist; int* bcount; void* img16; void* img16lo;   // fp16 pre-pass (pre16.hip)
     double* sums;
     float *vel_frag, *a_frag, *vel_x4, *stash, *seeds, *wout, *slabs;
     int64_t chunk, total;
@@ -585,6 +585,7 @@ static void plan_pde(int64_t P, void* ws, PdePlan* L) {
     L->sums = B.take<double>(4);
     L->xw16 = B.take<float4>(P); L->near = B.take<uint8_t>(nw * 64); L->blist = B.take<int>(P); L->bcount = L->cls_count + PDE_MAX_CLASS + 1;
     L->img16 = B.take<float4>(PRE16_IMAGE_BYTES / 16);
+    L->img16lo = B.take<float4>(PRE16_IMAGE_BYTES / 16);
     L->dcount = B.take<int>(16);
     L->vel_frag = B.take<float>(VEL_FRAG_FLOATS); L->a_frag = B.take<float>(VEL_FRAG_FLOATS);
     L->vel_x4 = B.take<float>(VEL_X4_FLOATS);
@@ -651,12 +652,15 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     if (use_jet < 0) { const char* e = getenv("NVFI_PDE_JET"); use_jet = e ? atoi(e) : 1; }
     // prefilter mode: fp32 (default: the feature-split kernel of vel_split.hip) | engine32 (k_rk2_fwd of vel.hip: the same numbers bit for
     // bit, ~4 % slower) | fp16band (pre16.hip: fp16-input pass + fp32 re-evaluation of the unsafe points)
+    // split16band (opt-in, pre16.hip): the pre-pass with fp32 products emulated by two binary16 terms per operand (three fp16 MFMAs), and a
+    // band 100 x narrower than fp16band's in front of the same fp32 re-evaluation
     static int pre16 = -1; static float band16 = 0.1f, eps16 = 2e-3f;
     if (pre16 < 0) {
         const char* e = getenv("NVFI_PDE_PREFILTER");
-        if (e && strcmp(e, "fp16band") && strcmp(e, "fp32") && strcmp(e, "split32") && strcmp(e, "engine32"))
-            return nvfi_fail(2, "NVFI_PDE_PREFILTER must be fp32, engine32 or fp16band");
-        pre16 = !e ? 2 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "engine32") ? 0 : 2));      // 2 = split kernel ("split32" = "fp32")
+        if (e && strcmp(e, "fp16band") && strcmp(e, "split16band") && strcmp(e, "fp32") && strcmp(e, "split32") && strcmp(e, "engine32"))
+            return nvfi_fail(2, "NVFI_PDE_PREFILTER must be fp32, engine32, fp16band or split16band");
+        pre16 = !e ? 2 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "split16band") ? 3 : (!strcmp(e, "engine32") ? 0 : 2)));      // 2 = split kernel ("split32" = "fp32")
+        if (pre16 == 3) { band16 = 1e-3f; eps16 = 2e-5f; }
         if ((e = getenv("NVFI_PDE_BAND"))) band16 = (float)atof(e);
         if ((e = getenv("NVFI_PDE_GATE_EPS"))) eps16 = (float)atof(e);
     }
@@ -704,7 +708,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     } else {
         // opt-in (pre16.hip): fp16-input pass over every candidate, then the fp32 kernel for the points whose decision is not safe
         Pre16Args qa; memset(&qa, 0, sizeof(qa));
-        qa.f = *f; qa.img = L.img16; qa.P = P; qa.list = L.perm; qa.xw = L.xw; qa.xout = L.xw16; qa.near = L.near;
+        qa.f = *f; qa.img = L.img16; qa.img_lo = pre16 == 3 ? L.img16lo : nullptr; qa.P = P; qa.list = L.perm; qa.xw = L.xw; qa.xout = L.xw16; qa.near = L.near;
         qa.pt_t = L.pt_t_perm; qa.pt_base = L.pt_base_perm; qa.dt_max = ra.dt_max; qa.max_steps = PDE_MAX_CLASS; qa.eps_gate = eps16;
         if (launch_pre16(f, qa, st)) return 1;
         da.n_direct = P; da.xw = L.xw16;
@@ -773,7 +777,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, L.kcount, out);
     LAUNCHCK();
     if (counters) {
-        hipLaunchKernelGGL(k_pde_counters, dim3(1), dim3(64), 0, st, L.cls_count, L.kcount, P, pre16 == 1, counters);
+        hipLaunchKernelGGL(k_pde_counters, dim3(1), dim3(64), 0, st, L.cls_count, L.kcount, P, pre16 == 1 || pre16 == 3, counters);
         LAUNCHCK();
     }
     return 0;

@@ -22,6 +22,7 @@
 #include "engine16.h"
 
 #define P16_THREADS 512
+#define SPLIT_SCALE 2048.f                           // split mode: the second binary16 term of an operand is stored x 2^11
 #define P16_L0 0                                   // 4 tiles x 2 K-steps x 64 lanes (h8 units)
 #define P16_LH(l) (512 + ((l) - 1) * 2048)          // l = 1..4: 4 x 8 x 64
 #define P16_L5 (512 + 4 * 2048)                     // 1 x 8 x 64
@@ -29,7 +30,7 @@
 static_assert(P16_H8 * 16 + 6 * 128 * 4 == PRE16_IMAGE_BYTES, "image size");
 
 // ---------------------------------------------------------------- packing: the LDS image, built in global memory once per call
-struct Pack16VelArgs { const float* W[6]; const float* b[6]; h8_t* img; };
+struct Pack16VelArgs { const float* W[6]; const float* b[6]; h8_t* img; h8_t* img_lo; };
 __global__ __launch_bounds__(256) void k_pack_vel16(Pack16VelArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < P16_H8) {
@@ -40,15 +41,17 @@ __global__ __launch_bounds__(256) void k_pack_vel16(Pack16VelArgs a) {
         const int lane = local & 63, ms = local >> 6, s = ms % NS, m = ms / NS;
         const int row = 32 * m + (lane & 31), h = lane >> 5;
         const float* W = a.W[l];
-        h8_t v;
+        h8_t v, vlo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int feat = slot_logical(kind, 2 * (8 * s + j) + h);     // register 8s + j of lane half h (engine.h)
             float w = 0.f;
             if (row < out && feat >= 0 && feat < in) w = W[(size_t)row * in + feat];
             v[j] = (_Float16)w;
+            vlo[j] = (_Float16)((w - (float)v[j]) * SPLIT_SCALE);           // second binary16 term of the weight (split mode)
         }
         a.img[idx] = v;
+        if (a.img_lo) a.img_lo[idx] = vlo;
     }
     if (idx < 6 * 128) {
         const int l = idx >> 7, row = idx & 127;
@@ -58,49 +61,87 @@ __global__ __launch_bounds__(256) void k_pack_vel16(Pack16VelArgs a) {
 }
 
 // ---------------------------------------------------------------- one layer: MT output tiles, NS K-steps; the epilogue of tile
-// m - 1 is issued behind the MFMAs of tile m (independent work for the scheduler, as in engine.h's layer_tiles)
-template <int MT, int NS, class Epi>
-__device__ __forceinline__ void layer16p(const h8_t* w, const float* bias, int lane, int h, const h8_t* B, Epi epi) {
+// m - 1 is issued behind the MFMAs of tile m (independent work for the scheduler, as in engine.h's layer_tiles).
+//
+// SPLIT (NVFI_PDE_PREFILTER=split16band): fp32 products emulated on the fp16 matrix pipe with TWO binary16 terms per operand,
+//   x = xh + xl / 2048,  w = wh + wl / 2048   (xh = rn16(x), xl = rn16((x - xh) 2048): |x - xh - xl/2048| <= 2^-22 |x|, likewise w)
+//   w x  ~  wh xh + (wh xl + wl xh) / 2048     - three MFMAs; the dropped wl xl term and the two representation errors are each <= 2^-22 |w x|,
+// accumulated in fp32 like the fp32 MFMA accumulates its exact products: a relative error of ~2^-21 per product against the 2^-24 of one fp32
+// rounding, i.e. the same order as the difference between two fp32 summation orders.  The hi fragments live in LDS as before; the lo
+// fragments (a second 147 KB image) are read from L2 one row tile ahead (16 bytes per lane and MFMA: ~14 B / clk / CU).  Measured with the
+// split arithmetic in place: 0.54 ms for the 1.0e6 evaluations of the prefilter against 0.305 ms for the one-term kernel and 1.31 ms for fp32 MFMA.
+template <int MT, int NS, bool SPLIT, class Epi>
+__device__ __forceinline__ void layer16p(const h8_t* w, const h8_t* __restrict__ wlo, const float* bias, int lane, int h, const h8_t* B, Epi epi) {
     f32x16 prev;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         f32x16 acc;
+        h8_t L[SPLIT ? NS : 1];
+        if (SPLIT) {
+            __builtin_amdgcn_sched_barrier(0);      // the lo fragments of ONE row tile in flight (hoisted over the four tiles they cost 128 registers and spill)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) L[s] = wlo[(m * NS + s) * 64 + lane];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bias[32 * m + (r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc = MFMA16(w[(m * NS + s) * 64 + lane], B[s], acc);
+        if (SPLIT) {
+            f32x16 lo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lo[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) lo = MFMA16(w[(m * NS + s) * 64 + lane], B[NS + s], lo);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) lo = MFMA16(L[s], B[s], lo);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(lo[r], 1.f / SPLIT_SCALE, acc[r]);
+        }
+        if (SPLIT) { epi(m, acc); __builtin_amdgcn_sched_barrier(0); continue; }   // (no deferred epilogue: its 16 registers are needed)
         if (m > 0) epi(m - 1, prev);
         prev = acc;
     }
-    epi(MT - 1, prev);
+    if (!SPLIT) epi(MT - 1, prev);
+}
+// one activation value -> its place in the B operands of the NEXT layer: register g (= 16 m + r of the D layout) is element g & 7 of K step
+// g >> 3; split mode stores the second binary16 term NS K-steps further on
+template <int NS, bool SPLIT>
+__device__ __forceinline__ void put_h8(h8_t* B, int g, float v) {
+    const _Float16 hi = (_Float16)v;
+    B[g >> 3][g & 7] = hi;
+    if (SPLIT) B[NS + (g >> 3)][g & 7] = (_Float16)((v - (float)hi) * SPLIT_SCALE);
 }
 
-// gated VelBasis.get_vel weights (velocity_field.py:77-93) of the wave's 32 points; out4 as velnet_forward (engine.h)
-__device__ __forceinline__ void velnet16(const h8_t* W, const float* bias, int lane, int h, const float4& q, float* out4) {
-    float xa[64], xb[64];
-    h8_t B[8];
-    vel_encode_slots(q, h, xb);
-    to_h8<2>(xb, B);
-    layer16p<4, 2>(W + P16_L0, bias, lane, h, B, [&](int m, const f32x16& acc) {
+// gated VelBasis.get_vel weights (velocity_field.py:77-93) of the wave's 32 points; out4 as velnet_forward (engine.h).
+// The activations live ONLY as MFMA operands: the epilogue of a layer writes act(z) straight into the (hi [, lo]) binary16 operand registers
+// of the next layer - two operand sets alternate, no fp32 activation array exists (the split mode needs its registers for the second terms).
+template <bool SPLIT = false>
+__device__ __forceinline__ void velnet16(const h8_t* W, const h8_t* Wlo, const float* bias, int lane, int h, const float4& q, float* out4) {
+    constexpr int NB = SPLIT ? 16 : 8;
+    h8_t Ba[NB], Bb[NB];
+    {
+        float x0[16];
+        vel_encode_slots(q, h, x0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xa[16 * m + r] = act_f<1>(acc[r]);
+        for (int g = 0; g < 16; ++g) put_h8<2, SPLIT>(Ba, g, x0[g]);
+    }
+    layer16p<4, 2, SPLIT>(W + P16_L0, Wlo + P16_L0, bias, lane, h, Ba, [&](int m, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) put_h8<8, SPLIT>(Bb, 16 * m + r, act_f<1>(acc[r]));
     });
 #pragma unroll 1
     for (int it = 0; it < 2; ++it) {
         const int l = 1 + 2 * it;
-        to_h8<8>(xa, B);
-        layer16p<4, 8>(W + P16_LH(l), bias + 128 * l, lane, h, B, [&](int m, const f32x16& acc) {
+        layer16p<4, 8, SPLIT>(W + P16_LH(l), Wlo + P16_LH(l), bias + 128 * l, lane, h, Bb, [&](int m, const f32x16& acc) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xb[16 * m + r] = act_f<1>(acc[r]);
+            for (int r = 0; r < 16; ++r) put_h8<8, SPLIT>(Ba, 16 * m + r, act_f<1>(acc[r]));
         });
-        to_h8<8>(xb, B);
-        layer16p<4, 8>(W + P16_LH(l + 1), bias + 128 * (l + 1), lane, h, B, [&](int m, const f32x16& acc) {
+        layer16p<4, 8, SPLIT>(W + P16_LH(l + 1), Wlo + P16_LH(l + 1), bias + 128 * (l + 1), lane, h, Ba, [&](int m, const f32x16& acc) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xa[16 * m + r] = act_f<1>(acc[r]);
+            for (int r = 0; r < 16; ++r) put_h8<8, SPLIT>(Bb, 16 * m + r, act_f<1>(acc[r]));
         });
     }
-    to_h8<8>(xa, B);
-    layer16p<1, 8>(W + P16_L5, bias + 128 * 5, lane, h, B, [&](int, const f32x16& acc) {
+    layer16p<1, 8, SPLIT>(W + P16_L5, Wlo + P16_L5, bias + 128 * 5, lane, h, Bb, [&](int, const f32x16& acc) {
         out4[0] = acc[0]; out4[1] = acc[1]; out4[2] = acc[2]; out4[3] = acc[3];
     });
 }
@@ -111,6 +152,7 @@ __device__ __forceinline__ bool near_gate(const nvfi_field_desc& f, float eps, f
 }
 
 // same recurrence as k_rk2_fwd<false, false> (vel.hip), per wave instead of per workgroup
+template <bool SPLIT>
 __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_pre16(Pre16Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
@@ -120,6 +162,7 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_pre16(Pre16Args a) {
     }
     __syncthreads();
     const h8_t* W = reinterpret_cast<const h8_t*>(lds);
+    const h8_t* Wlo = reinterpret_cast<const h8_t*>(a.img_lo);
     const float* bias = lds + P16_H8 * 4;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * (P16_THREADS / 64) + (threadIdx.x >> 6);
@@ -139,13 +182,13 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_pre16(Pre16Args a) {
         const float m = fminf(fabsf(off), a.dt_max);
         const float dt = off > 0.f ? m : (off < 0.f ? -m : 0.f);
         float o4[4], w1[6], w2[6], v1[3], v2[3];
-        velnet16(W, bias, lane, h, make_float4(x, y, z, tcur), o4);
+        velnet16<SPLIT>(W, Wlo, bias, lane, h, make_float4(x, y, z, tcur), o4);
         gather6(o4, h, w1);
         vel_from_w(w1, x, y, z, v1);
         if (gated_out(a.f, x, y, z)) { v1[0] = v1[1] = v1[2] = 0.f; }
         const float hdt = 0.5f * dt;
         const float px = x - hdt * v1[0], py = y - hdt * v1[1], pz = z - hdt * v1[2];
-        velnet16(W, bias, lane, h, make_float4(px, py, pz, tcur - hdt), o4);
+        velnet16<SPLIT>(W, Wlo, bias, lane, h, make_float4(px, py, pz, tcur - hdt), o4);
         gather6(o4, h, w2);
         vel_from_w(w2, px, py, pz, v2);
         if (gated_out(a.f, px, py, pz)) { v2[0] = v2[1] = v2[2] = 0.f; }
@@ -208,13 +251,13 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_inf16(Rk16Args a) {
             dt = off > 0.f ? m : (off < 0.f ? -m : 0.f);
         }
         float o4[4], w1[6], w2[6], v1[3], v2[3];
-        velnet16(W, bias, lane, h, make_float4(x, y, z, tcur), o4);
+        velnet16<false>(W, nullptr, bias, lane, h, make_float4(x, y, z, tcur), o4);
         gather6(o4, h, w1);
         vel_from_w(w1, x, y, z, v1);
         if (gated_out(a.f, x, y, z)) { v1[0] = v1[1] = v1[2] = 0.f; }
         const float hdt = 0.5f * dt;
         const float px = x - hdt * v1[0], py = y - hdt * v1[1], pz = z - hdt * v1[2];
-        velnet16(W, bias, lane, h, make_float4(px, py, pz, tcur - hdt), o4);
+        velnet16<false>(W, nullptr, bias, lane, h, make_float4(px, py, pz, tcur - hdt), o4);
         gather6(o4, h, w2);
         vel_from_w(w2, px, py, pz, v2);
         if (gated_out(a.f, px, py, pz)) { v2[0] = v2[1] = v2[2] = 0.f; }
@@ -242,6 +285,7 @@ int launch_rk2_inf16(const nvfi_field_desc* f, Rk16Args a, bool uniform, hipStre
     Pack16VelArgs pk;
     for (int l = 0; l < 6; ++l) { pk.W[l] = f->vW[l]; pk.b[l] = f->vb[l]; }
     pk.img = reinterpret_cast<h8_t*>(a.img);
+    pk.img_lo = nullptr;
     hipLaunchKernelGGL(k_pack_vel16, dim3((P16_H8 + 255) / 256), dim3(256), 0, st, pk);
     a.f = *f;
     const int64_t tiles = (a.P + TILE - 1) / TILE;
@@ -272,18 +316,21 @@ __global__ __launch_bounds__(256) void k_pde_band(nvfi_field_desc f, int64_t P, 
 int launch_pre16(const nvfi_field_desc* f, Pre16Args a, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        HIPCK(hipFuncSetAttribute((const void*)k_rk2_pre16, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_pre16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_pre16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
         attr = true;
     }
     Pack16VelArgs pk;
     for (int l = 0; l < 6; ++l) { pk.W[l] = f->vW[l]; pk.b[l] = f->vb[l]; }
     pk.img = reinterpret_cast<h8_t*>(a.img);
+    pk.img_lo = reinterpret_cast<h8_t*>(a.img_lo);
     hipLaunchKernelGGL(k_pack_vel16, dim3((P16_H8 + 255) / 256), dim3(256), 0, st, pk);
     const int64_t tiles = (a.P + TILE - 1) / TILE;
     const unsigned wgs = (unsigned)((tiles + P16_THREADS / 64 - 1) / (P16_THREADS / 64));
     {
         ProfScope ps(PK_PDE_PREFILTER, st);
-        hipLaunchKernelGGL(k_rk2_pre16, dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+        if (a.img_lo) hipLaunchKernelGGL(k_rk2_pre16<true>, dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+        else hipLaunchKernelGGL(k_rk2_pre16<false>, dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
     }
     LAUNCHCK();
     return 0;

@@ -20,6 +20,7 @@ python $REPO/bench.py --no-extras --workload cfg2 --no-cpu-baseline > $OUT/${TAG
 NVFI_WGRAD=engine python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_wgrad_engine.json 2>/dev/null
 # other kernel selections: opt-in fp16-input pre-pass with the fp32 band; the engine kernels of vel.hip instead of vel_split.hip
 NVFI_PDE_PREFILTER=fp16band python $REPO/bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_line_fp16band.json 2>/dev/null
+NVFI_PDE_PREFILTER=split16band python $REPO/bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_line_split16band.json 2>/dev/null
 NVFI_PDE_PREFILTER=engine32 NVFI_RK2_SPLIT=0 NVFI_RK2_SPLIT_BWD=0 python $REPO/bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_line_engine32.json 2>/dev/null
 NVFI_BENCH_CHILD=1 rocprofv3 --kernel-trace -d /tmp/prof_k16 -- env NVFI_PDE_PREFILTER=fp16band python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > /dev/null 2>&1
 python $REPO/tools/rocpd_stats.py $(find /tmp/prof_k16 -name "*.db" | head -1) $OUT/${TAG}_kernel_stats_fp16band.csv --after-marker > /dev/null
