@@ -34,7 +34,8 @@ typedef struct nvfi_field_desc {
     int32_t gate_sur;        /* 0 VelocityAABB(eps), 1 VelocityAABBSur (velocity_field.py:21-51) */
     int32_t has_amask;       /* alphaMask present (used in eval only, tensorf_keyframe.py:656) */
     int32_t shading;         /* shadingMode (tensorf_base.py:184-197): 0 MLP_PE (app_dim 32 + MLPRender_PE), 1 SH (app_dim 27, SHRender: no MLP) */
-    int32_t vel_fp16;        /* ABI v4, opt-in (0 = off, the default and the parity mode): 1 = every NO-GRAD back-advection (nvfi_integrate_pos,
+    int32_t vel_fp16;        /* ABI v4, opt-in (0 = off, the default and the parity mode; 2 = as 1 but with fp32 products emulated by TWO binary16
+                              * terms per operand, three MFMAs, ~2^-21 relative per product): 1 = every NO-GRAD back-advection (nvfi_integrate_pos,
                               * the warp of eval-mode renders, nvfi_compute_alpha) evaluates VelBasis with fp16-input MFMAs (weights and layer
                               * inputs rounded to binary16, fp32 accumulation) - the counterpart of the reference's autocast switch
                               * --disable_fp32 (train_nvfi.py:96,144) for inference; training renders, the PDE term and all gradients stay fp32 */

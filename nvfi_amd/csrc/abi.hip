@@ -62,7 +62,7 @@ extern "C" int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const flo
     }
     hipLaunchKernelGGL(k_pack_xt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, x, xw);
     if (f->vel_fp16) {      // opt-in fp16-input inference mode (pre16.hip): the fragment region of the workspace holds the fp16 image
-        static_assert(VEL_FRAG_FLOATS * 4 >= PRE16_IMAGE_BYTES, "fragment region holds the fp16 image");
+        static_assert(VEL_FRAG_FLOATS * 4 >= 2 * PRE16_IMAGE_BYTES, "fragment region holds the fp16 images (hi + lo)");
         Rk16Args h; memset(&h, 0, sizeof(h));
         h.img = fv; h.P = N; h.xw = xw; h.xout3 = xk; h.pt_t = t; h.pt_base = base; h.dt_max = dt_max_of(*f); h.max_steps = 4096;
         return launch_rk2_inf16(f, h, false, st);

@@ -90,7 +90,8 @@ int launch_pre16(const nvfi_field_desc* f, Pre16Args a, hipStream_t st);
 // compact -> dense map; per-point mode reads pt_t / pt_base at the compact index, uniform mode the step schedule (by value or `sched`)
 struct Rk16Args {
     nvfi_field_desc f;
-    void* img;                     // PRE16_IMAGE_BYTES of workspace
+    void* img;                     // 2 x PRE16_IMAGE_BYTES of workspace (the second half holds the lo image of the split mode, vel_fp16 = 2)
+    void* img_lo;                  // set by the launcher
     int64_t P; const int* count; const int* list;
     const float4* xw; float4* xout; float* xout3;
     const float* pt_t; const float* pt_base; float dt_max; int max_steps;

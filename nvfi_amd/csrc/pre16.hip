@@ -215,7 +215,7 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_pre16(Pre16Args a) {
 // as the prefilter pre-pass above, with the two time modes of k_rk2_fwd: per-point (t, base) or a uniform step schedule.
 // Training renders, the PDE regulariser and every gradient stay fp32.  tests/test_gpu_vel_fp16.py checks it against a CPU restatement
 // in the same arithmetic (binary16-rounded operands, fp32 accumulation).
-template <bool UNI>
+template <bool UNI, bool SPLIT>
 __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_inf16(Rk16Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_inf16(Rk16Args a) {
     }
     __syncthreads();
     const h8_t* W = reinterpret_cast<const h8_t*>(lds);
+    const h8_t* Wlo = reinterpret_cast<const h8_t*>(a.img_lo);
     const float* bias = lds + P16_H8 * 4;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     int64_t P = a.P;
@@ -251,13 +252,13 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_inf16(Rk16Args a) {
             dt = off > 0.f ? m : (off < 0.f ? -m : 0.f);
         }
         float o4[4], w1[6], w2[6], v1[3], v2[3];
-        velnet16<false>(W, nullptr, bias, lane, h, make_float4(x, y, z, tcur), o4);
+        velnet16<SPLIT>(W, Wlo, bias, lane, h, make_float4(x, y, z, tcur), o4);
         gather6(o4, h, w1);
         vel_from_w(w1, x, y, z, v1);
         if (gated_out(a.f, x, y, z)) { v1[0] = v1[1] = v1[2] = 0.f; }
         const float hdt = 0.5f * dt;
         const float px = x - hdt * v1[0], py = y - hdt * v1[1], pz = z - hdt * v1[2];
-        velnet16<false>(W, nullptr, bias, lane, h, make_float4(px, py, pz, tcur - hdt), o4);
+        velnet16<SPLIT>(W, Wlo, bias, lane, h, make_float4(px, py, pz, tcur - hdt), o4);
         gather6(o4, h, w2);
         vel_from_w(w2, px, py, pz, v2);
         if (gated_out(a.f, px, py, pz)) { v2[0] = v2[1] = v2[2] = 0.f; }
@@ -277,22 +278,31 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_inf16(Rk16Args a) {
 int launch_rk2_inf16(const nvfi_field_desc* f, Rk16Args a, bool uniform, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
-        HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
         attr = true;
     }
     if (a.P <= 0) return 0;
+    const bool split = f->vel_fp16 == 2;      // two binary16 terms per operand (fp32 products emulated): the lo image follows the hi image
+    a.img_lo = split ? (char*)a.img + PRE16_IMAGE_BYTES : nullptr;
     Pack16VelArgs pk;
     for (int l = 0; l < 6; ++l) { pk.W[l] = f->vW[l]; pk.b[l] = f->vb[l]; }
     pk.img = reinterpret_cast<h8_t*>(a.img);
-    pk.img_lo = nullptr;
+    pk.img_lo = reinterpret_cast<h8_t*>(a.img_lo);
     hipLaunchKernelGGL(k_pack_vel16, dim3((P16_H8 + 255) / 256), dim3(256), 0, st, pk);
     a.f = *f;
     const int64_t tiles = (a.P + TILE - 1) / TILE;
     const unsigned wgs = (unsigned)((tiles + P16_THREADS / 64 - 1) / (P16_THREADS / 64));
     ProfScope ps(PK_RK2_FWD, st);
-    if (uniform) hipLaunchKernelGGL(k_rk2_inf16<true>, dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
-    else hipLaunchKernelGGL(k_rk2_inf16<false>, dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+    if (uniform) {
+        if (split) hipLaunchKernelGGL((k_rk2_inf16<true, true>), dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+        else hipLaunchKernelGGL((k_rk2_inf16<true, false>), dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+    } else {
+        if (split) hipLaunchKernelGGL((k_rk2_inf16<false, true>), dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+        else hipLaunchKernelGGL((k_rk2_inf16<false, false>), dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+    }
     LAUNCHCK();
     return 0;
 }

@@ -1055,7 +1055,7 @@ struct RenderPlan {
     uint8_t *valid, *mflag, *rflag;
     float4 *xw, *rgbs, *rgb_pre, *gxw, *gxk;
     float *xpre, *gxpre;
-    float *vel_frag, *render_frag, *vel_x4, *vel_x4b;
+    float *vel_frag, *render_frag, *vel_x4, *vel_x4b; void* img16;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     float *slabs;
     long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
@@ -1086,6 +1086,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->xpre = B.take<float>(N);
     P->vel_frag = B.take<float>(VEL_FRAG_FLOATS);
     P->vel_x4 = nsteps > 0 ? B.take<float>(VEL_X4F_FLOATS) : nullptr;
+    P->img16 = (nsteps > 0 && !train && f->vel_fp16) ? (void*)B.take<float4>(2 * PRE16_IMAGE_BYTES / 16) : nullptr;   // fp16 inference images (hi, lo)
     P->vel_x4b = (nsteps > 0 && train) ? B.take<float>(VEL_X4B_FLOATS) : nullptr;
     P->render_frag = B.take<float>(RENDER_FRAG_FLOATS);
     P->maskv = (flags & NVFI_WANT_MASK) ? B.take<float>(N * 32) : nullptr;
@@ -1206,9 +1207,8 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
         if (split < 0) { const char* e = getenv("NVFI_RK2_SPLIT"); split = e ? atoi(e) : 1; }
         if (f->vel_fp16 && !train) {
             // opt-in fp16-input inference mode (pre16.hip): eval-mode renders only; the x4 fragment region holds the fp16 image
-            static_assert(VEL_X4F_FLOATS * 4 >= PRE16_IMAGE_BYTES, "x4 fragment region holds the fp16 image");
             Rk16Args h; memset(&h, 0, sizeof(h));
-            h.img = P.vel_x4; h.P = N; h.count = P.counters + 3; h.list = P.rlist; h.xw = P.xw; h.xout = P.xw; h.nsteps = nsteps; h.sched = sched;
+            h.img = P.img16; h.P = N; h.count = P.counters + 3; h.list = P.rlist; h.xw = P.xw; h.xout = P.xw; h.nsteps = nsteps; h.sched = sched;
             for (int s = 0; s < nsteps; ++s) { h.dt[s] = dts[s]; h.tcur[s] = tcs[s]; }
             if (launch_rk2_inf16(f, h, true, st)) return 1;
         } else if (split) {

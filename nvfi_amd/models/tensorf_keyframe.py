@@ -360,7 +360,8 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         # opt-in (not a reference attribute; the reference's counterpart is autocast via --disable_fp32, train_nvfi.py:96,144): every no-grad
         # back-advection - integrate_pos, the warp of eval-mode renders, getDenseAlpha - on the fp16-input MFMA (nvfi_field_desc.vel_fp16).
         # Training renders, the PDE term and all gradients stay fp32 whatever this says.
-        self.vel_fp16 = os.environ.get("NVFI_VEL_FP16", "0") == "1"
+        # True / 1: one binary16 term per MFMA operand; 2 / "split": two terms (fp32 products emulated, ~2^-21 relative per product, 2.4x fp32 speed)
+        self.vel_fp16 = {"0": False, "1": True, "2": 2, "split": 2}.get(os.environ.get("NVFI_VEL_FP16", "0"), False)
         self.register_load_state_dict_post_hook(lambda m, k: m.update_stepSize(m.gridSize.tolist()))
 
     # ------------------------------------------------------------------ construction
@@ -496,7 +497,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         d.K = int(self.num_keyframes)
         d.Cd, d.Ca, d.app_dim = int(self.density_n_comp[0]), int(self.app_n_comp[0]), int(self.app_dim)
         d.shading = 1 if self.shadingMode == "SH" else 0
-        d.vel_fp16 = 1 if self.vel_fp16 else 0
+        d.vel_fp16 = 2 if self.vel_fp16 in (2, "split", "split16") else (1 if self.vel_fp16 else 0)
         d.n_samples = int(self.nSamples)
         d.use_vel = int(self.use_vel)
         gsur, lo, hi = self._gate()

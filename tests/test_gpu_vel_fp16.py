@@ -131,3 +131,39 @@ def test_gpu_dense_alpha_fp16_is_close_to_fp32():
     d = (a32 - a16).abs()
     assert float(d.max()) < 5e-2 and float(d.mean()) < 1e-3
     assert float(((a32 > f.alphaMask_thres) != (a16 > f.alphaMask_thres)).float().mean()) < 5e-3
+
+
+@pytest.mark.gpu
+def test_gpu_split16_inference_meets_the_fp32_contract(gold, fields):
+    """vel_fp16 = 2: fp32 products emulated by two binary16 terms per operand (three fp16 MFMAs, ~2^-21 relative per product).  Unlike the
+    one-term mode this one is held to the FP32 bar: integrate_pos against the plain fp32 oracle, eval renders against the REFERENCE's own
+    goldens under the 1e-4 contract."""
+    from oracle import oracle as orc
+    model, meta = make_model("A")
+    f = model.nvfi
+    f.eval()
+    rng = np.random.default_rng(9)
+    N = 3000
+    x = (rng.random((N, 3), dtype=np.float32) * 2.1 - 1.05)
+    t = rng.random((N, 1), dtype=np.float32) * float(f.tmax) * 1.3
+    base = np.zeros_like(t)
+    xg, tg, bg = (torch.from_numpy(a).cuda() for a in (x, t, base))
+    with torch.no_grad():
+        ref32 = f.integrate_pos(xg.clone(), tg.clone(), bg).cpu().numpy()
+        f.vel_fp16 = 2
+        got = f.integrate_pos(xg.clone(), tg.clone(), bg).cpu().numpy()
+    ref = orc.integrate_pos(fields["A"], x, t, base)                     # the plain fp32 oracle
+    err = np.abs(got - ref).max(axis=1)
+    e32 = np.abs(ref32 - ref).max(axis=1)
+    print(f"split16 integrate_pos vs fp32 oracle: median {np.median(err):.2e}, max {err.max():.2e}   (fp32 MFMA path: median {np.median(e32):.2e}, max {e32.max():.2e})")
+    assert np.mean(err > 2e-5) < 2e-3 and np.median(err) < 5e-6
+    f.vel_fp16 = False
+    # every eval-render and integrate_pos golden of the REFERENCE (both fields: keyframe, non-keyframe, extrapolated, transfer, flipped
+    # background, alpha mask) under the unchanged 1e-4 contract with the switch on for the whole process
+    import subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, NVFI_VEL_FP16="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_cfg1.py"),
+                        "-k", "render_eval or integrate_pos or cfg1_matches"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    print(r.stdout.strip().splitlines()[-1])
