@@ -9,13 +9,28 @@ class Ray(torch.nn.Module):
         self.restore_shape = ray_o.shape[:-1]
         self.register_buffer("ray_origins", ray_o)
         self.register_buffer("ray_directions", ray_d)
-        self.register_buffer("near", near * torch.ones_like(self.ray_directions[..., :1]))
-        self.register_buffer("far", far * torch.ones_like(self.ray_directions[..., :1]))
         self.num_rays = ray_o.reshape(-1, 3).shape[0]
-        self.register_buffer("t", torch.zeros_like(ray_o[..., :1]) if t is None else t)
+        # near / far / t are per-ray buffers in the reference (models/camera.py:38-44).  The render path never reads them (the field samples
+        # between its own near / far), so they are materialised on first access instead of costing five launches per Ray.
+        self.__dict__["_lazy"] = {"near": near, "far": far, "t": t}
+
+    def __getattr__(self, name):
+        lazy = self.__dict__.get("_lazy")
+        if lazy is not None and name in lazy:
+            v = lazy.pop(name)
+            d = self._buffers["ray_directions"]
+            if name == "t":
+                buf = torch.zeros_like(d[..., :1]) if v is None else v
+            else:
+                buf = v if (isinstance(v, torch.Tensor) and v.dim() > 0) else v * torch.ones_like(d[..., :1])
+            self.register_buffer(name, buf)
+            return buf
+        return super().__getattr__(name)
 
     def update_near_far(self, near, far):
-        self.near, self.far = near, far
+        for k, v in (("near", near), ("far", far)):
+            self.__dict__["_lazy"].pop(k, None)
+            self.register_buffer(k, v) if isinstance(v, torch.Tensor) else setattr(self, k, v)
 
     def points_sampling(self, n_points, lindisp=False, perturb=True):
         """Stratified depths between near and far (models/camera.py:55-76); the hot path samples inside the field instead
