@@ -640,7 +640,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     if (ensure_pde_attrs() || ensure_lds_attrs()) return 1;
     PdePlan L; plan_pde(P, workspace, &L);
     if (L.total > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld bytes, got %lld", (long long)L.total, (long long)workspace_bytes);
-    HIPCK(hipMemsetAsync(L.cls_count, 0, (PDE_MAX_CLASS + 16) * sizeof(int), st));
+    HIPCK(hipMemsetAsync(L.cls_count, 0, (PDE_MAX_CLASS + 16) * sizeof(int), st));     // 320 bytes: 16-byte multiple, one fill kernel
     HIPCK(hipMemsetAsync(L.sums, 0, 4 * sizeof(double), st));
     PackJobs jobs; jobs.n = 0;
     VelFrags VW, AW;

@@ -13,7 +13,7 @@
 //   k_og          lanes = (sample, channel quad): the 24 tap loads of a lane are unconditional (clamped addresses, masked by a
 //                 select) and all in flight together; writes og[i][p][c] = d(loss)/d(value_p[c]) and, for the density branch,
 //                 the coordinate gradients (replaces the per-sample loop of k_density_bwd).
-//   k_tile_hist / k_tile_scan / k_tile_fill   counting sort of the samples by TxT-texel tile, once per space plane.
+//   k_tile_hist (+ the scan, in its last workgroup) / k_tile_fill   counting sort of the samples by TxT-texel tile, once per space plane.
 //   k_tile_scatter   ONE WAVE per (plane, tile, chunk of samples): the tile (+1 texel apron) of the space plane and the matching
 //                 strip of the paired time plane live in LDS and are updated with PLAIN read-add-write - a single wave executes
 //                 its LDS instructions in order and the lanes of one instruction ((channel, x-tap)) never collide - then flushed
@@ -207,6 +207,7 @@ __device__ __forceinline__ void bins_of(const TileGeom& g, const float4& q, int*
     b[2] = g.boff[2] + tile_of(q.y, q.z, g.G[1], g.G[2], g.ntx[2]);
 }
 
+__device__ void tile_scan_block(const TileSortArgs& a);
 __global__ __launch_bounds__(512) void k_tile_hist(TileSortArgs a) {
     extern __shared__ int h[];
     const int nb = a.g.nbins;
@@ -221,19 +222,29 @@ __global__ __launch_bounds__(512) void k_tile_hist(TileSortArgs a) {
     }
     __syncthreads();
     for (int k = threadIdx.x; k < nb; k += blockDim.x) if (h[k]) atomicAdd(&a.hist[k], h[k]);
+    // The last workgroup to arrive scans.  No fence: the histogram adds are agent-scope atomics (performed at the coherence point, not in a
+    // CU-local cache) that have completed - s_waitcnt vmcnt(0) - before the workgroup's ticket is drawn, and the scan reads the counts with
+    // agent-scope atomic loads.  (A __threadfence() per workgroup here - an L2 write-back / invalidate on every XCD - cost the step 10 %.)
+    __shared__ int last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(&a.hist[nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (last) tile_scan_block(a);
 }
 
-// one workgroup: tile starts (exclusive scan of the bin counts), chunk items, cursors; clears the histogram for the next call
-__global__ __launch_bounds__(1024) void k_tile_scan(TileSortArgs a) {
+// one workgroup: tile starts (exclusive scan of the bin counts), chunk items, cursors; clears the histogram (and the ticket) for the next
+// call.  Runs in the LAST workgroup of k_tile_hist to finish (ticket in hist[nbins]): one launch less per counting sort.
+__device__ void tile_scan_block(const TileSortArgs& a) {
     __shared__ int wsum[2][16];
     __shared__ int carry[2];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nt = blockDim.x;
     const int nb = a.g.nbins;
     if (tid == 0) { carry[0] = 0; carry[1] = 0; }
     __syncthreads();
-    for (int base = 0; base < nb; base += 1024) {
+    for (int base = 0; base < nb; base += nt) {
         const int k = base + tid;
-        const int c = k < nb ? a.hist[k] : 0;
+        const int c = k < nb ? __hip_atomic_load(&a.hist[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         const int nc = (c + SCATTER_CHUNK - 1) / SCATTER_CHUNK;
         int i0 = c, i1 = nc;
 #pragma unroll
@@ -253,10 +264,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSortArgs a) {
             }
         }
         __syncthreads();
-        if (tid == 1023) { carry[0] = c0 + w0 + i0; carry[1] = c1 + w1 + i1; }
+        if (tid == nt - 1) { carry[0] = c0 + w0 + i0; carry[1] = c1 + w1 + i1; }
         __syncthreads();
     }
-    if (tid == 0) *a.nitems = carry[1];
+    if (tid == 0) { *a.nitems = carry[1]; a.hist[nb] = 0; }
 }
 
 __global__ __launch_bounds__(512) void k_tile_fill(TileSortArgs a) {
@@ -432,16 +443,17 @@ int64_t tile_items_cap(const TileGeom& g, int64_t N) { return 3 * ((N + SCATTER_
 
 void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w) {
     tile_geom(f, &w->g);
-    w->hist = B.take<int>(w->g.nbins); w->cursor = B.take<int>(w->g.nbins); w->nitems = B.take<int>(4);
+    w->hist = B.take<int>(w->g.nbins + 64); w->cursor = B.take<int>(w->g.nbins); w->nitems = B.take<int>(4);   // hist[nbins]: ticket of k_tile_hist's last-workgroup scan
     w->items = B.take<int4>(tile_items_cap(w->g, N));
     w->sorted = B.take<float4>(3 * N);
     w->og = B.take<float>(N * 6 * 48);
     w->cap_items = tile_items_cap(w->g, N);
 }
 
-// histogram storage must be zero before the first k_tile_hist of a workspace; k_tile_scan re-zeroes it after every use
+// histogram storage (and its ticket) must be zero before the first k_tile_hist of a workspace; the scan re-zeroes both after every use
 int tile_work_init(const TileWork& w, hipStream_t st) {
-    HIPCK(hipMemsetAsync(w.hist, 0, sizeof(int) * w.g.nbins, st));
+    // (a size that is a multiple of 256 bytes is ONE fill kernel; an odd size is split into an aligned part and a tail: two launches)
+    HIPCK(hipMemsetAsync(w.hist, 0, (sizeof(int) * (w.g.nbins + 1) + 255) / 256 * 256, st));
     return 0;
 }
 
@@ -466,7 +478,6 @@ int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* 
     const int nb = w.g.nbins;
     unsigned hb = (unsigned)((N + 511) / 512); if (hb > 512) hb = 512;
     hipLaunchKernelGGL(k_tile_hist, dim3(hb), dim3(512), sizeof(int) * nb, st, sa);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, sa);
     hipLaunchKernelGGL(k_tile_fill, dim3((unsigned)((N + 511) / 512)), dim3(512), sizeof(int) * 2 * nb, st, sa);
     TileScatterArgs ta; memset(&ta, 0, sizeof(ta));
     ta.f = *f; ta.geo = w.g; ta.items = w.items; ta.nitems = w.nitems; ta.sorted = w.sorted; ta.list = list; ta.xw = xw; ta.og = w.og; ta.tn = tn;
