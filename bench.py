@@ -174,6 +174,7 @@ class Step:
         gloo = world > 1 and os.environ.get("NVFI_BENCH_BACKEND", "nccl") != "nccl"
         self.s_r2 = None
         if workload == "cfg3" and (ov == "1" or (ov is None and not gloo)):
+            model.nvfi.fork_backward = False      # the three chains already fill the device: no library-side fork inside a render's backward
             # (experiment switches: NVFI_PRIO_PDE / NVFI_PRIO_R1 / NVFI_PRIO_R2 = HIP stream priorities, -1 = high; with NVFI_PRIO_R2 set the
             #  keyframe render runs on a third side stream of that priority instead of the current stream)
             pr = [int(os.environ.get(k, "0")) for k in ("NVFI_PRIO_PDE", "NVFI_PRIO_R1")]

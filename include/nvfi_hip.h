@@ -72,6 +72,8 @@ typedef struct nvfi_grads {
 #define NVFI_WHITE_BG  2  /* rgb += 1-acc  (white_bg or the random-white coin, tensorf_keyframe.py:740) */
 #define NVFI_TRANSFER  4  /* transfer_vel: base time 0 (models/nvfi.py:30) */
 #define NVFI_WANT_MASK 8  /* plan workspace room for nvfi_render_mask (mask_field attached) */
+#define NVFI_BWD_FORK 16  /* nvfi_render_bwd at a keyframe time: the density half of the backward may run on a library-owned side stream beside the
+                           * appearance half (joined before the call returns); for callers that drive a single stream */
 
 /* counters written by nvfi_render_fwd (device int64[8]):
  * 0 valid samples V, 1 warped samples N, 2 appearance-masked samples M, 3 velocity-net evaluations, 7 device-time plan mismatch (nvfi_render_fwd_t) */

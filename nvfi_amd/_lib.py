@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.environ.get("NVFI_LIB", os.path.join(HERE, "csrc", "libnvfi_hip.so"))   # NVFI_LIB: alternative build (experiments)
 fp = C.c_void_p
 
-NVFI_TRAIN, NVFI_WHITE_BG, NVFI_TRANSFER, NVFI_WANT_MASK = 1, 2, 4, 8
+NVFI_TRAIN, NVFI_WHITE_BG, NVFI_TRANSFER, NVFI_WANT_MASK, NVFI_BWD_FORK = 1, 2, 4, 8, 16
 NCOUNTERS = 8
 
 

@@ -898,6 +898,22 @@ struct SideStream {
     }
 };
 static SideStream g_side;
+// NVFI_BWD_FORK (flags bit 16): at a keyframe time the two halves of the render backward - appearance (k_app_bwd, k_og<48>, tile scatter,
+// render-MLP weight gradients) and density (k_weights_bwd, k_og<24>, tile scatter) - share nothing but inputs, so a caller that drives ONE
+// stream can let the density half run beside the appearance half on a library-owned stream (its own tile-sort workspace; joined before
+// the call returns).  A caller that already overlaps several renders / the PDE term on its own streams (bench.py's fused driver) leaves the bit off.
+struct ForkStream {
+    hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; int state = -1;
+    int get() {
+        if (state >= 0) return state;
+        state = 1;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) state = 0;
+        if (state && hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) state = 0;
+        if (state && hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) state = 0;
+        return state;
+    }
+};
+static ForkStream g_fork;
 static int scatter_mask() { static int m = -1; if (m < 0) { const char* e = getenv("NVFI_SCATTER_MASK"); m = e ? atoi(e) : 63; } return m; }
 
 
@@ -1056,6 +1072,7 @@ struct RenderPlan {
     float4 *xw, *rgbs, *rgb_pre, *gxw, *gxk;
     float *xpre, *gxpre;
     float *vel_frag, *render_frag, *vel_x4, *vel_x4b; void* img16;
+    TileWork tw2;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     float *slabs;
     long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
@@ -1103,6 +1120,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
         P->shadow = nullptr;
         if (det_mode()) { int64_t off[12]; P->shadow = B.take<long long>(plane_elems(f, off)); }
         if (P->tiles) plan_tile_scatter(B, f, N, &P->tw);
+        if (P->tiles && nsteps == 0) plan_tile_scatter(B, f, N, &P->tw2);     // keyframe renders may run the density branch of the backward on a side stream (NVFI_BWD_FORK)
         if (nsteps > 0) {
             const int64_t nev = 2 * (int64_t)nsteps;
             P->zst = B.take<float>(nev * P->cap_tiles * (int64_t)(VEL_Z_REGS * REGF));
@@ -1277,6 +1295,11 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     const float* sched = t_on_device ? P.sched : nullptr;     // the record the forward's k_sched left in the workspace
     const unsigned ray_blocks = (unsigned)((R + 3) / 4);
     const bool side = g_side.get() != 0 && !P.tiles && !det_mode();   // the tile scatter reuses one og buffer for both branches: same stream
+    const bool want_aplanes0 = grads->aps[0] || grads->apt[0], want_dplanes0 = grads->dps[0] || grads->dpt[0];
+    const bool fork = (flags & NVFI_BWD_FORK) && P.tiles && nsteps == 0 && want_aplanes0 && want_dplanes0 && !det_mode() && g_fork.get() != 0;
+    hipStream_t sd = st;                                     // stream of the density half
+    if (fork) { HIPCK(hipEventRecord(g_fork.fork, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork, 0)); sd = g_fork.s; }
+    const TileWork& twd = fork ? P.tw2 : P.tw;
     // deterministic mode: the scatters add fixed-point integers into int64 shadow planes; k_det_finish folds them into the gradients
     nvfi_grads gdet = *grads;
     int64_t det_off[12]; int64_t det_n = 0;
@@ -1356,7 +1379,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     wa.far_ = f->far_; wa.mflag = P.mflag; wa.off_m = P.off_m; wa.rgbs = P.rgbs; wa.rgb_pre = P.rgb_pre;
     wa.g_rgb = g_rgb; wa.g_depth = g_depth; wa.g_acc = g_acc; wa.g_weight = g_weights; wa.gxpre = P.gxpre;
     wa.white_bg = (flags & NVFI_WHITE_BG) ? 1 : 0;
-    hipLaunchKernelGGL(k_weights_bwd, dim3(ray_blocks), dim3(256), 0, st, wa);
+    hipLaunchKernelGGL(k_weights_bwd, dim3(ray_blocks), dim3(256), 0, sd, wa);
     // density planes + coordinate grads
     DensityArgs da; memset(&da, 0, sizeof(da));
     da.f = *f; da.count = P.counters + 0; da.list = P.vlist; da.xw = P.xw; da.xpre = P.xpre; da.tn = tn; da.sched = sched;
@@ -1365,17 +1388,18 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     if (P.tiles) {
         // one pass over the samples: per-plane value gradients (og) for the tile scatter and, at non-keyframe times, the coordinate gradients
         if (nsteps > 0 || want_dplanes) {
-            ProfScope ps(PK_DENSITY_BWD, st);
+            ProfScope ps(PK_DENSITY_BWD, sd);
             OgArgs oa; memset(&oa, 0, sizeof(oa));
-            oa.f = *f; oa.count = P.counters + 0; oa.list = P.vlist; oa.xw = P.xw; oa.tn = tn; oa.sched = sched; oa.gxpre = P.gxpre; oa.og = want_dplanes ? P.tw.og : nullptr;
+            oa.f = *f; oa.count = P.counters + 0; oa.list = P.vlist; oa.xw = P.xw; oa.tn = tn; oa.sched = sched; oa.gxpre = P.gxpre; oa.og = want_dplanes ? twd.og : nullptr;
             oa.mflag = P.mflag; oa.gxw = P.gxw; oa.gxk = nsteps > 0 ? P.gxk : nullptr;
-            if (launch_og(f, oa, 24, nsteps > 0, N, st)) return 1;
+            if (launch_og(f, oa, 24, nsteps > 0, N, sd)) return 1;
         }
         if (want_dplanes) {
-            ProfScope ps(PK_DENSITY_SCATTER, st);
-            if (!want_aplanes && tile_work_init(P.tw, st)) return 1;
-            if (launch_tile_scatter(f, P.tw, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, st, sched)) return 1;
+            ProfScope ps(PK_DENSITY_SCATTER, sd);
+            if ((fork || !want_aplanes) && tile_work_init(twd, sd)) return 1;
+            if (launch_tile_scatter(f, twd, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, sd, sched)) return 1;
         }
+        if (fork) { HIPCK(hipEventRecord(g_fork.join, sd)); HIPCK(hipStreamWaitEvent(st, g_fork.join, 0)); }
     } else if (nsteps > 0) { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
     if (!P.tiles && want_dplanes) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));

@@ -357,6 +357,9 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         # host's issue time between the waits, and the extra cross-stream waits / record_stream bookkeeping only add to it.  Off by default.
         self.auto_overlap = os.environ.get("NVFI_AUTO_OVERLAP", "0") == "1"
         self.pde_debug = 0   # >0: also return the kept mask and the first n Jacobians of get_vel_loss
+        # the backward of a keyframe render may run its density half beside its appearance half on a library-owned stream (NVFI_BWD_FORK);
+        # a driver that already overlaps renders / the PDE term on its own streams (bench.py's fused step) switches this off
+        self.fork_backward = os.environ.get("NVFI_BWD_FORK", "1") != "0"
         # opt-in (not a reference attribute; the reference's counterpart is autocast via --disable_fp32, train_nvfi.py:96,144): every no-grad
         # back-advection - integrate_pos, the warp of eval-mode renders, getDenseAlpha - on the fp16-input MFMA (nvfi_field_desc.vel_fp16).
         # Training renders, the PDE term and all gradients stay fp32 whatever this says.
@@ -684,6 +687,8 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         jitter = None
         if training:
             flags |= _lib.NVFI_TRAIN
+            if self.fork_backward:
+                flags |= _lib.NVFI_BWD_FORK
             # the reference draws the per-ray jitter on the CPU generator (tensorf_base.py:302-306)
             jitter = self._jitter(R, ray_o.device)
         # white background or the training-time random-white coin, drawn on CPU (tensorf_keyframe.py:740)
