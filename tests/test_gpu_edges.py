@@ -214,3 +214,19 @@ def test_engine_rk2_kernels_still_match_goldens():
                         os.path.join(root, "tests", "test_gpu_training_loop.py"), "-q", "-x", "-m", "gpu"], env=env, cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("env", [dict(NVFI_WGRAD="engine"), dict(NVFI_WGRAD_CHAIN="0"), dict(NVFI_BWD_FORK="0")],
+                         ids=["wgrad_engine", "wgrad_no_chain", "no_bwd_fork"])
+def test_round3_switches_keep_the_goldens(env):
+    """the alternatives of the round-3 defaults - the register-operand weight-gradient kernel k_wgrad instead of k_wgrad_ring8, un-chained value /
+    tangent jobs in the ring kernel, the keyframe backward on one stream instead of the forked density half - under the gradient goldens"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_cfg2.py"),
+                        "-q", "-x", "-m", "gpu", "-k", "train_grads or pde_loss or mask_branch or cfg2"], env=dict(os.environ, **env), cwd=root,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
