@@ -898,17 +898,21 @@ struct SideStream {
     }
 };
 static SideStream g_side;
-// NVFI_BWD_FORK (flags bit 16): at a keyframe time the two halves of the render backward - appearance (k_app_bwd, k_og<48>, tile scatter,
-// render-MLP weight gradients) and density (k_weights_bwd, k_og<24>, tile scatter) - share nothing but inputs, so a caller that drives ONE
-// stream can let the density half run beside the appearance half on a library-owned stream (its own tile-sort workspace; joined before
-// the call returns).  A caller that already overlaps several renders / the PDE term on its own streams (bench.py's fused driver) leaves the bit off.
+// NVFI_BWD_FORK (flags bit 16), for a caller that drives ONE stream: parts of the render backward run on a library-owned stream, with their
+// own tile-sort workspace / slab region, joined before the call returns.
+//   keyframe time: the two halves - appearance (k_app_bwd, k_og<48>, tile scatter, render-MLP weight gradients) and density (k_weights_bwd,
+//     k_og<24>, tile scatter) - share nothing but inputs: the density half runs beside the appearance half;
+//   non-keyframe time: the coordinate gradients chain k_app_bwd -> k_og<48> -> k_og<24> -> RK2 adjoint -> velocity-net weight gradients; the
+//     plane scatters of both branches and the render-MLP weight gradients hang off that chain and run beside it.
+// A caller that already overlaps several renders / the PDE term on its own streams (bench.py's fused driver) leaves the bit off.
 struct ForkStream {
-    hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; int state = -1;
+    hipStream_t s = nullptr; hipEvent_t fork = nullptr, fork2 = nullptr, join = nullptr; int state = -1;
     int get() {
         if (state >= 0) return state;
         state = 1;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) state = 0;
         if (state && hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) state = 0;
+        if (state && hipEventCreateWithFlags(&fork2, hipEventDisableTiming) != hipSuccess) state = 0;
         if (state && hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) state = 0;
         return state;
     }
@@ -1072,7 +1076,7 @@ struct RenderPlan {
     float4 *xw, *rgbs, *rgb_pre, *gxw, *gxk;
     float *xpre, *gxpre;
     float *vel_frag, *render_frag, *vel_x4, *vel_x4b; void* img16;
-    TileWork tw2;
+    TileWork tw2; float* slabs2;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     float *slabs;
     long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
@@ -1120,7 +1124,8 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
         P->shadow = nullptr;
         if (det_mode()) { int64_t off[12]; P->shadow = B.take<long long>(plane_elems(f, off)); }
         if (P->tiles) plan_tile_scatter(B, f, N, &P->tw);
-        if (P->tiles && nsteps == 0) plan_tile_scatter(B, f, N, &P->tw2);     // keyframe renders may run the density branch of the backward on a side stream (NVFI_BWD_FORK)
+        if (P->tiles) plan_tile_scatter(B, f, N, &P->tw2);     // NVFI_BWD_FORK: the density half of the backward sorts / scatters beside the appearance half
+        P->slabs2 = nsteps > 0 ? B.take<float>((int64_t)NSLAB_MAX * SLAB_FLOATS * 6) : nullptr;   // ... and the velocity-net slabs beside the render-MLP slabs
         if (nsteps > 0) {
             const int64_t nev = 2 * (int64_t)nsteps;
             P->zst = B.take<float>(nev * P->cap_tiles * (int64_t)(VEL_Z_REGS * REGF));
@@ -1296,10 +1301,13 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     const unsigned ray_blocks = (unsigned)((R + 3) / 4);
     const bool side = g_side.get() != 0 && !P.tiles && !det_mode();   // the tile scatter reuses one og buffer for both branches: same stream
     const bool want_aplanes0 = grads->aps[0] || grads->apt[0], want_dplanes0 = grads->dps[0] || grads->dpt[0];
-    const bool fork = (flags & NVFI_BWD_FORK) && P.tiles && nsteps == 0 && want_aplanes0 && want_dplanes0 && !det_mode() && g_fork.get() != 0;
-    hipStream_t sd = st;                                     // stream of the density half
-    if (fork) { HIPCK(hipEventRecord(g_fork.fork, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork, 0)); sd = g_fork.s; }
-    const TileWork& twd = fork ? P.tw2 : P.tw;
+    const bool forkable = (flags & NVFI_BWD_FORK) && P.tiles && want_aplanes0 && want_dplanes0 && !det_mode() && g_fork.get() != 0;
+    const bool fork = forkable && nsteps == 0, fork2 = forkable && nsteps > 0;
+    hipStream_t sd = st;                                     // stream of k_weights_bwd / k_og<24> (keyframe fork: the side stream)
+    hipStream_t s_atail = st, s_dtail = st;                  // streams of the appearance tail (scatter, render-MLP weight gradients) and of the density scatter
+    if (fork) { HIPCK(hipEventRecord(g_fork.fork, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork, 0)); sd = g_fork.s; s_dtail = g_fork.s; }
+    if (fork2) { s_atail = g_fork.s; s_dtail = g_fork.s; }
+    const TileWork& twd = (fork || fork2) ? P.tw2 : P.tw;
     // deterministic mode: the scatters add fixed-point integers into int64 shadow planes; k_det_finish folds them into the gradients
     nvfi_grads gdet = *grads;
     int64_t det_off[12]; int64_t det_n = 0;
@@ -1337,9 +1345,10 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
             oa.f = *f; oa.count = P.counters + 1; oa.list = P.mlist; oa.xw = P.xw; oa.tn = tn; oa.sched = sched; oa.gg = P.gg; oa.og = want_aplanes ? P.tw.og : nullptr;
             oa.gxw_acc = nsteps > 0 ? P.gxw : nullptr;
             if (launch_og(f, oa, 48, nsteps > 0, N, st)) return 1;
+            if (fork2) { HIPCK(hipEventRecord(g_fork.fork, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork, 0)); }
             if (want_aplanes) {
-                if (tile_work_init(P.tw, st)) return 1;
-                if (launch_tile_scatter(f, P.tw, P.counters + 1, P.mlist, P.xw, tn, *grads, 48, N, st, sched)) return 1;
+                if (tile_work_init(P.tw, s_atail)) return 1;
+                if (launch_tile_scatter(f, P.tw, P.counters + 1, P.mlist, P.xw, tn, *grads, 48, N, s_atail, sched)) return 1;
             }
         }
     } else if (want_aplanes) {
@@ -1371,7 +1380,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         if (grads->rW[1] || grads->rb[1]) add(P.app_b + 16 * REGF, 64, P.app_f + 96 * REGF, 64, sl + 1 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->rW[1], grads->rb[1], 128, 128, SK_HIDDEN);
         if (grads->rW[0] || grads->rb[0]) add(P.app_b + 80 * REGF, 64, P.app_f + 32 * REGF, 64, sl + 2 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->rW[0], grads->rb[0], 128, 110, SK_RENDER_IN);
         if (grads->basis) add(P.app_b + 144 * REGF, 16, P.app_f + 0, 32, sl + 3 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->basis, nullptr, f->app_dim, f->Ca, SK_HIDDEN);
-        if (launch_wgrad(wj, rj, st)) return 1;
+        if (launch_wgrad(wj, rj, s_atail)) return 1;
     }
     // composites + raw2alpha
     WeightArgs wa; memset(&wa, 0, sizeof(wa));
@@ -1394,12 +1403,13 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
             oa.mflag = P.mflag; oa.gxw = P.gxw; oa.gxk = nsteps > 0 ? P.gxk : nullptr;
             if (launch_og(f, oa, 24, nsteps > 0, N, sd)) return 1;
         }
+        if (fork2) { HIPCK(hipEventRecord(g_fork.fork2, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork2, 0)); }
         if (want_dplanes) {
-            ProfScope ps(PK_DENSITY_SCATTER, sd);
-            if ((fork || !want_aplanes) && tile_work_init(twd, sd)) return 1;
-            if (launch_tile_scatter(f, twd, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, sd, sched)) return 1;
+            ProfScope ps(PK_DENSITY_SCATTER, s_dtail);
+            if ((fork || fork2 || !want_aplanes) && tile_work_init(twd, s_dtail)) return 1;
+            if (launch_tile_scatter(f, twd, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, s_dtail, sched)) return 1;
         }
-        if (fork) { HIPCK(hipEventRecord(g_fork.join, sd)); HIPCK(hipStreamWaitEvent(st, g_fork.join, 0)); }
+        if (fork) { HIPCK(hipEventRecord(g_fork.join, g_fork.s)); HIPCK(hipStreamWaitEvent(st, g_fork.join, 0)); }
     } else if (nsteps > 0) { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
     if (!P.tiles && want_dplanes) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
@@ -1434,9 +1444,10 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
             if (pack_vel_x4_bwd(VW, P.vel_x4b, ba.t4, st)) return 1;
             if (launch_rk2_split_bwd(ba, N, st)) return 1;
         } else if (launch_rk2_bwd(ra, N, st)) return 1;
-        if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 3, (int)P.cap_tiles, 2 * nsteps, BM_SILU, P.slabs, NSLAB,
+        if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 3, (int)P.cap_tiles, 2 * nsteps, BM_SILU, fork2 ? P.slabs2 : P.slabs, NSLAB,
                              grads->vW, grads->vb, 1.f, st)) return 1;
     }
+    if (fork2) { HIPCK(hipEventRecord(g_fork.join, g_fork.s)); HIPCK(hipStreamWaitEvent(st, g_fork.join, 0)); }
     if (forked) { HIPCK(hipEventRecord(g_side.join, g_side.s)); HIPCK(hipStreamWaitEvent(st, g_side.join, 0)); }
     return 0;
 }
