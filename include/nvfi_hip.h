@@ -139,6 +139,13 @@ int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float* points, c
                      float loss_scale, float* out, const nvfi_grads* grads,
                      void* workspace, int64_t workspace_bytes, int64_t* counters,
                      uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream);
+/* As nvfi_pde_loss_ex with the call split over two streams: out[] (the value) is complete on `stream` after the Jacobian forward; the adjoint
+ * pass and the weight gradients run on `bwd_stream`, ordered behind the forward by an event.  For the reference's loop, which waits for the
+ * value right after the call (train_nvfi.py:233) and then differentiates the renders: the PDE adjoint overlaps with them.  The caller
+ * orders its use of `grads` and the release of `workspace` behind `bwd_stream`.  P above one chunk (262 144): one stream. */
+int nvfi_pde_loss_split(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, float loss_scale,
+                        float* out, const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters,
+                        uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream, void* bwd_stream);
 
 /* nvfi_pde_loss with the loss scale (train_nvfi.py:229-234: vel_reg_weight, decayed every iteration) read from device memory */
 int nvfi_pde_loss_dev(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, const float* loss_scale_dev,

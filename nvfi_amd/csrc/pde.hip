@@ -617,11 +617,29 @@ static int ensure_pde_attrs() {
 static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, float loss_scale, const float* loss_scale_dev,
                          float* out, const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters,
                          uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream);
+// nvfi_pde_loss_split: the stream of the adjoint + weight-gradient half of the call in progress (NULL: everything on `stream`)
+static thread_local hipStream_t t_bwd_stream = nullptr;
+static thread_local hipEvent_t t_split_ev = nullptr;
 
 extern "C" int nvfi_pde_loss_ex(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, float loss_scale,
                                 float* out, const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters,
                                 uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream) {
     return pde_loss_impl(f, P, points, t, loss_scale, nullptr, out, grads, workspace, workspace_bytes, counters, kept_out, jac_out, n_jac, host_info, stream);
+}
+
+/* The VALUE of the loss (out[]) is complete on `stream` after the Jacobian forward; the adjoint pass and the weight gradients - a third of the
+ * call's time, needed only by the caller's backward - run on `bwd_stream`, ordered behind the forward by an event.  For a caller that waits
+ * for the value on `stream` right after the call (train_nvfi.py:233 `if loss_vel > 0`) and then issues other work there (the renders'
+ * backward), the two overlap.  The caller orders its use of the gradients (and the release of the workspace) behind `bwd_stream`.
+ * A candidate count above one chunk (262 144) falls back to one stream: the chunks share the stash. */
+extern "C" int nvfi_pde_loss_split(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, float loss_scale,
+                                   float* out, const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, int64_t* counters,
+                                   uint8_t* kept_out, float* jac_out, int64_t n_jac, int64_t* host_info, void* stream, void* bwd_stream) {
+    if (!t_split_ev) HIPCK(hipEventCreateWithFlags(&t_split_ev, hipEventDisableTiming));
+    t_bwd_stream = (bwd_stream && bwd_stream != stream) ? (hipStream_t)bwd_stream : nullptr;
+    const int rc = pde_loss_impl(f, P, points, t, loss_scale, nullptr, out, grads, workspace, workspace_bytes, counters, kept_out, jac_out, n_jac, host_info, stream);
+    t_bwd_stream = nullptr;
+    return rc;
 }
 
 extern "C" int nvfi_pde_loss_dev(const nvfi_field_desc* f, int64_t P, const float* points, const float* t, const float* loss_scale_dev,
@@ -736,6 +754,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         host_info[0] = hcnt[PDE_MAX_CLASS]; host_info[1] = evals;
     }
     if (kept_out) HIPCK(hipMemcpyAsync(kept_out, L.flags, (size_t)P, hipMemcpyDeviceToDevice, st));
+    bool finished = false;
     for (int64_t first = 0; first < P; first += L.chunk) {
         const int64_t cap = P - first < L.chunk ? (P - first + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES : L.chunk;
         PdeJetArgs ja; memset(&ja, 0, sizeof(ja));
@@ -759,22 +778,30 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
             hipLaunchKernelGGL(k_pde_seeds, dim3((unsigned)(cap / 256 + 1)), dim3(256), 0, st, ja);
         }
         if (grads) {
+            hipStream_t sb = st;
+            if (t_bwd_stream && P <= L.chunk) {      // split call: the value is finished on st first, the adjoint half follows on the other stream
+                hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, L.kcount, out);
+                HIPCK(hipEventRecord(t_split_ev, st));
+                HIPCK(hipStreamWaitEvent(t_bwd_stream, t_split_ev, 0));
+                sb = t_bwd_stream;
+                finished = true;
+            }
             {
-                ProfScope ps(PK_PDE_BWD, st);
+                ProfScope ps(PK_PDE_BWD, sb);
                 if (use_jet) {
-                    if (launch_pde_jet_bwd(ja, (unsigned)(cap / TILE), wgs, st)) return 1;
+                    if (launch_pde_jet_bwd(ja, (unsigned)(cap / TILE), wgs, sb)) return 1;
                 } else {
-                    hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
-                    hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
+                    hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, sb, ja);
+                    hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, sb, ja);
                 }
             }
             LAUNCHCK();
-            hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, st, L.kcount, first, cap, L.dcount);
-            if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, st)) return 1;
+            hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, sb, L.kcount, first, cap, L.dcount);
+            if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, sb)) return 1;
         }
         LAUNCHCK();
     }
-    hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, L.kcount, out);
+    if (!finished) hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, L.kcount, out);
     LAUNCHCK();
     if (counters) {
         hipLaunchKernelGGL(k_pde_counters, dim3(1), dim3(64), 0, st, L.cls_count, L.kcount, P, pre16 == 1 || pre16 == 3, counters);

@@ -194,9 +194,20 @@ class _PdeFn(torch.autograd.Function):
         kept = torch.zeros(P, dtype=torch.uint8, device=dev) if field.pde_debug else None
         jac = torch.zeros(field.pde_debug, 6, 4, device=dev) if field.pde_debug else None
         info = (C.c_int64 * 2)()
-        _lib.check(L.nvfi_pde_loss_ex(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(1.0), _lib.ptr(out),
-                                      C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters),
-                                      _lib.ptr(kept), _lib.ptr(jac), C.c_int64(int(field.pde_debug)), info, _stream_ptr()))
+        # split call (field.pde_split, default on): the VALUE is complete on the current stream after the Jacobian forward, the adjoint pass and
+        # the weight gradients run on the field's PDE side stream - under the reference's loop, which waits for the value right after this call
+        # (train_nvfi.py:233) and then differentiates the renders, the PDE adjoint overlaps with them; backward() waits for `ctx.done`
+        side = field._side_stream("p") if field.pde_split else None
+        _lib.check(L.nvfi_pde_loss_split(C.byref(desc), C.c_int64(P), _lib.ptr(points), _lib.ptr(t), C.c_float(1.0), _lib.ptr(out),
+                                         C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(counters),
+                                         _lib.ptr(kept), _lib.ptr(jac), C.c_int64(int(field.pde_debug)), info, _stream_ptr(),
+                                         C.c_void_p(side.cuda_stream) if side is not None else None))
+        ctx.done = None
+        if side is not None:
+            ctx.done = torch.cuda.Event()
+            ctx.done.record(side)
+            ws.record_stream(side)
+            grads[0]._base.record_stream(side)
         field.last_pde_kept, field.last_pde_jac = kept, jac
         field.last_pde_n_kept = int(info[0])
         field.last_pde_out = out
@@ -209,6 +220,8 @@ class _PdeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         field = ctx.field
+        if ctx.done is not None:
+            torch.cuda.current_stream().wait_event(ctx.done)     # the adjoint half of the split call has filled the gradients
         if field.accumulate_grads_inplace == "arena":
             tail = field._arena_attach(field._pde_params(), [True] * 24, want_tail=True)
             if tail is not None and tail.numel() == ctx.saved_tensors[0].numel():
@@ -360,6 +373,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         # the backward of a keyframe render may run its density half beside its appearance half on a library-owned stream (NVFI_BWD_FORK);
         # a driver that already overlaps renders / the PDE term on its own streams (bench.py's fused step) switches this off
         self.fork_backward = os.environ.get("NVFI_BWD_FORK", "1") != "0"
+        self.pde_split = os.environ.get("NVFI_PDE_SPLIT", "1") != "0"     # pde_loss(): adjoint half of the call on a side stream (nvfi_pde_loss_split)
         # opt-in (not a reference attribute; the reference's counterpart is autocast via --disable_fp32, train_nvfi.py:96,144): every no-grad
         # back-advection - integrate_pos, the warp of eval-mode renders, getDenseAlpha - on the fp16-input MFMA (nvfi_field_desc.vel_fp16).
         # Training renders, the PDE term and all gradients stay fp32 whatever this says.
