@@ -6,8 +6,9 @@
  * interface it replaces.  Plain pointers and sizes only: every pointer below is a DEVICE pointer
  * unless stated, `stream` is a hipStream_t passed as void*, the caller owns every buffer, nothing
  * is allocated inside (workspace sizes are queried first).  All calls are asynchronous on
- * `stream` - none of them waits for the device - with three documented exceptions that hand a value back to the host:
- * nvfi_pde_loss_ex when `host_info` is non-NULL, nvfi_prof_collect and nvfi_selftest.
+ * `stream` - none of them waits for the device - with the documented exceptions that hand a value back to the host or are diagnostics:
+ * nvfi_pde_loss_ex / nvfi_pde_loss_split when `host_info` is non-NULL, nvfi_prof_collect, nvfi_selftest, and nvfi_prof_enable(1) (it drops a
+ * marker launch on the null stream and waits for it).
  * Return value: 0 = ok, otherwise an error code; nvfi_last_error() gives the text.
  *
  * Layouts: factor planes are CHANNEL-LAST, [H][W][C] fp32 (the physical layout of a torch
