@@ -42,6 +42,12 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def mse_loss(x, target):
+    """the photometric loss of the fused driver: F.mse_loss with value and gradient from one launch (nvfi_mse); the drop-in loop keeps torch's"""
+    from nvfi_amd.utils import mse_loss as f
+    return f(x, target)
+
+
 VEL_FLOP = 139776          # 2*(28*128 + 4*128^2 + 128*6)   one VelBasis net evaluation
 APP_FLOP = 64768           # 2*(48*32 + 110*128 + 128^2 + 128*3)
 PEAK_FP32_MFMA = 157.3     # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
@@ -222,20 +228,33 @@ class Step:
                 i = int(self.rng.integers(0, 46))
             rays, target = self.rays()
             out = self.ren.render(i / 60.0, rays, white_background=True, mode="train")
-            loss = loss + torch.nn.functional.mse_loss(out[0], target)
+            loss = loss + mse_loss(out[0], target)
             self.counters.append(f.last_counters)
             t_key = 3 * int(self.rng.integers(0, 16)) / 60.0
         else:
             t_key = float(self.rng.integers(0, 46)) / 60.0   # radiance-only: continuous time rows
         rays, target = self.rays()
-        out = self.ren.render(t_key, rays, white_background=True, mode="train")
-        loss = loss + torch.nn.functional.mse_loss(out[0], target)
-        self.counters.append(f.last_counters)
         self.L1w *= self.lr_factor; self.tvd *= self.lr_factor; self.tva *= self.lr_factor
+        early_regs = self.fused_regs and self.world == 1 and self.fused_zero and self.stepped and os.environ.get("NVFI_EARLY_REGS", "1") != "0"
+        if early_regs:
+            # the regulariser pass (value + gradient of L1 / TV: a plain read-modify-write of the plane gradients) does not depend on the renders:
+            # it runs on a side stream beside the forward pass - the gradients are zero at this point (the Adam launch cleared them) - and the
+            # backward, whose scatters add atomically on top, waits for it
+            if getattr(self, "_s_reg", None) is None:
+                self._s_reg = torch.cuda.Stream(device=self.dev)
+            main = torch.cuda.current_stream()
+            self._s_reg.wait_stream(main)
+            with torch.cuda.stream(self._s_reg):
+                self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
+        out = self.ren.render(t_key, rays, white_background=True, mode="train")
+        loss = loss + mse_loss(out[0], target)
+        self.counters.append(f.last_counters)
         if not self.fused_regs:
             loss = loss + self.L1w * f.density_L1() + self.tvd * f.TV_loss_density(self.tv) + self.tva * f.TV_loss_app(self.tv)
+        if early_regs:
+            torch.cuda.current_stream().wait_stream(self._s_reg)
         loss.backward()
-        if self.fused_regs:   # same regularisers + their gradients, fused into one pass per plane (nvfi_plane_regs)
+        if self.fused_regs and not early_regs:   # same regularisers + their gradients, fused into one pass per plane (nvfi_plane_regs)
             self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
         if overlap:
             h = self.bucket.all_reduce_head_start(self.tail_off)
@@ -281,21 +300,21 @@ class Step:
             rays, target = self.rays()
             out = self.ren.render(i / 60.0, rays, white_background=True, mode="train")
             c1 = f.last_counters
-            torch.nn.functional.mse_loss(out[0], target).backward()
+            mse_loss(out[0], target).backward()
         if self.s_r2 is not None:
             with torch.cuda.stream(self.s_r2):
                 self.s_r2.wait_event(start)
                 rays, target = self.rays()
                 out = self.ren.render(t_key, rays, white_background=True, mode="train")
                 c2 = f.last_counters
-                loss = torch.nn.functional.mse_loss(out[0], target)
+                loss = mse_loss(out[0], target)
                 loss.backward()
             main.wait_stream(self.s_r2)
         else:
             rays, target = self.rays()
             out = self.ren.render(t_key, rays, white_background=True, mode="train")
             c2 = f.last_counters
-            loss = torch.nn.functional.mse_loss(out[0], target)
+            loss = mse_loss(out[0], target)
             loss.backward()
         self.counters += [c1, c2]
         self.L1w *= self.lr_factor; self.tvd *= self.lr_factor; self.tva *= self.lr_factor
@@ -401,17 +420,27 @@ class GraphedStep:
                 f.jitter_override = jit[0]
                 out = s.ren.render(DT(19.0 / 60.0, rec[0:1]), rays, white_background=True, mode="train")      # plan: a non-keyframe time (1 RK2 step)
                 self.flags.append(f.last_counters)
-                torch.nn.functional.mse_loss(out[0], target).backward()
+                mse_loss(out[0], target).backward()
         rays, target = s.rays()
+        early_regs = s.workload != "cfg3" and os.environ.get("NVFI_EARLY_REGS", "1") != "0"      # single chain: the regulariser pass beside the forward (Step.__call__)
+        if early_regs:
+            if getattr(s, "_s_reg", None) is None:
+                s._s_reg = torch.cuda.Stream(device=s.dev)
+            s._s_reg.wait_stream(main)
+            with torch.cuda.stream(s._s_reg):
+                s.last_regs = f.regularizers_backward_(rec[2:5])
         f.jitter_override = jit[-1]
         out = s.ren.render(DT(0.05 if s.workload == "cfg3" else 0.3, rec[1:2]), rays, white_background=True, mode="train")   # plan: a keyframe time / any time without a velocity field
         f.jitter_override = None
         self.flags.append(f.last_counters)
-        loss = torch.nn.functional.mse_loss(out[0], target)
+        loss = mse_loss(out[0], target)
+        if early_regs:
+            main.wait_stream(s._s_reg)
         loss.backward()
         if s.workload == "cfg3":
             main.wait_stream(s_pde); main.wait_stream(s_r1)
-        s.last_regs = f.regularizers_backward_(rec[2:5])
+        if not early_regs:
+            s.last_regs = f.regularizers_backward_(rec[2:5])
         s.opt.step(zero_grad=True, hyper_dev=rec[self.HEAD:self.HEAD + self.n_hyper])
         self.loss = loss
 

@@ -200,6 +200,9 @@ int nvfi_plane_regs_dev(const nvfi_field_desc* f, const float* w3_dev, float* ou
  *      parameter tensors in ONE launch.  `t` is a HOST array; p/g/m/v are device pointers (parameter, gradient, exp_avg, exp_avg_sq),
  *      n elements each, lr the tensor's learning rate; `step` counts from 1 (bias corrections); zero_grad != 0 clears g in the same pass. */
 typedef struct nvfi_adam_tensor { float* p; float* g; float* m; float* v; int64_t n; float lr; } nvfi_adam_tensor;
+/* F.mse_loss(x, target) of a training batch (train_nvfi.py:159,178) with its gradient in one launch: loss[0] = mean((x - target)^2),
+ * grad[i] = 2 (x[i] - target[i]) / n.  One workgroup: n <= 2^22. */
+int nvfi_mse(const float* x, const float* target, int64_t n, float* loss, float* grad, void* stream);
 int nvfi_adam_step(const nvfi_adam_tensor* t, int n_tensors, float beta1, float beta2, float eps, int64_t step, int zero_grad, void* stream);
 
 /* same step with the per-iteration scalars in DEVICE memory (hipGraph replay): hyper_dev[0] = 1/sqrt(1-beta2^step),

@@ -90,3 +90,34 @@ static int adam_impl(const nvfi_adam_tensor* t, int n_tensors, float beta1, floa
     }
     return 0;
 }
+
+
+// ---------------------------------------------------------------- photometric loss of the training loop (train_nvfi.py:159,178:
+// F.mse_loss(rgb_map, target)): value and d(loss)/d(x) in ONE launch.  torch issues three launches forward (square-difference,
+// reduce, divide) and three backward (two fills, one scaled difference) for 6 144 numbers; on a step that is a chain of ~45 dependent
+// launches each of them is ~5 us of critical path.  One workgroup: the batch of a training step is a few thousand values.
+__global__ __launch_bounds__(1024) void k_mse(const float* __restrict__ x, const float* __restrict__ y, int64_t n, float* loss, float* grad) {
+    __shared__ float part[16];
+    const float inv = 1.f / (float)n;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = x[i] - y[i];
+        s += d * d;
+        grad[i] = 2.f * d * inv;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += part[k];
+        *loss = t * inv;
+    }
+}
+extern "C" int nvfi_mse(const float* x, const float* target, int64_t n, float* loss, float* grad, void* stream) {
+    if (n <= 0) return nvfi_fail(2, "nvfi_mse: n must be positive");
+    if (n > (1 << 22)) return nvfi_fail(2, "nvfi_mse: one-workgroup kernel, n <= 4194304 (use torch.nn.functional.mse_loss for images)");
+    hipLaunchKernelGGL(k_mse, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, target, n, loss, grad);
+    LAUNCHCK();
+    return 0;
+}

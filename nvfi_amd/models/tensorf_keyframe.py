@@ -739,7 +739,12 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             with torch.no_grad():
                 rgb, depth, acc, weights, _ = _RenderFn.apply(self, t, ray_o, ray_d, jitter, flags, *params)
         if self.mask_field is None:
-            mask_map = torch.zeros(R, 3, device=ray_o.device)
+            # (R, 3) zeros like the reference's placeholder (tensorf_keyframe.py:673-676 without a mask_field) - a stride-0 view of one cached
+            # zero instead of a fill launch per render; nobody writes into it
+            z = _rt(self).get("_zero1")
+            if z is None or z.device != ray_o.device:
+                z = _rt(self)["_zero1"] = torch.zeros(1, 1, device=ray_o.device)
+            mask_map = z.expand(R, 3)
         elif training and torch.is_grad_enabled():
             mask_map = self._mask_map_train(R, weights)
         else:

@@ -56,3 +56,35 @@ def is_reference_tvloss(reg):
         _TV_OK[cls] = ok
     w = getattr(reg, "TVLoss_weight", None)
     return bool(ok) and isinstance(w, (int, float)) and not isinstance(w, bool)
+
+
+
+class _MseFn(__import__("torch").autograd.Function):
+    """F.mse_loss(x, target) with value and gradient from one launch (nvfi_mse); backward is one scaling launch."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        import ctypes as C
+        import torch
+        from .. import _lib
+        xc, tc = x.contiguous(), target.contiguous()
+        loss = torch.empty((), device=x.device)
+        grad = torch.empty_like(xc)
+        _lib.check(_lib.lib().nvfi_mse(_lib.ptr(xc), _lib.ptr(tc), C.c_int64(xc.numel()), _lib.ptr(loss), _lib.ptr(grad),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def mse_loss(x, target):
+    """torch.nn.functional.mse_loss(x, target) (mean reduction) for CUDA fp32 tensors of a training batch: one launch forward, one backward.
+    Falls back to torch for anything else (other dtypes / devices / sizes above 2^22)."""
+    import torch
+    if x.is_cuda and x.dtype == torch.float32 and target.dtype == torch.float32 and x.shape == target.shape and 0 < x.numel() <= (1 << 22):
+        return _MseFn.apply(x, target)
+    return torch.nn.functional.mse_loss(x, target)
