@@ -230,3 +230,19 @@ def test_round3_switches_keep_the_goldens(env):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("shape", [(1,), (2048, 3), (4099, 3)])
+def test_fused_mse_matches_torch(shape):
+    """nvfi_mse (value + gradient of F.mse_loss in one launch; bench.py's fused driver) against torch, with an upstream factor"""
+    import torch
+    from nvfi_amd.utils import mse_loss
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(*shape, device="cuda", generator=g, requires_grad=True)
+    y = torch.rand(*shape, device="cuda", generator=g)
+    x2 = x.detach().clone().requires_grad_()
+    (3.0 * mse_loss(x, y)).backward()
+    (3.0 * torch.nn.functional.mse_loss(x2, y)).backward()
+    assert torch.allclose(mse_loss(x, y).detach(), torch.nn.functional.mse_loss(x2, y).detach(), rtol=2e-6, atol=0)
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-6, atol=1e-9)
+    assert mse_loss(x.detach().cpu(), y.cpu()).item() == torch.nn.functional.mse_loss(x.detach().cpu(), y.cpu()).item()      # CPU tensors: torch
