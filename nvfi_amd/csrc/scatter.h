@@ -8,13 +8,20 @@
 #define SCATTER_CHUNK 256
 #endif
 //     // samples per (plane, tile) work item
-#define SCATTER_MAX_BINS 6144  // 3 planes x tiles; larger grids fall back to the atomic scatter
+#define SCATTER_MAX_BINS 6144  // 3 planes x tiles (8x8-texel LDS tiles); larger grids fall back to the atomic scatter
+#define SCATTER_T_MFMA 4       // MFMA scatter: 4x4-texel tiles (5x5 with the apron = 25 rows of two 16-row MFMA tiles), 64 samples per item
+#ifndef SCATTER_CHUNK_MFMA
+#define SCATTER_CHUNK_MFMA 128     // samples per item: a wave walks them in batches of 64
+#endif
+#define SCATTER_MAX_BINS_MFMA 8192
 
-struct TileGeom { int G[3]; int ntx[3]; int boff[3]; int nbins; };
+struct TileGeom { int G[3]; int ntx[3]; int nty[3]; int boff[3]; int nbins; int T; int chunk; int chunk_shift; int colmajor; };   // colmajor: tiles of planes 0 and 2 are numbered
+//  column by column, so that consecutive bins (and items) share the texel columns of the paired time plane (plane 1 pairs by rows: row-major)
 
 struct TileWork {              // device buffers inside the caller's workspace
     TileGeom g;
     int* hist; int* cursor; int* nitems; int4* items; float4* sorted; float* og;
+    int* start; int* istart;   // [nbins + 1] first sample / first item of every bin (the fill kernel writes the item list from them)
     int64_t cap_items;
 };
 
@@ -32,7 +39,7 @@ struct OgArgs {
 struct TileSortArgs {
     TileGeom g;
     const int* count; const int* list; const float4* xw;
-    int* hist; int* cursor; int4* items; int* nitems; float4* sorted;
+    int* hist; int* cursor; int4* items; int* nitems; float4* sorted; int* start; int* istart;
 };
 
 struct TileScatterArgs {

@@ -14,11 +14,19 @@
 //                 select) and all in flight together; writes og[i][p][c] = d(loss)/d(value_p[c]) and, for the density branch,
 //                 the coordinate gradients (replaces the per-sample loop of k_density_bwd).
 //   k_tile_hist (+ the scan, in its last workgroup) / k_tile_fill   counting sort of the samples by TxT-texel tile, once per space plane.
-//   k_tile_scatter   ONE WAVE per (plane, tile, chunk of samples): the tile (+1 texel apron) of the space plane and the matching
+//   k_tile_scatter_mfma (default, NVFI_SCATTER=mfma)   ONE WAVE per (plane, 4x4-texel tile, chunk of <= 128 samples): the scatter of
+//                 an item is the small GEMM  G[texel][channel] = sum_s W[texel][s] * og[s][channel]  on v_mfma_f32_16x16x4_f32 (exact
+//                 fp32 products, fp32 accumulation): 25 tile + apron texels = two 16-row tiles, the 2x5 strip of the paired time
+//                 plane a third, 24 / 48 channels = 2 / 3 column tiles.  The tile gradient lives in accumulators and is flushed
+//                 with global atomics from registers; the time strips of the 8 waves of a workgroup - consecutive items, which share
+//                 tile columns because the bins of planes 0 and 2 are numbered column by column - are summed in LDS first.
+//                 52 / 48 us per call (C = 48 / 24) against 104 / 92 us for the LDS kernel on the stationary bench workload.
+//   k_tile_scatter (NVFI_SCATTER=lds, and grids with more than 8192 4x4 tiles)   ONE WAVE per (plane, 8x8-texel tile, chunk of
+//                 samples): the tile (+1 texel apron) of the space plane and the matching
 //                 strip of the paired time plane live in LDS and are updated with PLAIN read-add-write - a single wave executes
 //                 its LDS instructions in order and the lanes of one instruction ((channel, x-tap)) never collide - then flushed
 //                 with one contiguous run of global atomics per tile row.  Global atomics drop from 576 per sample to
-//                 (tiles x apron) per chunk.
+//                 (tiles x apron) per chunk.  ~50 VALU instructions (4 cycles each) per sample and 24 channels bound it.
 // Pairing of time planes: the time plane whose spatial axis is one of the space plane's axes shares that axis' tap index, so its
 // two touched rows restricted to the tile are a (T+1)-texel strip:  plane 0 (x,y) <-> time plane 5 (x), plane 1 (x,z) <-> time
 // plane 3 (z), plane 2 (y,z) <-> time plane 4 (y).
@@ -193,23 +201,25 @@ int launch_density_q(const DensityArgs& da, int64_t N, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- tile sort
-__device__ __forceinline__ int tile_of(float gx, float gy, int W, int H, int ntx) {
+__device__ __forceinline__ int tile_of(float gx, float gy, int W, int H, int ntx, int nty, int T, bool colmajor) {
     float x = (gx + 1.f) * ((float)(W - 1) / 2.f), y = (gy + 1.f) * ((float)(H - 1) / 2.f);
     float xf = floorf(x), yf = floorf(y);
     xf = fminf(fmaxf(xf, 0.f), (float)(W - 1)); yf = fminf(fmaxf(yf, 0.f), (float)(H - 1));
     if (!(xf == xf)) xf = 0.f;
     if (!(yf == yf)) yf = 0.f;
-    return ((int)yf / TT) * ntx + (int)xf / TT;
+    const int tx = (int)xf / T, ty = (int)yf / T;
+    return colmajor ? tx * nty + ty : ty * ntx + tx;
 }
 __device__ __forceinline__ void bins_of(const TileGeom& g, const float4& q, int* b) {
-    b[0] = tile_of(q.x, q.y, g.G[0], g.G[1], g.ntx[0]);
-    b[1] = g.boff[1] + tile_of(q.x, q.z, g.G[0], g.G[2], g.ntx[1]);
-    b[2] = g.boff[2] + tile_of(q.y, q.z, g.G[1], g.G[2], g.ntx[2]);
+    b[0] = tile_of(q.x, q.y, g.G[0], g.G[1], g.ntx[0], g.nty[0], g.T, g.colmajor != 0);
+    b[1] = g.boff[1] + tile_of(q.x, q.z, g.G[0], g.G[2], g.ntx[1], g.nty[1], g.T, false);
+    b[2] = g.boff[2] + tile_of(q.y, q.z, g.G[1], g.G[2], g.ntx[2], g.nty[2], g.T, g.colmajor != 0);
 }
 
 __device__ void tile_scan_block(const TileSortArgs& a);
 __global__ __launch_bounds__(512) void k_tile_hist(TileSortArgs a) {
-    extern __shared__ int h[];
+    extern __shared__ int sh[];
+    int* h = sh;
     const int nb = a.g.nbins;
     for (int k = threadIdx.x; k < nb; k += blockDim.x) h[k] = 0;
     __syncthreads();
@@ -235,39 +245,58 @@ __global__ __launch_bounds__(512) void k_tile_hist(TileSortArgs a) {
 
 // one workgroup: tile starts (exclusive scan of the bin counts), chunk items, cursors; clears the histogram (and the ticket) for the next
 // call.  Runs in the LAST workgroup of k_tile_hist to finish (ticket in hist[nbins]): one launch less per counting sort.
+#define SCAN_PAD(k) ((k) + ((k) >> 4))      // LDS position of bin k: a thread's 16 consecutive bins sit 17 words from its neighbour's
 __device__ void tile_scan_block(const TileSortArgs& a) {
+    // every thread owns SCAN_PT consecutive bins: one block-wide scan of the per-thread sums instead of nbins / 512 dependent rounds.
+    // Global memory is touched in coalesced rows only (bin = thread + 512 j), transposed through LDS: with thread-strided accesses
+    // every wave instruction of this single workgroup touched 32 cache lines.
+    constexpr int SCAN_PT = (SCATTER_MAX_BINS_MFMA + 511) / 512;
+    static_assert(SCAN_PT == 16, "SCAN_PAD assumes 16 bins per thread");
+    extern __shared__ int sh[];                  // [0, P): counts, then first samples; [P, 2P): first items;  P = SCAN_PAD(nbins) + 1
     __shared__ int wsum[2][16];
-    __shared__ int carry[2];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nt = blockDim.x;
-    const int nb = a.g.nbins;
-    if (tid == 0) { carry[0] = 0; carry[1] = 0; }
-    __syncthreads();
-    for (int base = 0; base < nb; base += nt) {
-        const int k = base + tid;
-        const int c = k < nb ? __hip_atomic_load(&a.hist[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        const int nc = (c + SCATTER_CHUNK - 1) / SCATTER_CHUNK;
-        int i0 = c, i1 = nc;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nb = a.g.nbins, chunk = a.g.chunk, csh = a.g.chunk_shift;     // chunk = 1 << csh
+    int* sa = sh; int* sb = sh + SCAN_PAD(nb) + 1;
+    __syncthreads();                             // (the histogram in sh[] is dead: every thread is past its flush)
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int t0 = __shfl_up(i0, o), t1 = __shfl_up(i1, o); if (lane >= o) { i0 += t0; i1 += t1; } }
-        if (lane == 63) { wsum[0][w] = i0; wsum[1][w] = i1; }
-        __syncthreads();
-        int w0 = 0, w1 = 0;
-        for (int j = 0; j < w; ++j) { w0 += wsum[0][j]; w1 += wsum[1][j]; }
-        const int c0 = carry[0], c1 = carry[1];
-        const int start = c0 + w0 + i0 - c, istart = c1 + w1 + i1 - nc;
-        if (k < nb) {
-            a.cursor[k] = start;
-            a.hist[k] = 0;
-            for (int j = 0; j < nc; ++j) {
-                int4 it; it.x = k; it.y = start + j * SCATTER_CHUNK; it.z = min(SCATTER_CHUNK, c - j * SCATTER_CHUNK); it.w = 0;
-                a.items[istart + j] = it;
-            }
-        }
-        __syncthreads();
-        if (tid == nt - 1) { carry[0] = c0 + w0 + i0; carry[1] = c1 + w1 + i1; }
-        __syncthreads();
+    for (int j = 0; j < SCAN_PT; ++j) {
+        const int k = tid + 512 * j;
+        if (k < nb) sa[SCAN_PAD(k)] = __hip_atomic_load(&a.hist[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid == 0) { *a.nitems = carry[1]; a.hist[nb] = 0; }
+    __syncthreads();
+    const int k0 = tid * SCAN_PT;
+    int c[SCAN_PT];
+    int s0 = 0, s1 = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_PT; ++j) {
+        c[j] = k0 + j < nb ? sa[17 * tid + j] : 0;
+        s0 += c[j]; s1 += (c[j] + chunk - 1) >> csh;
+    }
+    int i0 = s0, i1 = s1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t0 = __shfl_up(i0, o), t1 = __shfl_up(i1, o); if (lane >= o) { i0 += t0; i1 += t1; } }
+    if (lane == 63) { wsum[0][w] = i0; wsum[1][w] = i1; }
+    __syncthreads();
+    int w0 = 0, w1 = 0, t0 = 0, t1 = 0;
+    for (int j = 0; j < (int)(blockDim.x >> 6); ++j) { if (j < w) { w0 += wsum[0][j]; w1 += wsum[1][j]; } t0 += wsum[0][j]; t1 += wsum[1][j]; }
+    int start = w0 + i0 - s0, istart = w1 + i1 - s1;
+#pragma unroll
+    for (int j = 0; j < SCAN_PT; ++j) {
+        if (k0 + j < nb) { sa[17 * tid + j] = start; sb[17 * tid + j] = istart; }
+        start += c[j]; istart += (c[j] + chunk - 1) >> csh;
+    }
+    __syncthreads();
+    // (the item list itself is written by the fill kernel's many workgroups from start / istart)
+#pragma unroll
+    for (int j = 0; j < SCAN_PT; ++j) {
+        const int k = tid + 512 * j;
+        if (k < nb) {
+            const int st = sa[SCAN_PAD(k)];
+            a.cursor[k] = st; a.start[k] = st; a.istart[k] = sb[SCAN_PAD(k)];
+            a.hist[k] = 0;
+        }
+    }
+    if (tid == 0) { a.start[nb] = t0; a.istart[nb] = t1; *a.nitems = t1; a.hist[nb] = 0; }
 }
 
 __global__ __launch_bounds__(512) void k_tile_fill(TileSortArgs a) {
@@ -288,8 +317,28 @@ __global__ __launch_bounds__(512) void k_tile_fill(TileSortArgs a) {
         for (int p = 0; p < 3; ++p) r[p] = atomicAdd(&cnt[b[p]], 1);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) if (cnt[k]) bas[k] = atomicAdd(&a.cursor[k], cnt[k]);
+    {   // one returning atomic per touched bin: all of a thread's requests are in flight before the first result is stored
+        constexpr int PT = (SCATTER_MAX_BINS_MFMA + 511) / 512;
+        int rr[PT];
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int k = threadIdx.x + j * 512;
+            const int c = k < nb ? cnt[k] : 0;
+            rr[j] = c ? atomicAdd(&a.cursor[k], c) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int k = threadIdx.x + j * 512;
+            if (k < nb) bas[k] = rr[j];
+        }
+    }
     __syncthreads();
+    // items of bins blockIdx.x, blockIdx.x + gridDim.x, ...: (bin, first sample, samples, 0) per chunk
+    for (int k = blockIdx.x + threadIdx.x * gridDim.x; k < nb; k += gridDim.x * blockDim.x) {
+        const int s0 = a.start[k], c = a.start[k + 1] - s0, chunk = a.g.chunk;
+        int4* it = a.items + a.istart[k];
+        for (int q = 0; q * chunk < c; ++q) it[q] = make_int4(k, s0 + q * chunk, min(chunk, c - q * chunk), 0);
+    }
     if (i < count) {
         // record = (sample index, u, v): the two in-plane coordinates of the pass, so the scatter needs no second and third lookup
         a.sorted[bas[b[0]] + r[0]] = make_float4(__int_as_float(i), qq.x, qq.y, 0.f);
@@ -424,26 +473,237 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_scatter(TileScatterArgs 
     }
 }
 
+// ---------------------------------------------------------------- MFMA tile scatter: one wave per item, the tile gradient in accumulators
+// The scatter of one item is a small GEMM: G[texel][channel] = sum over the item's samples of W[texel][sample] * og[sample][channel], where
+// W holds the bilinear weight of the sample at the texel (four non-zeros per column).  With 4x4-texel tiles the tile and its apron are 25
+// texels - two 16-row tiles of v_mfma_f32_16x16x4_f32 - and the matching 2x5 strip of the paired time plane is a third; 24 (48) channels
+// are 2 (3) column tiles, so a step of 4 samples is 6 (9) MFMAs of 32 cycles against ~200 VALU cycles per sample and 24 channels of the
+// LDS read-add-write kernel above.  The products are exact fp32 (same e*s weights, fp32 accumulation); only the order of the sum differs,
+// as it does between two runs of the LDS kernel.  Lane s prepares sample s once: the five x- and five y-weights of the tile columns / rows
+// (zeros except at the tap pair; the zero-padding masks folded in), the same for the time strip, and the sample index, as a 19-word record
+// in LDS; in the loop lane (k = lane / 16, row = lane % 16) reads the two factors of W[row][4 step + k] for each row tile (conflict-free:
+// odd record stride) and the og row of its sample straight from global memory (16 lanes = 64 contiguous bytes), two steps in flight.
+// No workgroup barrier: the four waves of a workgroup own separate items, records and accumulators and flush with global atomics from
+// registers (16 lanes = 16 consecutive channels of one texel).
+#ifndef MS_WAVES
+#define MS_WAVES 8
+#endif
+// timing experiments (tools/r03_scatter_bisect.sh): MSX_NOLOOP=1 skips the MFMA loop, MSX_NOFLUSH=1/2/3 skips all / the time / the space atomics
+#ifndef MSX_NOLOOP
+#define MSX_NOLOOP 0
+#endif
+#ifndef MSX_NOFLUSH
+#define MSX_NOFLUSH 0
+#endif
+#define MS_W (SCATTER_T_MFMA + 1)
+#define MS_REC 19              // wx[5] wy[5] wtx[5] wty[2] index zero
+typedef float ms_f4 __attribute__((ext_vector_type(4)));
+
+template <int CT>
+__global__ __launch_bounds__(64 * MS_WAVES) void k_tile_scatter_mfma(TileScatterArgs a) {
+    constexpr int NCT = (CT + 15) / 16;
+    constexpr int T = SCATTER_T_MFMA;
+    static_assert(10 * 16 * NCT <= 64 * MS_REC, "a wave's time strip is parked in its record area");
+    __shared__ float rec_all[MS_WAVES][64 * MS_REC];
+    __shared__ int col_of[MS_WAVES];                       // strip id (plane, tile column / row) of each wave's item, -1: none
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int itx = blockIdx.x * MS_WAVES + wv;
+    const int nitems = *a.nitems;
+    if ((int)blockIdx.x * MS_WAVES >= nitems) return;      // (whole workgroup)
+    const nvfi_field_desc& f = a.f;
+    float* rec = rec_all[wv];
+    const bool live = itx < nitems;
+    const int4 item = live ? a.items[itx] : make_int4(0, 0, 0, 0);
+    const int p = item.x >= a.geo.boff[2] ? 2 : (item.x >= a.geo.boff[1] ? 1 : 0);
+    const int tile = item.x - a.geo.boff[p];
+    const bool t_on_u = p != 1;                                // the paired time plane runs along the u axis of plane p, else along v
+    int tx, ty;
+    if (t_on_u && a.geo.colmajor) { tx = tile / a.geo.nty[p]; ty = tile - tx * a.geo.nty[p]; }
+    else { ty = tile / a.geo.ntx[p]; tx = tile - ty * a.geo.ntx[p]; }
+    const int ox = tx * T, oy = ty * T;
+    const int ia = p == 2 ? 1 : 0, ib = p == 0 ? 1 : 2;       // matModeSpace axes of plane p
+    const int W = f.G[ia], H = f.G[ib];
+    const int tp = p == 0 ? 5 : (p == 1 ? 3 : 4);              // paired time plane
+    const int Wt = t_on_u ? W : H, ot = t_on_u ? ox : oy;
+    const int y0t = SCHED_Y0(a);
+    float* gsp = CT == 24 ? a.g.dps[p] : a.g.aps[p];
+    float* gtm = CT == 24 ? a.g.dpt[tp - 3] : a.g.apt[tp - 3];
+    const int n = lane & 15, k = lane >> 4;
+    // record words of this lane's A rows: space texels n and 16 + n (row-major 5x5), time texel n (row-major 2x5); word 18 is zero
+    const int ax0 = n % MS_W, ay0 = 5 + n / MS_W;
+    const int ax1 = 16 + n < 25 ? (16 + n) % MS_W : 18, ay1 = 16 + n < 25 ? 5 + (16 + n) / MS_W : 18;
+    const int atx = n < 10 ? 10 + n % MS_W : 18, aty = n < 10 ? 15 + n / MS_W : 18;
+    ms_f4 acc[3][NCT];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[r][c] = ms_f4{0.f, 0.f, 0.f, 0.f};
+    const float* ogp = a.og + (size_t)p * CT + n;
+    const int dtp = (tp - p) * CT;
+#pragma unroll 1
+    for (int b0 = 0; b0 < item.z; b0 += 64) {
+        const int nb = min(64, item.z - b0);
+        {   // lane s prepares sample s of the batch
+            float wxa = 0.f, wxb = 0.f, wya = 0.f, wyb = 0.f, txa = 0.f, txb = 0.f, tya = 0.f, tyb = 0.f;
+            int sx = -8, sy = -8, st = -8, il = 0;
+            if (lane < nb) {
+                const float4 r = a.sorted[item.y + b0 + lane];
+                il = __float_as_int(r.x);
+                Bl b, bt;
+                int x0, y0, xt, yt;
+                bl_setup_xy(r.y, r.z, W, H, b, x0, y0);
+                bl_setup_xy(t_on_u ? r.y : r.z, SCHED_TN(a), Wt, f.K, bt, xt, yt);
+                wxa = (x0 >= 0 && x0 < W) ? b.e : 0.f; wxb = (x0 + 1 >= 0 && x0 + 1 < W) ? b.w : 0.f;
+                wya = (y0 >= 0 && y0 < H) ? b.s : 0.f; wyb = (y0 + 1 >= 0 && y0 + 1 < H) ? b.n : 0.f;
+                txa = (xt >= 0 && xt < Wt) ? bt.e : 0.f; txb = (xt + 1 >= 0 && xt + 1 < Wt) ? bt.w : 0.f;
+                tya = (yt >= 0 && yt < f.K) ? bt.s : 0.f; tyb = (yt + 1 >= 0 && yt + 1 < f.K) ? bt.n : 0.f;
+                // (yt is the launch's time row y0t whenever a time weight is non-zero: same floor, same clamp)
+                sx = x0 - ox; sy = y0 - oy; st = xt - ot;
+            }
+            float* q = rec + lane * MS_REC;
+#pragma unroll
+            for (int j = 0; j < MS_W; ++j) {
+                q[j] = j == sx ? wxa : (j == sx + 1 ? wxb : 0.f);
+                q[5 + j] = j == sy ? wya : (j == sy + 1 ? wyb : 0.f);
+                q[10 + j] = j == st ? txa : (j == st + 1 ? txb : 0.f);
+            }
+            q[15] = tya; q[16] = tyb; q[17] = __int_as_float(il); q[18] = 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nst = ((nb + 15) >> 4) << 2;         // steps of 4 samples, a multiple of 4 (records past the batch hold zero weights)
+        auto load_b = [&](int s, float (&bp)[NCT], float (&bt)[NCT]) {
+            const int sc = s < nst ? s : nst - 1;
+            const int i = __float_as_int(rec[(4 * sc + k) * MS_REC + 17]);
+            const float* q = ogp + (size_t)i * (6 * CT);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) { bp[c] = q[16 * c]; bt[c] = q[dtp + 16 * c]; }
+        };
+        auto step = [&](int s, const float (&bp)[NCT], const float (&bt)[NCT]) {
+            const float* r = rec + (4 * s + k) * MS_REC;
+            const float a0 = r[ax0] * r[ay0], a1 = r[ax1] * r[ay1], at = r[atx] * r[aty];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bp[c], acc[0][c], 0, 0, 0);
+                acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bp[c], acc[1][c], 0, 0, 0);
+                acc[2][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, bt[c], acc[2][c], 0, 0, 0);
+            }
+        };
+        // four operand sets rotate: the og rows of step s + 3 are requested before the MFMAs of step s are issued
+        float bp0[NCT], bt0[NCT], bp1[NCT], bt1[NCT], bp2[NCT], bt2[NCT], bp3[NCT], bt3[NCT];
+        load_b(0, bp0, bt0);
+        load_b(1, bp1, bt1);
+        load_b(2, bp2, bt2);
+#pragma unroll 1
+        for (int s = 0; s < (MSX_NOLOOP ? 0 : nst); s += 4) {
+            load_b(s + 3, bp3, bt3);
+            __builtin_amdgcn_sched_barrier(0);
+            step(s, bp0, bt0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s + 4, bp0, bt0);
+            __builtin_amdgcn_sched_barrier(0);
+            step(s + 1, bp1, bt1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s + 5, bp1, bt1);
+            __builtin_amdgcn_sched_barrier(0);
+            step(s + 2, bp2, bt2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s + 6, bp2, bt2);
+            __builtin_amdgcn_sched_barrier(0);
+            step(s + 3, bp3, bt3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the next batch overwrites the records)
+    }
+    // park the time strip (10 texels x 16 NCT channels) in the wave's own record area: the workgroup sums the strips of waves that
+    // share a tile column before they go to memory - consecutive items do (column-major bins), and the 2 x Wt texels of a time plane
+    // would otherwise take one atomic per item, all on the same few cache lines
+    if (live) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 4 * k + v;
+            if (r < 10) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) rec[r * (16 * NCT) + 16 * c + n] = acc[2][c][v];
+            }
+        }
+    }
+    if (lane == 0) col_of[wv] = live && item.z > 0 ? (p << 16) | (t_on_u ? tx : ty) : -1;
+    // space tile: straight from the accumulators; output register v of lane (k, n) is row 4 k + v, channel 16 c + n of each 16 x 16 tile
+    if (live && MSX_NOFLUSH != 1 && MSX_NOFLUSH != 3 && gsp) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int r = 16 * rt + 4 * k + v;
+                const int X = ox + r % MS_W, Y = oy + r / MS_W;
+                if (r < 25 && X < W && Y < H) {
+                    float* g = gsp + ((size_t)Y * W + X) * CT + n;
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) {
+                        const float val = acc[rt][c][v];
+                        if (16 * c + n < CT && val != 0.f) atomicAdd(g + 16 * c, val);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (MSX_NOFLUSH == 1 || MSX_NOFLUSH == 2) return;
+    // thread (texel r, channel c) walks the waves in order and sends one sum per run of equal strip ids
+    const int tid = threadIdx.x;
+    if (tid < 10 * 16 * NCT) {
+        const int c = tid % (16 * NCT), r = tid / (16 * NCT);
+        float sum = 0.f;
+        int cur = -1;
+        auto flush = [&]() {
+            if (cur < 0 || sum == 0.f || c >= CT) return;
+            const int pp = cur >> 16, o = (cur & 0xffff) * T;
+            const int tpp = pp == 0 ? 5 : (pp == 1 ? 3 : 4);
+            const int Wtt = pp == 2 ? f.G[1] : (pp == 1 ? f.G[2] : f.G[0]);       // plane 0: x, plane 1 (x,z): z, plane 2 (y,z): y
+            float* g = CT == 24 ? a.g.dpt[tpp - 3] : a.g.apt[tpp - 3];
+            const int X = o + r % MS_W, Y = y0t + r / MS_W;
+            if (g && X < Wtt && Y >= 0 && Y < f.K) atomicAdd(g + ((size_t)Y * Wtt + X) * CT + c, sum);
+        };
+        for (int w = 0; w < MS_WAVES; ++w) {
+            const int id = col_of[w];
+            if (id != cur) { flush(); cur = id; sum = 0.f; }
+            if (id >= 0) sum += rec_all[w][tid];
+        }
+        flush();
+    }
+    (void)gtm; (void)Wt;
+}
+
 // ---------------------------------------------------------------- host
-int tile_geom(const nvfi_field_desc* f, TileGeom* g) {
+// NVFI_SCATTER=mfma (default) | lds: the MFMA kernel on 4x4-texel tiles, or the LDS read-add-write kernel on 8x8-texel tiles
+static bool scatter_mfma() { static int u = -1; if (u < 0) { const char* e = getenv("NVFI_SCATTER"); u = (e && !strcmp(e, "lds")) ? 0 : 1; } return u != 0; }
+static int tile_geom_T(const nvfi_field_desc* f, TileGeom* g, int T, int chunk) {
     const int ia[3] = {0, 0, 1}, ib[3] = {1, 2, 2};
     int off = 0;
     for (int p = 0; p < 3; ++p) {
-        g->ntx[p] = (f->G[ia[p]] + TT - 1) / TT;
-        const int nty = (f->G[ib[p]] + TT - 1) / TT;
+        g->ntx[p] = (f->G[ia[p]] + T - 1) / T;
+        g->nty[p] = (f->G[ib[p]] + T - 1) / T;
         g->boff[p] = off;
-        off += g->ntx[p] * nty;
+        off += g->ntx[p] * g->nty[p];
     }
-    g->nbins = off;
+    g->nbins = off; g->T = T; g->chunk = chunk; g->chunk_shift = 31 - __builtin_clz(chunk); g->colmajor = T == SCATTER_T_MFMA ? 1 : 0;
     for (int c = 0; c < 3; ++c) g->G[c] = f->G[c];
-    return off <= SCATTER_MAX_BINS ? 0 : 1;
+    return off;
+}
+int tile_geom(const nvfi_field_desc* f, TileGeom* g) {
+    if (scatter_mfma() && tile_geom_T(f, g, SCATTER_T_MFMA, SCATTER_CHUNK_MFMA) <= SCATTER_MAX_BINS_MFMA) return 0;
+    return tile_geom_T(f, g, SCATTER_T, SCATTER_CHUNK) <= SCATTER_MAX_BINS ? 0 : 1;
 }
 
-int64_t tile_items_cap(const TileGeom& g, int64_t N) { return 3 * ((N + SCATTER_CHUNK - 1) / SCATTER_CHUNK) + g.nbins; }
+static_assert((SCATTER_CHUNK & (SCATTER_CHUNK - 1)) == 0 && (SCATTER_CHUNK_MFMA & (SCATTER_CHUNK_MFMA - 1)) == 0, "chunks are powers of two");
+int64_t tile_items_cap(const TileGeom& g, int64_t N) { return 3 * ((N + g.chunk - 1) / g.chunk) + g.nbins; }
 
 void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w) {
     tile_geom(f, &w->g);
     w->hist = B.take<int>(w->g.nbins + 64); w->cursor = B.take<int>(w->g.nbins); w->nitems = B.take<int>(4);   // hist[nbins]: ticket of k_tile_hist's last-workgroup scan
+    w->start = B.take<int>(w->g.nbins + 1); w->istart = B.take<int>(w->g.nbins + 1);
     w->items = B.take<int4>(tile_items_cap(w->g, N));
     w->sorted = B.take<float4>(3 * N);
     w->og = B.take<float>(N * 6 * 48);
@@ -474,10 +734,13 @@ int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int
 int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* count, const int* list, const float4* xw, float tn,
                         const nvfi_grads& g, int C, int64_t N, hipStream_t st, const float* sched) {
     TileSortArgs sa; memset(&sa, 0, sizeof(sa));
-    sa.g = w.g; sa.count = count; sa.list = list; sa.xw = xw; sa.hist = w.hist; sa.cursor = w.cursor; sa.items = w.items; sa.nitems = w.nitems; sa.sorted = w.sorted;
+    sa.g = w.g; sa.count = count; sa.list = list; sa.xw = xw; sa.hist = w.hist; sa.cursor = w.cursor; sa.items = w.items; sa.nitems = w.nitems; sa.sorted = w.sorted; sa.start = w.start; sa.istart = w.istart;
     const int nb = w.g.nbins;
     unsigned hb = (unsigned)((N + 511) / 512); if (hb > 512) hb = 512;
-    hipLaunchKernelGGL(k_tile_hist, dim3(hb), dim3(512), sizeof(int) * nb, st, sa);
+    const size_t hist_lds = sizeof(int) * 2 * (size_t)(nb + (nb >> 4) + 1);      // the histogram, then the scan's two transposed rows
+    static bool big_lds = false;
+    if (!big_lds) { HIPCK(hipFuncSetAttribute((const void*)k_tile_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); big_lds = true; }
+    hipLaunchKernelGGL(k_tile_hist, dim3(hb), dim3(512), hist_lds, st, sa);
     hipLaunchKernelGGL(k_tile_fill, dim3((unsigned)((N + 511) / 512)), dim3(512), sizeof(int) * 2 * nb, st, sa);
     TileScatterArgs ta; memset(&ta, 0, sizeof(ta));
     ta.f = *f; ta.geo = w.g; ta.items = w.items; ta.nitems = w.nitems; ta.sorted = w.sorted; ta.list = list; ta.xw = xw; ta.og = w.og; ta.tn = tn;
@@ -486,7 +749,11 @@ int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* 
     float yf = floorf(y);
     yf = fminf(fmaxf(yf, -4.f), (float)f->K + 2.f);
     ta.y0 = (int)yf;
-    if (C == 24) hipLaunchKernelGGL(k_tile_scatter<24>, dim3((unsigned)w.cap_items, 1), dim3(64 * TS_WAVES), 0, st, ta);
+    if (w.g.T == SCATTER_T_MFMA) {
+        const unsigned wgs = (unsigned)((w.cap_items + MS_WAVES - 1) / MS_WAVES);
+        if (C == 24) hipLaunchKernelGGL(k_tile_scatter_mfma<24>, dim3(wgs), dim3(64 * MS_WAVES), 0, st, ta);
+        else hipLaunchKernelGGL(k_tile_scatter_mfma<48>, dim3(wgs), dim3(64 * MS_WAVES), 0, st, ta);
+    } else if (C == 24) hipLaunchKernelGGL(k_tile_scatter<24>, dim3((unsigned)w.cap_items, 1), dim3(64 * TS_WAVES), 0, st, ta);
     else hipLaunchKernelGGL(k_tile_scatter<48>, dim3((unsigned)w.cap_items, 2), dim3(64 * TS_WAVES), 0, st, ta);
     LAUNCHCK();
     return 0;

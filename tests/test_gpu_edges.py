@@ -123,6 +123,29 @@ def test_atomic_scatter_fallback_still_matches_goldens():
     assert " passed" in r.stdout
 
 
+def test_scatter_kernels_agree(tmp_path):
+    """The three plane-gradient scatters - MFMA on 4x4-texel tiles (default), LDS read-add-write on 8x8 tiles (NVFI_SCATTER=lds), global
+    atomics (NVFI_SCATTER_TILES=0) - sum the same fp32 products in different orders: all twelve plane gradients of a keyframe and a
+    non-keyframe backward agree to summation-order noise on a 37x50x41 grid (partial edge tiles on every axis)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode, env in (("mfma", dict(NVFI_SCATTER="mfma")), ("lds", dict(NVFI_SCATTER="lds")), ("atomic", dict(NVFI_SCATTER_TILES="0"))):
+        out = str(tmp_path / f"{mode}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "scatter_modes_worker.py"), out], env=dict(os.environ, **env),
+                           cwd=os.path.join(root, "tests"), capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        got[mode] = dict(np.load(out))
+    for name, ref in got["atomic"].items():
+        assert float(np.abs(ref).max()) > 0, name
+        for mode in ("mfma", "lds"):
+            err = float(np.linalg.norm(got[mode][name] - ref) / np.linalg.norm(ref))
+            worst = float(np.abs(got[mode][name] - ref).max() / np.abs(ref).max())
+            assert err < 3e-6 and worst < 1e-5, (mode, name, err, worst)
+
+
 def test_fast_activation_and_trig_error_bounds():
     """engine.h replaces libm on the hot path: `fast_sigmoid` (v_exp_f32 + v_rcp_f32) and `trig_sel` (3-constant Cody-Waite reduction +
     minimax kernels).  Direct error bounds against float64 over the argument ranges the path produces: pre-activations |z| <= 40;
@@ -216,11 +239,12 @@ def test_engine_rk2_kernels_still_match_goldens():
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("env", [dict(NVFI_WGRAD="engine"), dict(NVFI_WGRAD_CHAIN="0"), dict(NVFI_BWD_FORK="0")],
-                         ids=["wgrad_engine", "wgrad_no_chain", "no_bwd_fork"])
+@pytest.mark.parametrize("env", [dict(NVFI_WGRAD="engine"), dict(NVFI_WGRAD_CHAIN="0"), dict(NVFI_BWD_FORK="0"), dict(NVFI_SCATTER="lds")],
+                         ids=["wgrad_engine", "wgrad_no_chain", "no_bwd_fork", "scatter_lds"])
 def test_round3_switches_keep_the_goldens(env):
     """the alternatives of the round-3 defaults - the register-operand weight-gradient kernel k_wgrad instead of k_wgrad_ring8, un-chained value /
-    tangent jobs in the ring kernel, the keyframe backward on one stream instead of the forked density half - under the gradient goldens"""
+    tangent jobs in the ring kernel, the keyframe backward on one stream instead of the forked density half, the LDS read-add-write tile
+    scatter instead of the MFMA one - under the gradient goldens"""
     import os
     import subprocess
     import sys
