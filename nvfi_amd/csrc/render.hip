@@ -1080,6 +1080,7 @@ struct RenderPlan {
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     float *slabs;
     long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
+    int64_t zero_bytes;        // counters .. end of the sort histograms: zeroed by the forward's single fill
     TileWork tw; bool tiles;   // sorted-tile plane scatter (scatter.hip); tiles = false: grid too large, atomic scatter instead
     int64_t total;
 };
@@ -1095,7 +1096,14 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     const bool train = flags & NVFI_TRAIN;
     P->N = N; P->nsteps = nsteps;
     P->cap_tiles = (N + WG_SAMPLES - 1) / WG_SAMPLES * 4;   // whole workgroups: every wave of an active workgroup owns a stash tile
+    const int64_t off_counters = align_up(B.off, 256);
     P->counters = B.take<int>(16);
+    // the histograms (+ tickets) of the backward's two counting sorts sit right behind the counters: the forward's one fill zeroes all
+    // three (the scans re-zero the histograms after every use, so the backward needs no fill of its own)
+    P->tiles = train && tile_geom(f, &P->tw.g) == 0 && use_tiles() && !det_mode();
+    P->tw.hist = P->tw2.hist = nullptr;
+    if (P->tiles) { P->tw2.g = P->tw.g; P->tw.hist = B.take<int>(P->tw.g.nbins + 64); P->tw2.hist = B.take<int>(P->tw.g.nbins + 64); }
+    P->zero_bytes = align_up(B.off, 256) - off_counters;
     P->sched = B.take<float>(SCHED_FLOATS);
     P->cnt_v = B.take<int>(R); P->off_v = B.take<int>(R + 1);
     P->cnt_m = B.take<int>(R); P->off_m = B.take<int>(R + 1);
@@ -1120,7 +1128,6 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
         P->app_f = B.take<float>(P->cap_tiles * (int64_t)(APP_F_ROWS * REGF));
         P->app_b = B.take<float>(P->cap_tiles * (int64_t)(APP_B_ROWS * REGF));
         P->slabs = B.take<float>((int64_t)NSLAB_MAX * SLAB_FLOATS * 6);
-        P->tiles = tile_geom(f, &P->tw.g) == 0 && use_tiles() && !det_mode();
         P->shadow = nullptr;
         if (det_mode()) { int64_t off[12]; P->shadow = B.take<long long>(plane_elems(f, off)); }
         if (P->tiles) plan_tile_scatter(B, f, N, &P->tw);
@@ -1191,7 +1198,7 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
     const int S = f->n_samples;
     const int64_t N = P.N;
     const float tn = f->use_vel ? norm_time(*f, base) : norm_time(*f, t);
-    HIPCK(hipMemsetAsync(P.counters, 0, 16 * sizeof(int), st));
+    HIPCK(hipMemsetAsync(P.counters, 0, (size_t)P.zero_bytes, st));
     const float* sched = nullptr;
     if (t_dev) {
         if (nsteps > 4) return nvfi_fail(2, "a device-side time supports plans of up to 4 RK2 steps (t=%g needs %d)", t, nsteps);
@@ -1347,7 +1354,6 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
             if (launch_og(f, oa, 48, nsteps > 0, N, st)) return 1;
             if (fork2) { HIPCK(hipEventRecord(g_fork.fork, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork, 0)); }
             if (want_aplanes) {
-                if (tile_work_init(P.tw, s_atail)) return 1;
                 if (launch_tile_scatter(f, P.tw, P.counters + 1, P.mlist, P.xw, tn, *grads, 48, N, s_atail, sched)) return 1;
             }
         }
@@ -1406,7 +1412,6 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         if (fork2) { HIPCK(hipEventRecord(g_fork.fork2, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork2, 0)); }
         if (want_dplanes) {
             ProfScope ps(PK_DENSITY_SCATTER, s_dtail);
-            if ((fork || fork2 || !want_aplanes) && tile_work_init(twd, s_dtail)) return 1;
             if (launch_tile_scatter(f, twd, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, s_dtail, sched)) return 1;
         }
         if (fork) { HIPCK(hipEventRecord(g_fork.join, g_fork.s)); HIPCK(hipStreamWaitEvent(st, g_fork.join, 0)); }

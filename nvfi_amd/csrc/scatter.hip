@@ -702,7 +702,8 @@ int64_t tile_items_cap(const TileGeom& g, int64_t N) { return 3 * ((N + g.chunk 
 
 void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w) {
     tile_geom(f, &w->g);
-    w->hist = B.take<int>(w->g.nbins + 64); w->cursor = B.take<int>(w->g.nbins); w->nitems = B.take<int>(4);   // hist[nbins]: ticket of k_tile_hist's last-workgroup scan
+    if (!w->hist) w->hist = B.take<int>(w->g.nbins + 64);      // (render.hip takes the histograms itself, next to its counters)
+    w->cursor = B.take<int>(w->g.nbins); w->nitems = B.take<int>(4);   // hist[nbins]: ticket of k_tile_hist's last-workgroup scan
     w->start = B.take<int>(w->g.nbins + 1); w->istart = B.take<int>(w->g.nbins + 1);
     w->items = B.take<int4>(tile_items_cap(w->g, N));
     w->sorted = B.take<float4>(3 * N);
@@ -710,12 +711,8 @@ void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w
     w->cap_items = tile_items_cap(w->g, N);
 }
 
-// histogram storage (and its ticket) must be zero before the first k_tile_hist of a workspace; the scan re-zeroes both after every use
-int tile_work_init(const TileWork& w, hipStream_t st) {
-    // (a size that is a multiple of 256 bytes is ONE fill kernel; an odd size is split into an aligned part and a tail: two launches)
-    HIPCK(hipMemsetAsync(w.hist, 0, (sizeof(int) * (w.g.nbins + 1) + 255) / 256 * 256, st));
-    return 0;
-}
+// histogram storage (and its ticket, hist[nbins]) must be zero before the first k_tile_hist of a workspace - the forward's fill of the
+// counters covers it (render.hip: plan_render) - and the scan re-zeroes both after every use
 
 int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int64_t N, hipStream_t st) {
     const int spw = C == 24 ? 32 : 16;
