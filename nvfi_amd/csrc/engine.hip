@@ -204,27 +204,43 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_wgrad(WgradJobs jobs) {
 #ifndef REDUCE_BLOCKS
 #define REDUCE_BLOCKS 260
 #endif
-// 64 G entries per workgroup; 4 threads per entry each sum a quarter of the slabs
+// 128 G entries per workgroup as 32 float4 columns; 8 thread groups each sum an eighth of the slabs (16-byte loads, eight in flight per
+// thread: the 4-byte, one-at-a-time version ran at 2.8 TB/s), then thread (g < 4, q) finishes component g of column q
 __global__ __launch_bounds__(256) void k_wgrad_reduce(ReduceJobs jobs) {
-    __shared__ float part[4][64];
+    __shared__ float4 part[8][32];
     const ReduceJob& J = jobs.j[blockIdx.y];
     const int a_rows = 32 * J.MTA, b_rows = 32 * J.KTB;
-    const size_t slab = (size_t)a_rows * b_rows + a_rows;
+    const size_t slab = (size_t)a_rows * b_rows + a_rows;       // (a multiple of 32 floats)
     const int total = a_rows * b_rows + a_rows;
-    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int q = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int start = J.gW ? 0 : a_rows * b_rows;   // bias-only job: skip the weight entries
-    for (int base = start + blockIdx.x * 64; base < total; base += gridDim.x * 64) {
-        const int idx = base + e;
-        float s = 0.f;
-        if (idx < total) {
-            for (int k = g; k < J.nslab; k += 4) s += J.slabs[(size_t)k * slab + idx];
-            if (J.slabs2) for (int k = g; k < J.nslab2; k += 4) s += J.slabs2[(size_t)k * slab + idx];
+    for (int base = start + blockIdx.x * 128; base < total; base += gridDim.x * 128) {
+        const int idx4 = base + 4 * q;
+        float4 s = zero4();
+        if (idx4 < total) {
+            auto sum = [&](const float* sl, int ns) {
+                int k = g;
+                for (; k + 56 < ns; k += 64) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = ld4(sl + (size_t)(k + 8 * u) * slab + idx4);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+                }
+                for (; k < ns; k += 8) { const float4 v = ld4(sl + (size_t)k * slab + idx4); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+            };
+            sum(J.slabs, J.nslab);
+            if (J.slabs2) sum(J.slabs2, J.nslab2);
         }
         __syncthreads();
-        part[g][e] = s;
+        part[g][q] = s;
         __syncthreads();
-        if (g == 0 && idx < total) {
-            s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        const int idx = idx4 + g;
+        if (g < 4 && idx4 < total) {
+            const float* pp = reinterpret_cast<const float*>(&part[0][q]) + g;
+            float r = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r += pp[u * 32 * 4];
             int pA, pB = -1;
             if (idx < a_rows * b_rows) { pA = idx / b_rows; pB = idx - pA * b_rows; }
             else pA = idx - a_rows * b_rows;
@@ -234,8 +250,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(ReduceJobs jobs) {
                 if (pB >= 0) {
                     const int in = slot_logical(J.slot_kind, pB);
                     // atomic: launches on different streams (the two renders and the PDE term of a step) may accumulate into the same gradient
-                    if (in >= 0 && in < J.in && J.gW) atomicAdd(&J.gW[(size_t)o * J.in + in], J.scale * s);
-                } else if (J.gb) atomicAdd(&J.gb[o], J.scale * s);
+                    if (in >= 0 && in < J.in && J.gW) atomicAdd(&J.gW[(size_t)o * J.in + in], J.scale * r);
+                } else if (J.gb) atomicAdd(&J.gb[o], J.scale * r);
             }
         }
     }
