@@ -58,6 +58,7 @@ struct AppArgs {
     const float* sched;
     const float* rays_d; const float* view_per_point;
     float4* rgbs; int rgb_dense;
+    const float* feat48;   // (M,48) plane-product features of the masked samples by compact index (k_app_feat): no plane gather in k_app_fwd
     const float* feat_in;  // (N, app_dim) appearance features given by the caller (renderModule as a stand-alone call): no plane gather, no basis_mat
     float* stash_f; float* stash_b;
     // backward

@@ -379,13 +379,23 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
     }
     float x[64];
     float* scr = lds_w + SCR_OFF;
-    if (!a.feat_in) {
-        Bl b[6];
-        plane_setups(f, q.x, q.y, q.z, tn, b);
-        app_gather_to_scratch(f, b, h, scr);
-    }
+    if (a.feat48) {
+        // lane (j,h) holds channels 4*(2a+h)+c, a=0..5, of its sample
+        const float* fp = a.feat48 + (size_t)(active ? i : 0) * 48 + 4 * h;
 #pragma unroll
-    for (int s = 0; s < 24; ++s) x[s] = a.feat_in ? 0.f : scr[s * 256 + threadIdx.x];
+        for (int a6 = 0; a6 < 6; ++a6) {
+            const float4 v = active ? ld4(fp + 8 * a6) : zero4();
+            x[4 * a6 + 0] = v.x; x[4 * a6 + 1] = v.y; x[4 * a6 + 2] = v.z; x[4 * a6 + 3] = v.w;
+        }
+    } else {
+        if (!a.feat_in) {
+            Bl b[6];
+            plane_setups(f, q.x, q.y, q.z, tn, b);
+            app_gather_to_scratch(f, b, h, scr);
+        }
+#pragma unroll
+        for (int s = 0; s < 24; ++s) x[s] = a.feat_in ? 0.f : scr[s * 256 + threadIdx.x];
+    }
     float* st = STASH ? a.stash_f + (size_t)tile * (APP_F_ROWS * REGF) : nullptr;
     if (STASH) {
 #pragma unroll
@@ -1089,6 +1099,7 @@ static int nslab_rt() { static int n = -1; if (n < 0) { const char* e = getenv("
 #define NSLAB (nslab_rt())
 #define SLAB_FLOATS (128 * 128 + 128)
 
+static bool app_feat_split() { static int u = -1; if (u < 0) { const char* e = getenv("NVFI_APP_FEAT"); u = e ? atoi(e) : 1; } return u != 0; }
 static bool use_tiles() { static int u = -1; if (u < 0) { const char* e = getenv("NVFI_SCATTER_TILES"); u = e ? atoi(e) : 1; } return u != 0; }
 static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nsteps, void* ws, RenderPlan* P) {
     Bump B{(char*)ws, 0, 0};
@@ -1266,6 +1277,13 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
     const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
     {
         ProfScope ps(PK_APP_FWD, st);
+        // train: the plane-product features of the masked samples from their own gather kernel (parked in gg, which only the backward writes)
+        if (train && f->Ca == 48 && app_feat_split()) {
+            OgArgs oa; memset(&oa, 0, sizeof(oa));
+            oa.f = *f; oa.count = P.counters + 1; oa.list = P.mlist; oa.xw = P.xw; oa.tn = tn; oa.sched = sched; oa.og = P.gg;
+            if (launch_app_feat(oa, N, st)) return 1;
+            aa.feat48 = P.gg;
+        }
         if (launch_app_fwd(aa, N, train, st)) return 1;
     }
     // composite

@@ -56,4 +56,5 @@ void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w
 int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int64_t N, hipStream_t st);
 int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* count, const int* list, const float4* xw, float tn,
                         const nvfi_grads& g, int C, int64_t N, hipStream_t st, const float* sched = nullptr);
+int launch_app_feat(const OgArgs& oa, int64_t N, hipStream_t st);   // oa.og: feat[i][48], the appearance feature of masked sample i (Ca == 48)
 int launch_density_q(const DensityArgs& da, int64_t N, hipStream_t st);   // Cd == 24 only

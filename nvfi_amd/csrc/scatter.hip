@@ -144,6 +144,44 @@ __global__ __launch_bounds__(256) void k_og(OgArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- k_app_feat
+// The 48-channel appearance feature (product of the six plane samples, tensorf_keyframe.py:274-310) of every masked sample, with the lanes
+// of k_og: 16 per sample, 12 active, one channel quad each - a wave instruction covers the 192 contiguous bytes of a texel for four
+// samples.  Inside k_app_fwd (lane = sample, two quads per pass, six passes) the same taps cost six dependent round trips and used 32 of
+// every 128 bytes fetched per pass; feat[i][48] (compact index) is read back there with six 16-byte loads per lane.
+__global__ __launch_bounds__(256) void k_app_feat(OgArgs a) {
+    constexpr int LPS = 16, NQ = 12, SPW = 256 / LPS;
+    const nvfi_field_desc& f = a.f;
+    const int count = *a.count;
+    const int sub = threadIdx.x % LPS;
+    const int i = blockIdx.x * SPW + threadIdx.x / LPS;
+    if (blockIdx.x * SPW >= count) return;
+    const bool act = i < count && sub < NQ;
+    const int ic = i < count ? i : count - 1;
+    const int n = a.list[ic];
+    const float4 q = a.xw[n];
+    const int qd = sub < NQ ? sub : 0;
+    Bl b[6];
+    plane_setups(f, q.x, q.y, q.z, SCHED_TN(a), b);
+    const float* pl[6] = {f.aps[0], f.aps[1], f.aps[2], f.apt[0], f.apt[1], f.apt[2]};
+    float4 v[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) v[p] = bl_sample4(pl[p], f.Ca, b[p], qd);
+    if (act) {
+        float4 o;       // (same association as the in-kernel gather of k_app_fwd)
+        o.x = ((v[0].x * v[1].x) * v[2].x) * ((v[3].x * v[4].x) * v[5].x);
+        o.y = ((v[0].y * v[1].y) * v[2].y) * ((v[3].y * v[4].y) * v[5].y);
+        o.z = ((v[0].z * v[1].z) * v[2].z) * ((v[3].z * v[4].z) * v[5].z);
+        o.w = ((v[0].w * v[1].w) * v[2].w) * ((v[3].w * v[4].w) * v[5].w);
+        *reinterpret_cast<float4*>(a.og + (size_t)i * 48 + 4 * qd) = o;
+    }
+}
+int launch_app_feat(const OgArgs& oa, int64_t N, hipStream_t st) {
+    hipLaunchKernelGGL(k_app_feat, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, st, oa);
+    LAUNCHCK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- k_density_q
 // compute_densityfeature + density_shift (+ softplus) with lanes = (sample, channel quad): 8 lanes per sample, 6 active.
 __global__ __launch_bounds__(256) void k_density_q(DensityArgs a) {
