@@ -1181,6 +1181,7 @@ static int ensure_render_attrs() {
     HIPCK(hipFuncSetAttribute((const void*)k_app_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     HIPCK(hipFuncSetAttribute((const void*)k_app_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     HIPCK(hipFuncSetAttribute((const void*)k_app_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    if (ensure_scatter_attrs()) return 1;
     done = true;
     return 0;
 }

@@ -53,6 +53,7 @@ struct TileScatterArgs {
 
 int tile_geom(const nvfi_field_desc* f, TileGeom* g);
 void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w);
+int ensure_scatter_attrs();
 int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int64_t N, hipStream_t st);
 int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* count, const int* list, const float4* xw, float tn,
                         const nvfi_grads& g, int C, int64_t N, hipStream_t st, const float* sched = nullptr);

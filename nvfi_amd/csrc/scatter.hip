@@ -752,6 +752,15 @@ void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w
 // histogram storage (and its ticket, hist[nbins]) must be zero before the first k_tile_hist of a workspace - the forward's fill of the
 // counters covers it (render.hip: plan_render) - and the scan re-zeroes both after every use
 
+// k_tile_hist's scan uses up to 70 KB of dynamic LDS (8192 bins): raised once, from the entry points (never inside a stream capture)
+int ensure_scatter_attrs() {
+    static bool done = false;
+    if (done) return 0;
+    HIPCK(hipFuncSetAttribute((const void*)k_tile_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    done = true;
+    return 0;
+}
+
 int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int64_t N, hipStream_t st) {
     const int spw = C == 24 ? 32 : 16;
     const unsigned blocks = (unsigned)((N + spw - 1) / spw);
@@ -773,8 +782,6 @@ int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* 
     const int nb = w.g.nbins;
     unsigned hb = (unsigned)((N + 511) / 512); if (hb > 512) hb = 512;
     const size_t hist_lds = sizeof(int) * 2 * (size_t)(nb + (nb >> 4) + 1);      // the histogram, then the scan's two transposed rows
-    static bool big_lds = false;
-    if (!big_lds) { HIPCK(hipFuncSetAttribute((const void*)k_tile_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); big_lds = true; }
     hipLaunchKernelGGL(k_tile_hist, dim3(hb), dim3(512), hist_lds, st, sa);
     hipLaunchKernelGGL(k_tile_fill, dim3((unsigned)((N + 511) / 512)), dim3(512), sizeof(int) * 2 * nb, st, sa);
     TileScatterArgs ta; memset(&ta, 0, sizeof(ta));
