@@ -1,6 +1,6 @@
 """Worker of test_gpu_edges.py::test_scatter_kernels_agree: the plane gradients of one training backward (a keyframe time and a
 non-keyframe time, grid sizes that are not multiples of the tile edge) for the scatter kernel selected by the environment
-(NVFI_SCATTER / NVFI_SCATTER_TILES are read once per process).  usage: scatter_modes_worker.py <out.npz>"""
+(NVFI_SCATTER / NVFI_SCATTER_TILES are read once per process).  usage: scatter_modes_worker.py <out.npz> [Gx Gy Gz]"""
 import sys
 
 import numpy as np
@@ -9,10 +9,10 @@ import torch
 from helpers import make_model
 
 
-def main(out):
+def main(out, grid=(37, 50, 41)):
     model, meta = make_model("A")
     f = model.nvfi
-    f.upsample_volume_grid([37, 50, 41], int(meta["num_keyframes"]))
+    f.upsample_volume_grid([int(g) for g in grid], int(meta["num_keyframes"]))
     f.train()
     g = torch.Generator().manual_seed(11)
     n = 3000
@@ -34,4 +34,4 @@ def main(out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], tuple(sys.argv[2:5]) if len(sys.argv) >= 5 else (37, 50, 41))

@@ -123,10 +123,12 @@ def test_atomic_scatter_fallback_still_matches_goldens():
     assert " passed" in r.stdout
 
 
-def test_scatter_kernels_agree(tmp_path):
+@pytest.mark.parametrize("grid", [(37, 50, 41), (7, 5, 9), (130, 97, 61)])
+def test_scatter_kernels_agree(tmp_path, grid):
     """The three plane-gradient scatters - MFMA on 4x4-texel tiles (default), LDS read-add-write on 8x8 tiles (NVFI_SCATTER=lds), global
     atomics (NVFI_SCATTER_TILES=0) - sum the same fp32 products in different orders: all twelve plane gradients of a keyframe and a
-    non-keyframe backward agree to summation-order noise on a 37x50x41 grid (partial edge tiles on every axis)."""
+    non-keyframe backward agree to summation-order noise on grids with partial edge tiles on every axis (37x50x41, 130x97x61) and on one
+    with fewer texels than a tile along an axis (7x5x9)."""
     import os
     import subprocess
     import sys
@@ -134,7 +136,7 @@ def test_scatter_kernels_agree(tmp_path):
     got = {}
     for mode, env in (("mfma", dict(NVFI_SCATTER="mfma")), ("lds", dict(NVFI_SCATTER="lds")), ("atomic", dict(NVFI_SCATTER_TILES="0"))):
         out = str(tmp_path / f"{mode}.npz")
-        r = subprocess.run([sys.executable, os.path.join(root, "tests", "scatter_modes_worker.py"), out], env=dict(os.environ, **env),
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "scatter_modes_worker.py"), out] + [str(g) for g in grid], env=dict(os.environ, **env),
                            cwd=os.path.join(root, "tests"), capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         got[mode] = dict(np.load(out))
