@@ -18,9 +18,9 @@
 //                 an item is the small GEMM  G[texel][channel] = sum_s W[texel][s] * og[s][channel]  on v_mfma_f32_16x16x4_f32 (exact
 //                 fp32 products, fp32 accumulation): 25 tile + apron texels = two 16-row tiles, the 2x5 strip of the paired time
 //                 plane a third, 24 / 48 channels = 2 / 3 column tiles.  The tile gradient lives in accumulators and is flushed
-//                 with global atomics from registers; the time strips of the 8 waves of a workgroup - consecutive items, which share
+//                 with global atomics from registers; the time strips of the 4 waves of a workgroup - consecutive items, which share
 //                 tile columns because the bins of planes 0 and 2 are numbered column by column - are summed in LDS first.
-//                 52 / 48 us per call (C = 48 / 24) against 104 / 92 us for the LDS kernel on the stationary bench workload.
+//                 49 / 44 us per call (C = 48 / 24) against 104 / 92 us for the LDS kernel on the stationary bench workload.
 //   k_tile_scatter (NVFI_SCATTER=lds, and grids with more than 8192 4x4 tiles)   ONE WAVE per (plane, 8x8-texel tile, chunk of
 //                 samples): the tile (+1 texel apron) of the space plane and the matching
 //                 strip of the paired time plane live in LDS and are updated with PLAIN read-add-write - a single wave executes
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_scatter(TileScatterArgs 
 // No workgroup barrier: the four waves of a workgroup own separate items, records and accumulators and flush with global atomics from
 // registers (16 lanes = 16 consecutive channels of one texel).
 #ifndef MS_WAVES
-#define MS_WAVES 8
+#define MS_WAVES 4      // (2: same; 8: +4 us per call, 16: +10 us - the workgroup waits for its slowest item at the barrier)
 #endif
 // timing experiments (tools/r03_scatter_bisect.sh): MSX_NOLOOP=1 skips the MFMA loop, MSX_NOFLUSH=1/2/3 skips all / the time / the space atomics
 #ifndef MSX_NOLOOP
@@ -690,8 +690,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void k_tile_scatter_mfma(TileScatter
     __syncthreads();
     if (MSX_NOFLUSH == 1 || MSX_NOFLUSH == 2) return;
     // thread (texel r, channel c) walks the waves in order and sends one sum per run of equal strip ids
-    const int tid = threadIdx.x;
-    if (tid < 10 * 16 * NCT) {
+    for (int tid = threadIdx.x; tid < 10 * 16 * NCT; tid += 64 * MS_WAVES) {
         const int c = tid % (16 * NCT), r = tid / (16 * NCT);
         float sum = 0.f;
         int cur = -1;
