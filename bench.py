@@ -935,8 +935,9 @@ def main():
                           and not os.environ.get("NVFI_BENCH_CHILD") and os.environ.get("NVFI_PDE_PREFILTER", "fp32") == "fp32")
     if default_invocation:
         import subprocess
-        def extra(extra_args, env=None):
-            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
+        def extra(extra_args, env=None, steps_factor=1):
+            # (the radiance-only step is 0.8 ms: K = 20 steps are a 16 ms timed region, shorter than the clock ramp of an idle GPU - 10 K there)
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps * steps_factor), "--warmup", str(args.warmup * steps_factor), "--no-cpu-baseline",
                    "--profile-steps", "0", "--no-extras", "--rays", str(args.rays), "--pts", str(args.pts), "--grid", str(args.grid),
                    "--samples", str(args.samples)] + extra_args
             try:
@@ -949,7 +950,7 @@ def main():
         out["extras"] = {
             "dropin": dict(extra(["--mode", "dropin"]), what="the loop body of the reference's train_nvfi.py:139-249 verbatim on the `models` alias (plain autograd, "
                            "torch.optim.Adam, reference-signature regularisers, the per-iteration .item() waits): what tools/run_reference_driver.py gets"),
-            "cfg2_radiance_only": dict(extra(["--workload", "cfg2", "--graph", "off"]), what="BASELINE configs[1]: bat.yaml radiance-only, 2048-ray batches, HBM-bound (gathers / scatters)"),
+            "cfg2_radiance_only": dict(extra(["--workload", "cfg2", "--graph", "off"], steps_factor=10), what="BASELINE configs[1]: bat.yaml radiance-only, 2048-ray batches, HBM-bound (gathers / scatters); 10 K steps"),
             "optin_split16band_prefilter": dict(extra(["--graph", "off"], {"NVFI_PDE_PREFILTER": "split16band"}),
                                                 what="opt-in (NOT the headline): the PDE occupancy prefilter with fp32 products emulated on the fp16 matrix pipe (two binary16 "
                                                      "terms per operand, three MFMAs, fp32 accumulation: ~2^-21 relative per product) + an fp32 re-evaluation band of 0.1 %; "
