@@ -691,7 +691,8 @@ __device__ __forceinline__ float dpp_xor1(float v) { return __shfl_xor(v, 1); }
 #define DET_SCALE 1125899906842624.0      /* 2^50: +-8192 of range, 8.9e-16 of resolution */
 template <bool DET>
 __device__ __forceinline__ void grad_add(float* g, size_t idx, float v) {
-    if (DET) atomicAdd(reinterpret_cast<unsigned long long*>(g) + idx, (unsigned long long)__double2ll_rn((double)v * DET_SCALE));
+    // (a single contribution saturates at the int64 range instead of wrapping; running SUMS beyond +-8192 still wrap - test mode)
+    if (DET) atomicAdd(reinterpret_cast<unsigned long long*>(g) + idx, (unsigned long long)__double2ll_rn(fmin(fmax((double)v * DET_SCALE, -9.2e18), 9.2e18)));
     else atomicAdd(g + idx, v);
 }
 __global__ void k_det_finish(const long long* __restrict__ shadow, float* __restrict__ g, int64_t n) {

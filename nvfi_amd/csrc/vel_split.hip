@@ -128,11 +128,124 @@ __device__ __forceinline__ void velnet_split(const float4* const* f4, float4* xc
         for (int r = 0; r < 4; ++r) out4[t][r] = bc[(t * 4 + r) * 64 + lane];
 }
 
-template <int NT>
-__global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
+// ---------------------------------------------------------------- the same evaluation with the 128 -> 6 OUTPUT layer on the vector pipe
+// On the matrix pipe the output layer is 64 MFMAs of a 32-row tile that holds 6 useful rows, issued by one wave per tile while the
+// other waves of the workgroup wait at the barrier behind it: 10 % of an evaluation's critical path for 0.5 % of its arithmetic.
+// Here every lane multiplies the 16 activations of the last hidden layer it already holds in registers (its point i, features
+// 32 w + (r & 3) + 8 (r >> 2) + 4 h) with the matching 16 x 6 output weights (LDS image [w][h][r][8], 4 KB), the two halves meet by
+// one cross-lane add, the four waves' partial sums by one trip through LDS (8 KB, added in wave order by every wave: replicated state
+// stays bit-identical across the workgroup), and the last hidden layer's activations never go to the exchange buffer.
+// fp32 FMAs in a fixed order instead of the MFMA's products and sums: the same arithmetic, another rounding (1e-7 relative).
+#define SPLIT_VOUT_LDS_BYTES(NT) ((NT) * (SPLIT_XCH_F4 * 16 + 4 * 2 * 32 * 16) + 6 * 128 * 4 + 4 * 2 * 16 * 8 * 4)
+template <int NT, bool STASH = false>
+__device__ __forceinline__ void velnet_split_vout(const float4* const* f4, float4* xch, float4* part, const float4* w5l, int w, int lane, int h,
+                                                  const float4* q, float4* wq, const float* lb, float (&out6)[NT][6],
+                                                  float* const* zst = nullptr, float* const* x0st = nullptr) {
+    f32x16 acc[NT];
+    const float4* xl = xch + lane;
+    {
+        float in0[NT][16];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            vel_encode_slots(q[t], h, in0[t]);
+            if (STASH && w == t) stash_store<16>(x0st[t], lane, in0[t]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = lb[32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+        }
+        split_mfma<4, NT, 16>(wq, in0, acc);             // wq holds layer 0 (loaded by the caller / the previous evaluation)
+    }
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        split_load<16>(f4[l + 1] + (size_t)w * 16 * 64, lane, wq);
+        if (STASH) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane] = acc[t][r];
+        }
+        __syncthreads();                                 // the previous layer's readers of the exchange buffer are done
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                xch[(t * 16 + 4 * w + k) * 64 + lane] = make_float4(act_f<1>(acc[t][4 * k]), act_f<1>(acc[t][4 * k + 1]), act_f<1>(acc[t][4 * k + 2]),
+                                                                    act_f<1>(acc[t][4 * k + 3]));
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = lb[128 * (l + 1) + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+        split_mfma_lds<NT>(wq, xl, 0, acc);
+    }
+    // layer 0 of the NEXT evaluation (the caller stops using wq before that)
+    split_load<4>(f4[0] + (size_t)w * 4 * 64, lane, wq);
+    if (STASH) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zst[t][(size_t)(4 * 64 + 16 * w + r) * REGF + lane] = acc[t][r];
+    }
+    float p[NT][6];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int o = 0; o < 6; ++o) p[t][o] = 0.f;
+    const float4* wl = w5l + (w * 2 + h) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if ((r & 1) == 0) __builtin_amdgcn_sched_barrier(0);     // weight reads in groups of two rows (all 32 at once cost 128 registers)
+        const float4 wa = wl[2 * r], wb = wl[2 * r + 1];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float av = act_f<1>(acc[t][r]);
+            p[t][0] = __builtin_fmaf(av, wa.x, p[t][0]); p[t][1] = __builtin_fmaf(av, wa.y, p[t][1]); p[t][2] = __builtin_fmaf(av, wa.z, p[t][2]);
+            p[t][3] = __builtin_fmaf(av, wa.w, p[t][3]); p[t][4] = __builtin_fmaf(av, wb.x, p[t][4]); p[t][5] = __builtin_fmaf(av, wb.y, p[t][5]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int o = 0; o < 6; ++o) p[t][o] += __shfl_xor(p[t][o], 32);
+        if (h == 0) {
+            part[((t * 4 + w) * 2 + 0) * 32 + lane] = make_float4(p[t][0], p[t][1], p[t][2], p[t][3]);
+            part[((t * 4 + w) * 2 + 1) * 32 + lane] = make_float4(p[t][4], p[t][5], 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int o = 0; o < 6; ++o) out6[t][o] = lb[128 * 5 + o];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            __builtin_amdgcn_sched_barrier(0);                        // (all sixteen reads of a two-tile workgroup at once cost 64 registers)
+            const float4 A = part[((t * 4 + ww) * 2 + 0) * 32 + (lane & 31)], B = part[((t * 4 + ww) * 2 + 1) * 32 + (lane & 31)];
+            out6[t][0] += A.x; out6[t][1] += A.y; out6[t][2] += A.z; out6[t][3] += A.w; out6[t][4] += B.x; out6[t][5] += B.y;
+        }
+    }
+}
+
+template <int NT, bool VOUT, bool STASH = false>
+__device__ __forceinline__ void velnet_any(const float4* const* f4, float4* xch, float4* part, float* bc, const float4* w5l, int w, int owner, int lane,
+                                           int h, const float4* q, float4* wq, const float* lb, float (&out6)[NT][6],
+                                           float* const* zst = nullptr, float* const* x0st = nullptr) {
+    if (VOUT) velnet_split_vout<NT, STASH>(f4, xch, part, w5l, w, lane, h, q, wq, lb, out6, zst, x0st);
+    else {
+        float o4[NT][4];
+        velnet_split<NT, STASH>(f4, xch, bc, w, owner, lane, h, q, wq, lb, o4, zst, x0st);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gather6(o4[t], h, out6[t]);
+    }
+}
+
+// VOUT: the output layer on the vector pipe (default); false: on the matrix pipe like every other layer (NVFI_SPLIT_VOUT=0: bit-identical
+// to k_rk2_fwd<false, false> of vel.hip)
+template <int NT, bool VOUT>
+__global__ __launch_bounds__(WG_THREADS, NT <= 2 ? 3 : 2) void k_rk2_split(SplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* xch = reinterpret_cast<float4*>(lds);
-    float* bc = lds + NT * SPLIT_XCH_F4 * 4;
+    float4* part = xch + NT * SPLIT_XCH_F4;               // VOUT: [tile][wave][2][32 points] partial output sums; else the 4 x 64 broadcast rows
+    float* bc = reinterpret_cast<float*>(part);
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int owner = blockIdx.x & 3;
@@ -153,8 +266,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
     float4 wq[16];
     split_load<4>(a.f4[0] + (size_t)w * 4 * 64, lane, wq);
     // the six bias vectors live in LDS for the whole kernel (3 KB; rows beyond a layer's width read as the fragment's zero padding)
-    float* lb = bc + NT * 4 * 64;
+    float* lb = VOUT ? reinterpret_cast<float*>(part + NT * 4 * 2 * 32) : bc + NT * 4 * 64;
     for (int k = threadIdx.x; k < 6 * 128; k += WG_THREADS) lb[k] = (k & 127) < (k < 640 ? 128 : 32) ? a.bv[k >> 7][k & 127] : 0.f;
+    // ... and (VOUT) the output layer's weights in the order the lanes hold the last hidden layer: [w][h][r][8] (6 outputs + 2 zeros)
+    float* w5f = lb + 6 * 128;
+    if (VOUT)
+        for (int k = threadIdx.x; k < 4 * 2 * 16 * 8; k += WG_THREADS) {
+            const int o = k & 7, r = (k >> 3) & 15, hh = (k >> 7) & 1, ww = k >> 8;
+            w5f[k] = o < 6 ? a.f.vW[5][o * 128 + 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
+        }
+    const float4* w5l = reinterpret_cast<const float4*>(w5f);
     __syncthreads();
 #pragma unroll 1
     for (int s = 0; s < a.max_steps; ++s) {
@@ -168,26 +289,26 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
             dt[t] = off[t] > 0.f ? m : (off[t] < 0.f ? -m : 0.f);
         }
         if (!__any(any)) break;                           // the same decision in all four waves (replicated state)
-        float o4[NT][4], px[NT], py[NT], pz[NT];
+        float o6[NT][6], px[NT], py[NT], pz[NT];
         float4 q[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur[t]);
-        velnet_split<NT>(a.f4, xch, bc, w, owner, lane, h, q, wq, lb, o4);
+        velnet_any<NT, VOUT>(a.f4, xch, part, bc, w5l, w, owner, lane, h, q, wq, lb, o6);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float w1[6], v1[3];
-            gather6(o4[t], h, w1);
+            float v1[3];
+            const float* w1 = o6[t];
             vel_from_w(w1, x[t], y[t], z[t], v1);
             if (gated_out(a.f, x[t], y[t], z[t])) { v1[0] = v1[1] = v1[2] = 0.f; }
             const float hdt = 0.5f * dt[t];
             px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
             q[t] = make_float4(px[t], py[t], pz[t], tcur[t] - hdt);
         }
-        velnet_split<NT>(a.f4, xch, bc, w, owner, lane, h, q, wq, lb, o4);
+        velnet_any<NT, VOUT>(a.f4, xch, part, bc, w5l, w, owner, lane, h, q, wq, lb, o6);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float w2[6], v2[3];
-            gather6(o4[t], h, w2);
+            float v2[3];
+            const float* w2 = o6[t];
             vel_from_w(w2, px[t], py[t], pz[t], v2);
             if (gated_out(a.f, px[t], py[t], pz[t])) { v2[0] = v2[1] = v2[2] = 0.f; }
             const float nx = x[t] - dt[t] * v2[0], ny = y[t] - dt[t] * v2[1], nz = z[t] - dt[t] * v2[2];
@@ -203,11 +324,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split(SplitArgs a) {
 
 // ---------------------------------------------------------------- render warp: every sample takes the same (dt_s, t_s) sequence
 // (k_rk2_fwd<true, STASH> of vel.hip on the feature-split layout; same stash, same records, same numbers)
-template <int NT, bool STASH>
-__global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split_uni(SplitUniArgs a) {
+template <int NT, bool STASH, bool VOUT>
+__device__ __forceinline__ void rk2_split_uni_body(const SplitUniArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* xch = reinterpret_cast<float4*>(lds);
-    float* bc = lds + NT * SPLIT_XCH_F4 * 4;
+    float4* part = xch + NT * SPLIT_XCH_F4;
+    float* bc = reinterpret_cast<float*>(part);
     const Rk2Args& ra = a.r;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -226,8 +348,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split_uni(SplitUniArgs a)
     }
     float4 wq[16];
     split_load<4>(a.f4[0] + (size_t)w * 4 * 64, lane, wq);
-    float* lb = bc + NT * 4 * 64;
+    float* lb = VOUT ? reinterpret_cast<float*>(part + NT * 4 * 2 * 32) : bc + NT * 4 * 64;
     for (int k = threadIdx.x; k < 6 * 128; k += WG_THREADS) lb[k] = (k & 127) < (k < 640 ? 128 : 32) ? a.bv[k >> 7][k & 127] : 0.f;
+    float* w5f = lb + 6 * 128;
+    if (VOUT)
+        for (int k = threadIdx.x; k < 4 * 2 * 16 * 8; k += WG_THREADS) {
+            const int o = k & 7, r = (k >> 3) & 15, hh = (k >> 7) & 1, ww = k >> 8;
+            w5f[k] = o < 6 ? ra.f.vW[5][o * 128 + 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
+        }
+    const float4* w5l = reinterpret_cast<const float4*>(w5f);
     __syncthreads();
 #pragma unroll 1
     for (int s = 0; s < ra.nsteps; ++s) {
@@ -240,27 +369,28 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split_uni(SplitUniArgs a)
             z1[t] = STASH ? ra.zst + e1 * (VEL_Z_REGS * REGF) : nullptr; z2[t] = STASH ? ra.zst + e2 * (VEL_Z_REGS * REGF) : nullptr;
             x1[t] = STASH ? ra.x0st + e1 * (VEL_X0_REGS * REGF) : nullptr; x2[t] = STASH ? ra.x0st + e2 * (VEL_X0_REGS * REGF) : nullptr;
         }
-        float o4[NT][4], px[NT], py[NT], pz[NT], w1[NT][6];
+        float o6[NT][6], px[NT], py[NT], pz[NT], w1[NT][6];
         bool g1[NT];
         float4 q[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur);
-        velnet_split<NT, STASH>(a.f4, xch, bc, w, owner, lane, h, q, wq, lb, o4, z1, x1);
+        velnet_any<NT, VOUT, STASH>(a.f4, xch, part, bc, w5l, w, owner, lane, h, q, wq, lb, o6, z1, x1);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v1[3];
-            gather6(o4[t], h, w1[t]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w1[t][k] = o6[t][k];
             vel_from_w(w1[t], x[t], y[t], z[t], v1);
             g1[t] = gated_out(ra.f, x[t], y[t], z[t]);
             if (g1[t]) { v1[0] = v1[1] = v1[2] = 0.f; }
             px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
             q[t] = make_float4(px[t], py[t], pz[t], tcur - hdt);
         }
-        velnet_split<NT, STASH>(a.f4, xch, bc, w, owner, lane, h, q, wq, lb, o4, z2, x2);
+        velnet_any<NT, VOUT, STASH>(a.f4, xch, part, bc, w5l, w, owner, lane, h, q, wq, lb, o6, z2, x2);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float w2[6], v2[3];
-            gather6(o4[t], h, w2);
+            float v2[3];
+            const float* w2 = o6[t];
             vel_from_w(w2, px[t], py[t], pz[t], v2);
             const bool g2 = gated_out(ra.f, px[t], py[t], pz[t]);
             if (g2) { v2[0] = v2[1] = v2[2] = 0.f; }
@@ -281,14 +411,27 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split_uni(SplitUniArgs a)
     for (int t = 0; t < NT; ++t)
         if (active[t] && h == 0 && w == 0) ra.xw[n[t]] = make_float4(x[t], y[t], z[t], zw[t]);
 }
+template <int NT, bool STASH, bool VOUT>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_split_uni(SplitUniArgs a) { rk2_split_uni_body<NT, STASH, VOUT>(a); }
 
 int launch_rk2_split_uni(const SplitUniArgs& a, int64_t cap_samples, bool stash, hipStream_t st) {
     const int64_t tiles = (cap_samples + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
     ProfScope ps(PK_RK2_FWD, st);
     const dim3 g((unsigned)((tiles + 1) / 2)), b(WG_THREADS);
-    if (stash) hipLaunchKernelGGL((k_rk2_split_uni<2, true>), g, b, SPLIT_LDS_BYTES(2), st, a);
-    else hipLaunchKernelGGL((k_rk2_split_uni<2, false>), g, b, SPLIT_LDS_BYTES(2), st, a);
+    // NVFI_SPLIT_UNI_VOUT=1 (opt-in): the output layer on the vector pipe as in the prefilter (velnet_split_vout).  Alone the kernel gains 5.5 %
+    // (0.475 -> 0.447 ms per step, 0.59 -> 0.63 of the fp32 MFMA peak), but the allocator then takes 228 / 204 registers instead of 179 / 150, the
+    // gather / scatter kernels of the other chains no longer fit beside its two waves per SIMD, and the three-stream step gains nothing
+    // (5.04 against 5.07 ms): off by default, where it is the numbers of k_rk2_fwd<true, STASH> bit for bit
+    static int vout = -1;
+    if (vout < 0) { const char* e = getenv("NVFI_SPLIT_UNI_VOUT"); vout = e ? atoi(e) : 0; }
+    if (vout) {
+        if (stash) hipLaunchKernelGGL((k_rk2_split_uni<2, true, true>), g, b, SPLIT_VOUT_LDS_BYTES(2), st, a);
+        else hipLaunchKernelGGL((k_rk2_split_uni<2, false, true>), g, b, SPLIT_VOUT_LDS_BYTES(2), st, a);
+    } else {
+        if (stash) hipLaunchKernelGGL((k_rk2_split_uni<2, true, false>), g, b, SPLIT_LDS_BYTES(2), st, a);
+        else hipLaunchKernelGGL((k_rk2_split_uni<2, false, false>), g, b, SPLIT_LDS_BYTES(2), st, a);
+    }
     LAUNCHCK();
     return 0;
 }
@@ -474,22 +617,29 @@ int launch_rk2_split_bwd(const SplitBwdArgs& a, int64_t cap_samples, hipStream_t
     return 0;
 }
 
-// wide = 0: one tile per workgroup (shortest latency: short lists); wide = 1: two tiles per workgroup share every weight load
+// wide = 0: one tile per workgroup (shortest latency: short lists); wide = 1: NVFI_SPLIT_NT tiles per workgroup share every weight load
 int launch_rk2_split(const SplitArgs& a, int64_t cap_points, int wide, hipStream_t st) {
     const int64_t tiles = (cap_points + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
     ProfScope ps(PK_PDE_PREFILTER, st);
-    if (wide) {
-        static int nt = -1;
-        if (nt < 0) {
-            const char* e = getenv("NVFI_SPLIT_NT"); nt = e ? atoi(e) : 2;
-            HIPCK(hipFuncSetAttribute((const void*)k_rk2_split<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES(4)));
-        }
-        if (nt == 1) hipLaunchKernelGGL(k_rk2_split<1>, dim3((unsigned)tiles), dim3(WG_THREADS), SPLIT_LDS_BYTES(1), st, a);
-        else if (nt == 4) hipLaunchKernelGGL(k_rk2_split<4>, dim3((unsigned)((tiles + 3) / 4)), dim3(WG_THREADS), SPLIT_LDS_BYTES(4), st, a);
-        else hipLaunchKernelGGL(k_rk2_split<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(WG_THREADS), SPLIT_LDS_BYTES(2), st, a);
+    static int nt = -1, vout = 1;
+    if (nt < 0) {
+        // NVFI_SPLIT_NT: tiles per workgroup of the wide launch.  With the output layer on the vector pipe one tile is the default: alone it is
+        // 1.5 % slower than two (1.32 against 1.30 ms; every weight load feeds one tile), but its 130-register workgroups leave the render
+        // chains' kernels more room beside it - the three-stream step is 1 % faster (5.04 against 5.10 ms).  NVFI_SPLIT_VOUT=0: matrix pipe.
+        const char* e = getenv("NVFI_SPLIT_NT"); nt = e ? atoi(e) : 1;
+        e = getenv("NVFI_SPLIT_VOUT"); vout = e ? atoi(e) : 1;
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_split<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_VOUT_LDS_BYTES(4)));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_split<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_VOUT_LDS_BYTES(4)));
     }
-    else hipLaunchKernelGGL(k_rk2_split<1>, dim3((unsigned)tiles), dim3(WG_THREADS), SPLIT_LDS_BYTES(1), st, a);
+    const int n = wide ? nt : 1;
+    const dim3 b(WG_THREADS);
+    // (both variants get the larger LDS image of the vector-pipe form: three workgroups per CU either way)
+#define SPLIT_GO(NT_) do { const dim3 g((unsigned)((tiles + NT_ - 1) / NT_));                                                              \
+        if (vout) hipLaunchKernelGGL((k_rk2_split<NT_, true>), g, b, SPLIT_VOUT_LDS_BYTES(NT_), st, a);                                   \
+        else hipLaunchKernelGGL((k_rk2_split<NT_, false>), g, b, SPLIT_VOUT_LDS_BYTES(NT_), st, a); } while (0)
+    if (n == 1) SPLIT_GO(1); else if (n == 4) SPLIT_GO(4); else SPLIT_GO(2);
+#undef SPLIT_GO
     LAUNCHCK();
     return 0;
 }
