@@ -6,7 +6,7 @@ for q in "$@"; do
 import json,sys
 try:
     d=json.loads(sys.stdin.readline()); pc=d['roofline']['per_class']
-    print('[$q] prefilter ms', round(pc['pde_prefilter']['ms_per_step'],4), 'frac', round(pc['pde_prefilter']['frac'],4), 'rk2_fwd ms', round(pc['rk2_fwd']['ms_per_step'],4), 'frac', round(pc['rk2_fwd']['frac'],4), 'serial', round(d['work_per_step']['ms_per_step_profiled_serial'],3), 'eager', round(d['value']))
+    print('[$q] prefilter ms', round(pc['pde_prefilter']['ms_per_step'],4), 'frac', round(pc['pde_prefilter']['frac'],4), 'rk2_fwd ms', round(pc['rk2_fwd']['ms_per_step'],4), 'frac', round(pc['rk2_fwd']['frac'],4), 'rk2_bwd ms', round(pc['rk2_bwd']['ms_per_step'],4), 'serial', round(d['work_per_step']['ms_per_step_profiled_serial'],3), 'eager', round(d['value']))
 except Exception as e: print('ERR [$q]', e)"
   for rep in 1 2 3; do
   env $q NVFI_BENCH_CHILD=1 timeout 300 python bench.py --graph on --no-cpu-baseline --profile-steps 0 --no-extras 2>/dev/null | python -c "
