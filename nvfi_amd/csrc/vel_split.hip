@@ -240,8 +240,11 @@ __device__ __forceinline__ void velnet_any(const float4* const* f4, float4* xch,
 
 // VOUT: the output layer on the vector pipe (default); false: on the matrix pipe like every other layer (NVFI_SPLIT_VOUT=0: bit-identical
 // to k_rk2_fwd<false, false> of vel.hip)
+#ifndef SPLIT_WG_PER_CU_1
+#define SPLIT_WG_PER_CU_1 4     // one-tile workgroups: 126 registers, four per CU (three: prefilter 1.31 instead of 1.29 ms)
+#endif
 template <int NT, bool VOUT>
-__global__ __launch_bounds__(WG_THREADS, NT <= 2 ? 3 : 2) void k_rk2_split(SplitArgs a) {
+__global__ __launch_bounds__(WG_THREADS, NT == 1 ? SPLIT_WG_PER_CU_1 : (NT == 2 ? 3 : 2)) void k_rk2_split(SplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* xch = reinterpret_cast<float4*>(lds);
     float4* part = xch + NT * SPLIT_XCH_F4;               // VOUT: [tile][wave][2][32 points] partial output sums; else the 4 x 64 broadcast rows
