@@ -555,11 +555,15 @@ class DropinStep:
         self.tvreg = TVLoss()
         self.groups = model.get_optparam_groups(0.02, 1e-3, 1e-3)
         self.live = live
+        # NVFI_DROPIN_FUSED_ADAM=1 (`tools/run_reference_driver.py --fused-adam`): the caller's optimiser built with fused=True - one kwarg away from
+        # train_nvfi.py:95; the default stays the reference's call as written (torch's multi-tensor implementation)
+        akw = dict(fused=True) if os.environ.get("NVFI_DROPIN_FUSED_ADAM") == "1" else {}
+        self.fused_adam = bool(akw)
         if live:
-            self.opt = torch.optim.Adam(self.groups, betas=(0.9, 0.99))
+            self.opt = torch.optim.Adam(self.groups, betas=(0.9, 0.99), **akw)
         else:
             sg, self.pairs = _shadow_groups([dict(params=list(g["params"]), lr=g["lr"]) for g in self.groups])
-            self.opt = torch.optim.Adam(sg, betas=(0.9, 0.99))
+            self.opt = torch.optim.Adam(sg, betas=(0.9, 0.99), **akw)
         self.host_rays = host_rays
         self.pose = pose_spherical(30.0, -30.0, 4.0).to("cpu" if host_rays else device)
         self.focal = 0.5 * W_IMG / np.tan(0.5 * ANGLE_X)
@@ -950,6 +954,9 @@ def main():
         out["extras"] = {
             "dropin": dict(extra(["--mode", "dropin"]), what="the loop body of the reference's train_nvfi.py:139-249 verbatim on the `models` alias (plain autograd, "
                            "torch.optim.Adam, reference-signature regularisers, the per-iteration .item() waits): what tools/run_reference_driver.py gets"),
+            "dropin_fused_adam": dict(extra(["--mode", "dropin"], {"NVFI_DROPIN_FUSED_ADAM": "1"}),
+                                      what="the same loop with `fused=True` in the caller's torch.optim.Adam (tools/run_reference_driver.py --fused-adam; opt-in: "
+                                           "the reference's call as written is the line above)"),
             "cfg2_radiance_only": dict(extra(["--workload", "cfg2", "--graph", "off"], steps_factor=10), what="BASELINE configs[1]: bat.yaml radiance-only, 2048-ray batches, HBM-bound (gathers / scatters); 10 K steps"),
             "optin_split16band_prefilter": dict(extra(["--graph", "off"], {"NVFI_PDE_PREFILTER": "split16band"}),
                                                 what="opt-in (NOT the headline): the PDE occupancy prefilter with fp32 products emulated on the fp16 matrix pipe (two binary16 "

@@ -421,6 +421,16 @@ int launch_rk2_split_uni(const SplitUniArgs& a, int64_t cap_samples, bool stash,
     const int64_t tiles = (cap_samples + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
     ProfScope ps(PK_RK2_FWD, st);
+    // NVFI_SPLIT_UNI_NT=1 (experiment): one tile per workgroup, output layer on the vector pipe
+    static int unt = -1;
+    if (unt < 0) { const char* e = getenv("NVFI_SPLIT_UNI_NT"); unt = e ? atoi(e) : 2; }
+    if (unt == 1) {
+        const dim3 g1((unsigned)tiles), b1(WG_THREADS);
+        if (stash) hipLaunchKernelGGL((k_rk2_split_uni<1, true, true>), g1, b1, SPLIT_VOUT_LDS_BYTES(1), st, a);
+        else hipLaunchKernelGGL((k_rk2_split_uni<1, false, true>), g1, b1, SPLIT_VOUT_LDS_BYTES(1), st, a);
+        LAUNCHCK();
+        return 0;
+    }
     const dim3 g((unsigned)((tiles + 1) / 2)), b(WG_THREADS);
     // NVFI_SPLIT_UNI_VOUT=1 (opt-in): the output layer on the vector pipe as in the prefilter (velnet_split_vout).  Alone the kernel gains 5.5 %
     // (0.475 -> 0.447 ms per step, 0.59 -> 0.63 of the fp32 MFMA peak), but the allocator then takes 228 / 204 registers instead of 179 / 150, the

@@ -72,6 +72,29 @@ def test_launcher_orders_the_packages(tmp_path):
     assert d["tv_module"] == "utils" and d["tv_fused"] is True and d["nottv_fused"] is False
 
 
+def test_fused_adam_flag_wraps_the_callers_optimiser(tmp_path):
+    """--fused-adam: torch.optim.Adam built by the driver WITHOUT a fused / foreach choice gets fused=True for CUDA parameters; CPU parameters and
+    explicit choices are left alone; without the flag torch.optim.Adam is torch's own class"""
+    body = """
+        import json, torch
+        from models import *
+        p = torch.nn.Parameter(torch.zeros(4))
+        a = torch.optim.Adam([dict(params=[p], lr=0.02)], betas=(0.9, 0.99))
+        b = torch.optim.Adam([p], lr=1e-3, foreach=True)
+        print(json.dumps(dict(cls=type(a).__name__, wrapped=bool(getattr(torch.optim.Adam, "__nvfi_fused_default__", False)), is_adam=isinstance(a, torch.optim.Optimizer),
+                              cpu_fused=a.defaults.get("fused"), explicit_foreach=b.defaults.get("foreach"), explicit_fused=b.defaults.get("fused"),
+                              betas=a.defaults["betas"], lr=a.param_groups[0]["lr"])))
+    """
+    co = _decoy(tmp_path, body)
+    for flag, wrapped in ((["--fused-adam"], True), ([], False)):
+        r = subprocess.run([sys.executable, LAUNCHER, *flag, str(co / "train_nvfi.py")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["cls"] == "Adam" and d["is_adam"] and d["wrapped"] is wrapped
+        assert not d["cpu_fused"] and d["explicit_foreach"] is True and not d["explicit_fused"]
+        assert d["betas"] == [0.9, 0.99] and d["lr"] == 0.02
+
+
 def test_tvloss_check_is_structural():
     from nvfi_amd.utils import TVLoss
     from nvfi_amd.utils.tensorf_utils import is_reference_tvloss

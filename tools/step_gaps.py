@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 
-def main(path, marker="void k_rk2_split<2>", back=3):
+def main(path, marker="void k_rk2_split<", back=3):
     c = sqlite3.connect(path).cursor()
     rows = c.execute("select name, start, end from kernels order by start").fetchall()
     marks = [r[1] for r in rows if r[0].startswith(marker)]
