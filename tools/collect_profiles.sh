@@ -16,6 +16,8 @@ python $REPO/bench.py --no-extras --steps 100 --warmup 5 --no-cpu-baseline > $OU
 NVFI_OVERLAP=0 python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_one_stream.json 2>/dev/null
 python $REPO/bench.py --no-extras --live --no-cpu-baseline > $OUT/${TAG}_bench_line_live.json 2>/dev/null
 python $REPO/bench.py --no-extras --mode dropin --no-cpu-baseline > $OUT/${TAG}_bench_line_dropin.json 2>/dev/null
+NVFI_DROPIN_FUSED_ADAM=1 python $REPO/bench.py --no-extras --mode dropin --no-cpu-baseline > $OUT/${TAG}_bench_line_dropin_fused_adam.json 2>/dev/null
+NVFI_SPLIT_VOUT=0 NVFI_SPLIT_NT=2 python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_prefilter_out_on_mfma.json 2>/dev/null
 python $REPO/bench.py --no-extras --workload cfg2 --no-cpu-baseline > $OUT/${TAG}_bench_line_cfg2.json 2>/dev/null
 NVFI_WGRAD=engine python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_wgrad_engine.json 2>/dev/null
 # other kernel selections: opt-in fp16-input pre-pass with the fp32 band; the engine kernels of vel.hip instead of vel_split.hip
