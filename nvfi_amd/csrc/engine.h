@@ -30,6 +30,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDS_B_FLOATS 128
 #define ENGINE_LDS_BYTES ((LDS_W_FLOATS + LDS_B_FLOATS) * 4)
 #define REGF (64)                     // floats per stash register row (one per lane)
+// Stash rows are written once and read back once or twice, hundreds of MB later: their stores and their loads in the adjoint kernels are
+// non-temporal (`global_store_dword ... nt` / `global_load_dword ... nt`), so that they stream past L2 / MALL instead of evicting the
+// planes and weight fragments (measured: k_app_fwd<stash> -8 %, k_pde_jet_bwd -5 %, step 5.065 -> 4.96 ms).
+// -DNVFI_STASH_TEMPORAL keeps plain accesses (bisecting).
+#ifdef NVFI_STASH_TEMPORAL
+#define STASH_ST(p, v) ((p) = (v))
+#define STASH_LD(p) (p)
+#else
+#define STASH_ST(p, v) __builtin_nontemporal_store((float)(v), &(p))
+#define STASH_LD(p) __builtin_nontemporal_load(&(p))
+#endif
 
 // ---------------------------------------------------------------- layout maps
 // D-layout: register index s (= 16*tile + r) and half h  ->  row index
@@ -239,14 +250,14 @@ __device__ __forceinline__ void layer_tiles(const float* lds_w, const float* lds
 template <int NR>
 __device__ __forceinline__ void stash_store(float* base, int lane, const float* v) {
 #pragma unroll
-    for (int s = 0; s < NR; ++s) base[s * REGF + lane] = v[s];
+    for (int s = 0; s < NR; ++s) STASH_ST(base[s * REGF + lane], v[s]);
 }
 template <int MT>
 __device__ __forceinline__ void stash_store_acc(float* base, int lane, const f32x16* acc) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) base[(16 * m + r) * REGF + lane] = acc[m][r];
+        for (int r = 0; r < 16; ++r) STASH_ST(base[(16 * m + r) * REGF + lane], acc[m][r]);
 }
 
 // ---------------------------------------------------------------- velocity-basis nets
@@ -480,7 +491,7 @@ struct FragPipe {
 template <int NR>
 __device__ __forceinline__ void stash_load(const float* base, int lane, float* v) {
 #pragma unroll
-    for (int s = 0; s < NR; ++s) v[s] = base[s * REGF + lane];
+    for (int s = 0; s < NR; ++s) v[s] = STASH_LD(base[s * REGF + lane]);
 }
 
 // (A pipelined FORWARD was built the same way and measured: rk2_fwd unchanged, the PDE prefilter 12 % slower - the forward

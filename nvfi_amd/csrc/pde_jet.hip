@@ -191,14 +191,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_jet_fwd(PdeJetArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float z = acc[0][r];
-            T[(size_t)(PDE_Z + row0 + r) * REGF + lane] = z;
+            STASH_ST(T[(size_t)(PDE_Z + row0 + r) * REGF + lane], z);
             const float s = fast_sigmoid(z);
             const float d1 = s * (1.f + z * (1.f - s));
             acc[0][r] = z * s;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float zd = acc[1 + j][r];
-                T[(size_t)(PDE_ZD + 320 * j + row0 + r) * REGF + lane] = zd;
+                STASH_ST(T[(size_t)(PDE_ZD + 320 * j + row0 + r) * REGF + lane], zd);
                 acc[1 + j][r] = d1 * zd;
             }
         }
@@ -320,12 +320,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_jet_bwd(PdeJetArgs a) {
         const int row0 = l * 64 + 16 * w;
         float zr[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zr[r] = T[(size_t)(PDE_Z + row0 + r) * REGF + lane];
+        for (int r = 0; r < 16; ++r) zr[r] = STASH_LD(T[(size_t)(PDE_Z + row0 + r) * REGF + lane]);
         float zd[4][16];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) zd[j][r] = T[(size_t)(PDE_ZD + 320 * j + row0 + r) * REGF + lane];
+            for (int r = 0; r < 16; ++r) zd[j][r] = STASH_LD(T[(size_t)(PDE_ZD + 320 * j + row0 + r) * REGF + lane]);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             f32x2 d1, d2;
@@ -337,14 +337,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_jet_bwd(PdeJetArgs a) {
                 cj[j] = d2 * (f32x2){zd[j][r], zd[j][r + 1]} * a2;
                 const f32x2 g2 = d1 * a2;
                 acc[1 + j][r] = g2.x; acc[1 + j][r + 1] = g2.y;
-                T[(size_t)(PDE_GA + 336 * (1 + j) + row0 + r) * REGF + lane] = g2.x;
-                T[(size_t)(PDE_GA + 336 * (1 + j) + row0 + r + 1) * REGF + lane] = g2.y;
+                STASH_ST(T[(size_t)(PDE_GA + 336 * (1 + j) + row0 + r) * REGF + lane], g2.x);
+                STASH_ST(T[(size_t)(PDE_GA + 336 * (1 + j) + row0 + r + 1) * REGF + lane], g2.y);
             }
             f32x2 v = d1 * (f32x2){acc[0][r], acc[0][r + 1]};
             v = v + ((cj[0] + cj[1]) + (cj[2] + cj[3]));
             acc[0][r] = v.x; acc[0][r + 1] = v.y;
-            T[(size_t)(PDE_GA + row0 + r) * REGF + lane] = v.x;
-            T[(size_t)(PDE_GA + row0 + r + 1) * REGF + lane] = v.y;
+            STASH_ST(T[(size_t)(PDE_GA + row0 + r) * REGF + lane], v.x);
+            STASH_ST(T[(size_t)(PDE_GA + row0 + r + 1) * REGF + lane], v.y);
         }
         if (l == 0) break;
         jet_exchange(xch, w, lane, acc, g);

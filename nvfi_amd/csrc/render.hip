@@ -399,7 +399,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
     float* st = STASH ? a.stash_f + (size_t)tile * (APP_F_ROWS * REGF) : nullptr;
     if (STASH) {
 #pragma unroll
-        for (int s = 0; s < 32; ++s) st[s * REGF + lane] = s < 24 ? x[s] : 0.f;
+        for (int s = 0; s < 32; ++s) STASH_ST(st[s * REGF + lane], s < 24 ? x[s] : 0.f);
     }
     // positional encodings (tensorf_model_utils.py:176-183) -> scratch rows 0..35 (sin|cos selected by h)
 #pragma unroll 1
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
         }
         g[0] = go[0]; g[1] = go[1]; g[2] = go[2]; g[3] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) stb[s * REGF + lane] = s < 3 ? g[s] : 0.f;
+        for (int s = 0; s < 16; ++s) STASH_ST(stb[s * REGF + lane], s < 3 ? g[s] : 0.f);
     }
     __syncthreads();
     stage_frag(lds_w, lds_b, a.W.t3, RT_3, nullptr, 0);
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[16 * m + r] = h2[(16 * m + r) * REGF + lane] > 0.f ? acc[m][r] : 0.f;
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = STASH_LD(h2[(16 * m + r) * REGF + lane]) > 0.f ? acc[m][r] : 0.f;
     }
     stash_store<64>(stb + 16 * REGF, lane, g);
     __syncthreads();
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[16 * m + r] = h1[(16 * m + r) * REGF + lane] > 0.f ? acc[m][r] : 0.f;
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = STASH_LD(h1[(16 * m + r) * REGF + lane]) > 0.f ? acc[m][r] : 0.f;
     }
     stash_store<64>(stb + 80 * REGF, lane, g);
     __syncthreads();
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const int sl = 19 + c * 6 + k;
-                const float mine = xin[sl * REGF + lane];
+                const float mine = STASH_LD(xin[sl * REGF + lane]);
                 const float other = __shfl_xor(mine, 32);
                 const float fr = (float)(1 << k);
                 s += (h ? -fr * other : fr * other) * acc[sl >> 4][sl & 15];
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
     }   // MLP_PE
     // gfeat (tile 0) -> stash, then basis^T -> gg (48 channels in gather layout)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { g[r] = acc[0][r]; stb[(144 + r) * REGF + lane] = g[r]; }
+    for (int r = 0; r < 16; ++r) { g[r] = acc[0][r]; STASH_ST(stb[(144 + r) * REGF + lane], g[r]); }
     __syncthreads();
     stage_frag(lds_w, lds_b, a.W.tb, RT_B, nullptr, 0);
     __syncthreads();

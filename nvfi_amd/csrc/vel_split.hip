@@ -92,7 +92,7 @@ __device__ __forceinline__ void velnet_split(const float4* const* f4, float4* xc
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) zst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane] = acc[t][r];
+                for (int r = 0; r < 16; ++r) STASH_ST(zst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane], acc[t][r]);
         }
         __syncthreads();                                 // the previous layer's readers of the exchange buffer are done
 #pragma unroll
@@ -161,7 +161,7 @@ __device__ __forceinline__ void velnet_split_vout(const float4* const* f4, float
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) zst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane] = acc[t][r];
+                for (int r = 0; r < 16; ++r) STASH_ST(zst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane], acc[t][r]);
         }
         __syncthreads();                                 // the previous layer's readers of the exchange buffer are done
 #pragma unroll
@@ -183,7 +183,7 @@ __device__ __forceinline__ void velnet_split_vout(const float4* const* f4, float
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) zst[t][(size_t)(4 * 64 + 16 * w + r) * REGF + lane] = acc[t][r];
+            for (int r = 0; r < 16; ++r) STASH_ST(zst[t][(size_t)(4 * 64 + 16 * w + r) * REGF + lane], acc[t][r]);
     }
     float p[NT][6];
 #pragma unroll
@@ -469,7 +469,7 @@ __device__ __forceinline__ void velnet_split_bwd(const float4* const* t4, float4
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zp[t][r] = zst[t][(size_t)(4 * 64 + 16 * w + r) * REGF + lane];
+        for (int r = 0; r < 16; ++r) zp[t][r] = STASH_LD(zst[t][(size_t)(4 * 64 + 16 * w + r) * REGF + lane]);
         if (w == t) {                                     // adjoint of the 6 outputs: B operand of the output layer's weight gradient
             float* gw_rows = gst[t] + (size_t)5 * 64 * REGF;
 #pragma unroll
@@ -495,11 +495,11 @@ __device__ __forceinline__ void velnet_split_bwd(const float4* const* t4, float4
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 g[t][r] = acc[t][r] * act_d1<1>(zp[t][r]);
-                gst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane] = g[t][r];
+                STASH_ST(gst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane], g[t][r]);
             }
             if (l >= 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) zp[t][r] = zst[t][(size_t)((l - 1) * 64 + 16 * w + r) * REGF + lane];
+                for (int r = 0; r < 16; ++r) zp[t][r] = STASH_LD(zst[t][(size_t)((l - 1) * 64 + 16 * w + r) * REGF + lane]);
             }
         }
         __syncthreads();                                  // the previous layer's readers of the exchange buffer are done
