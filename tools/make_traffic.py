@@ -4,21 +4,25 @@ bytes per launch = 2*FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.m
 a class with several kernels is the sum of their per-launch averages."""
 import csv
 import json
+import re
 import sys
 
+# kernel-name patterns per profiler class (regular expressions matched against the start of the demangled name with a leading "void "
+# removed; template arguments change from round to round, so they are matched loosely - a class that matches NO kernel of the trace is
+# reported on stderr instead of silently becoming 0)
 CLASSES = {
-    "wgrad": ["k_wgrad", "k_wgrad_ring8"],
-    "pde_prefilter": ["void k_rk2_fwd<false, false>", "void k_rk2_split<2>", "void k_rk2_split<1>", "void k_rk2_split<4>", "k_rk2_pre16"],
-    "rk2_fwd": ["void k_rk2_fwd<true, true>", "void k_rk2_split_uni<2, true>"],
-    "rk2_bwd": ["k_rk2_bwd", "void k_rk2_split_bwd<2>"],
-    "pde_bwd": ["k_pde_jet_bwd", "k_pde_tangent_bwd", "k_pde_value_bwd"],
-    "pde_fwd": ["k_pde_jet_fwd", "k_pde_value_fwd", "k_pde_tangent_fwd"],
-    "app_fwd": ["void k_app_fwd<true>"],
-    "app_bwd": ["k_app_bwd"],
-    "density_fwd": ["k_density_q"],
-    "density_bwd": ["void k_og<24, true>"],
-    "density_scatter": ["void k_tile_scatter<24>", "k_tile_hist", "k_tile_scan", "k_tile_fill"],
-    "app_scatter": ["void k_og<48, true>", "void k_tile_scatter<48>", "k_tile_hist", "k_tile_scan", "k_tile_fill"],
+    "wgrad": [r"k_wgrad$", r"k_wgrad_ring8$"],
+    "pde_prefilter": [r"k_rk2_fwd<false, false>", r"k_rk2_split<", r"k_rk2_pre16"],
+    "rk2_fwd": [r"k_rk2_fwd<true, true>", r"k_rk2_split_uni<"],
+    "rk2_bwd": [r"k_rk2_bwd", r"k_rk2_split_bwd<"],
+    "pde_bwd": [r"k_pde_jet_bwd", r"k_pde_tangent_bwd", r"k_pde_value_bwd"],
+    "pde_fwd": [r"k_pde_jet_fwd", r"k_pde_value_fwd", r"k_pde_tangent_fwd"],
+    "app_fwd": [r"k_app_fwd<true>", r"k_app_feat$"],
+    "app_bwd": [r"k_app_bwd"],
+    "density_fwd": [r"k_density_q"],
+    "density_bwd": [r"k_og<24, true>"],
+    "density_scatter": [r"k_tile_scatter(_mfma)?<24>", r"k_tile_hist", r"k_tile_scan", r"k_tile_fill"],
+    "app_scatter": [r"k_og<48, true>", r"k_tile_scatter(_mfma)?<48>", r"k_tile_hist", r"k_tile_scan", r"k_tile_fill"],
 }
 
 
@@ -34,10 +38,15 @@ def main(fetch_csv, write_csv, out_json, note):
     f, w = per_launch(fetch_csv, "FETCH_SIZE"), per_launch(write_csv, "WRITE_SIZE")
     res = {}
     for cls, ks in CLASSES.items():
-        tot = 0.0
-        for k in ks:
-            tot += (2.0 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024.0
-        res[cls] = tot
+        tot, hit = 0.0, 0
+        for name in sorted(set(f) | set(w)):
+            bare = name[5:] if name.startswith("void ") else name
+            if any(re.match(k, bare) for k in ks):
+                tot += (2.0 * f.get(name, 0.0) + w.get(name, 0.0)) * 1024.0
+                hit += 1
+        if not hit:
+            print(f"make_traffic: class {cls} matches no kernel of the trace ({ks})", file=sys.stderr)
+        res[cls] = tot if hit else None
     json.dump({"source": f"{fetch_csv} + {write_csv} ({note})",
                "note": "bytes per launch = 2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, KiB->B; classes with several kernels: sum of their per-launch averages",
                "bytes_per_launch": res}, open(out_json, "w"), indent=1)
