@@ -174,3 +174,24 @@ def test_rccl_comm_needs_a_process_group_for_the_bootstrap():
     from nvfi_amd.dist import RcclComm
     with pytest.raises(_lib.NvfiError, match="init_process_group"):
         RcclComm(world=2, rank=1)
+
+
+def test_traffic_classes_match_the_committed_counter_pass(tmp_path):
+    """bench.py quotes roofline.traffic from profiles/<tag>_traffic.json, which tools/make_traffic.py derives from the committed FETCH_SIZE /
+    WRITE_SIZE summaries by kernel name.  A renamed kernel (new template arguments) must not silently turn a class into 0 bytes: every
+    class the current default path launches has to match a kernel of the committed trace, and the dominant class has to carry bytes."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_traffic", os.path.join(ROOT, "tools", "make_traffic.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    bench_src = open(os.path.join(ROOT, "bench.py")).read()
+    tag = re.search(r'^PROFILE_TAG = "(\w+)"', bench_src, re.M).group(1)
+    prof = os.path.join(ROOT, "profiles")
+    out = tmp_path / "traffic.json"
+    mt.main(os.path.join(prof, f"{tag}_pmc_fetch_size.csv"), os.path.join(prof, f"{tag}_pmc_write_size.csv"), str(out), "test")
+    fresh = json.load(open(out))["bytes_per_launch"]
+    assert all(v is not None and v > 0 for v in fresh.values()), fresh
+    committed = json.load(open(os.path.join(prof, f"{tag}_traffic.json")))["bytes_per_launch"]
+    assert committed == pytest.approx(fresh)
+    assert committed["pde_prefilter"] > 1e6
