@@ -61,6 +61,8 @@ struct AppArgs {
     const float* feat48;   // (M,48) plane-product features of the masked samples by compact index (k_app_feat): no plane gather in k_app_fwd
     const float* feat_in;  // (N, app_dim) appearance features given by the caller (renderModule as a stand-alone call): no plane gather, no basis_mat
     float* stash_f; float* stash_b;
+    unsigned* relu_mask;   // [tile][layer 1 | layer 2][lo | hi][64 lanes]: bit s of a lane = (hidden activation register s > 0), written by k_app_fwd<stash>,
+                           // read by k_app_bwd instead of the 128 activation rows themselves (1 KB instead of 32 KB per tile)
     // backward
     nvfi_grads g;
     const float* g_rgb; const float4* rgb_pre; const float* weight;

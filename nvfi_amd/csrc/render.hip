@@ -358,6 +358,13 @@ __device__ __forceinline__ void app_gather_to_scratch(const nvfi_field_desc& f, 
     }
 }
 
+// ReLU masks of a hidden layer for the backward pass: bit s of the lane's pair of words = (activation register s > 0)
+__device__ __forceinline__ void relu_mask_store(unsigned* dst, int lane, const float* x) {
+    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) { lo |= x[s] > 0.f ? 1u << s : 0u; hi |= x[32 + s] > 0.f ? 1u << s : 0u; }
+    dst[lane] = lo; dst[64 + lane] = hi;
+}
 template <bool STASH>
 __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -463,6 +470,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[16 * m + r] = fmaxf(acc[m][r], 0.f);
     if (STASH) stash_store<64>(st + 96 * REGF, lane, x);
+    if (STASH) relu_mask_store(a.relu_mask + (size_t)tile * 256, lane, x);
     __syncthreads();
     stage_frag(lds_w, lds_b, a.W.f2, RF_2, a.W.b2, 128);
     __syncthreads();
@@ -473,6 +481,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[16 * m + r] = fmaxf(acc[m][r], 0.f);
     if (STASH) stash_store<64>(st + 160 * REGF, lane, x);
+    if (STASH) relu_mask_store(a.relu_mask + (size_t)tile * 256 + 128, lane, x);
     __syncthreads();
     stage_frag(lds_w, lds_b, a.W.f3, RF_3, a.W.b3, 32);
     __syncthreads();
@@ -570,11 +579,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
     acc_init<4>(acc, lds_b, 0, false);
     layer_mfma<4, 4>(lds_w, lane, g, acc);
     {
-        const float* h2 = stf + 160 * REGF;
+        const unsigned* mk = a.relu_mask + (size_t)tile * 256 + 128;
+        const unsigned mlo = mk[lane], mhi = mk[64 + lane];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[16 * m + r] = STASH_LD(h2[(16 * m + r) * REGF + lane]) > 0.f ? acc[m][r] : 0.f;
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = (((m < 2 ? mlo : mhi) >> ((16 * m + r) & 31)) & 1u) ? acc[m][r] : 0.f;
     }
     stash_store<64>(stb + 16 * REGF, lane, g);
     __syncthreads();
@@ -583,11 +593,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_app_bwd(AppArgs a) {
     acc_init<4>(acc, lds_b, 0, false);
     layer_mfma<4, 64>(lds_w, lane, g, acc);
     {
-        const float* h1 = stf + 96 * REGF;
+        const unsigned* mk = a.relu_mask + (size_t)tile * 256;
+        const unsigned mlo = mk[lane], mhi = mk[64 + lane];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[16 * m + r] = STASH_LD(h1[(16 * m + r) * REGF + lane]) > 0.f ? acc[m][r] : 0.f;
+            for (int r = 0; r < 16; ++r) g[16 * m + r] = (((m < 2 ? mlo : mhi) >> ((16 * m + r) & 31)) & 1u) ? acc[m][r] : 0.f;
     }
     stash_store<64>(stb + 80 * REGF, lane, g);
     __syncthreads();
@@ -1089,6 +1100,7 @@ struct RenderPlan {
     float *vel_frag, *render_frag, *vel_x4, *vel_x4b; void* img16;
     TileWork tw2; float* slabs2;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
+    unsigned* app_relu;
     float *slabs;
     long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
     int64_t zero_bytes;        // counters .. end of the sort histograms: zeroed by the forward's single fill
@@ -1132,6 +1144,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->render_frag = B.take<float>(RENDER_FRAG_FLOATS);
     P->maskv = (flags & NVFI_WANT_MASK) ? B.take<float>(N * 32) : nullptr;
     P->mask_frag = (flags & NVFI_WANT_MASK) ? B.take<float>(64 * 1024) : nullptr;
+    P->app_relu = nullptr;
     P->app_f = P->app_b = P->zst = P->x0st = P->rec = P->gst = P->slabs = nullptr;
     P->gxw = P->gxk = nullptr; P->gxpre = nullptr; P->gg = nullptr;
     if (train) {
@@ -1139,6 +1152,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
         P->gg = B.take<float>(N * 48);
         P->app_f = B.take<float>(P->cap_tiles * (int64_t)(APP_F_ROWS * REGF));
         P->app_b = B.take<float>(P->cap_tiles * (int64_t)(APP_B_ROWS * REGF));
+        P->app_relu = B.take<unsigned>(P->cap_tiles * (int64_t)256);
         P->slabs = B.take<float>((int64_t)NSLAB_MAX * SLAB_FLOATS * 6);
         P->shadow = nullptr;
         if (det_mode()) { int64_t off[12]; P->shadow = B.take<long long>(plane_elems(f, off)); }
@@ -1275,7 +1289,7 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
     // appearance
     AppArgs aa; memset(&aa, 0, sizeof(aa));
     aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S; aa.sched = sched;
-    aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f;
+    aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f; aa.relu_mask = P.app_relu;
     const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
     {
         ProfScope ps(PK_APP_FWD, st);
@@ -1357,7 +1371,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     // appearance branch
     AppArgs aa; memset(&aa, 0, sizeof(aa));
     aa.f = *f; aa.W = RW; aa.count = P.counters + 1; aa.list = P.mlist; aa.xw = P.xw; aa.tn = tn; aa.S = S; aa.sched = sched;
-    aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f; aa.stash_b = P.app_b; aa.g = *grads;
+    aa.rays_d = rays_d; aa.rgbs = P.rgbs; aa.stash_f = P.app_f; aa.relu_mask = P.app_relu; aa.stash_b = P.app_b; aa.g = *grads;
     aa.g_rgb = g_rgb; aa.rgb_pre = P.rgb_pre; aa.weight = weights; aa.gxw = P.gxw; aa.gg = P.gg;
     aa.plane_tail = P.tiles ? 0 : 1;
     const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
