@@ -9,8 +9,8 @@
 //     other's MFMAs) walks EVERY job of the launch with the same share of each job's items - all workgroups do identical work whatever
 //     the mix of 128x128, 32x128 and 128x32 jobs - and writes slab g of every job;
 //   * every byte of a stash image is fetched ONCE per item, by LDS-DMA: a wave-instruction moves 1 KiB (8 rows of 128 B) without
-//     touching a VGPR, into a ring of 4 item slots (3 for the tangent jobs with their second B stream): three items - 96 KB per CU -
-//     are in flight behind the one being contracted, across the single barrier per item (raw s_barrier + counted s_waitcnt vmcnt: a
+//     touching a VGPR, into a ring of RING_MAX_SLOTS item slots (2 since the end of round 3; 4 before - 96 KB per CU in flight - was no faster): the next item
+//     is in flight behind the one being contracted, across the single barrier per item (raw s_barrier + counted s_waitcnt vmcnt: a
 //     __syncthreads() would drain the DMA queue).  The DMA is inline asm with an SGPR base + a per-lane 32-bit offset that is constant
 //     for the whole job, so an item costs ~30 scalar instructions per wave;
 //   * the LDS image is row-major [row p][32 samples] with the eight 16-byte chunks of a row XOR-permuted by (p >> 1) & 7 - applied on
@@ -30,7 +30,9 @@
 #define RING_ROW_BYTES 128                 // one stash row of a tile: 32 samples
 #define RING_TILE_BYTES 4096               // 32 rows
 #ifndef RING_MAX_SLOTS
-#define RING_MAX_SLOTS 4                   // ring slots of one item (3 when 4 slots would not fit: the tangent jobs)
+#define RING_MAX_SLOTS 2                   // ring slots of one item: the item being contracted + one in flight (64 KB; 96 KB for the tangent jobs).  Measured
+                                           // in the step, -D variants: 4 slots (128 KB) 1.128-1.137 ms per step for the four launches, 3 slots 1.127, 2 slots 1.104-1.110
+                                           // (5 slots like 4): the window is not what limits the kernel, and 64 KB of LDS stay free for the kernels of the other streams
 #endif
 
 // LDS-DMA of 1 KiB per wave-instruction: lane L's 16 bytes at base + voff land at lds_dst + 16 L (base: SGPR pair, lds_dst: wave-uniform
