@@ -574,8 +574,8 @@ class DropinStep:
         self.lr_factor = 0.1 ** (1 / 30000)
         self.L1w, self.tvd, self.tva, self.vw = 8e-4, 1.0, 1.0, 1.0
         self.counters, self.pde_counters = [], []
-        # the field's defaults for a plain autograd driver: gradients accumulated in place into its own flat buffer
-        # (NVFI_INPLACE_GRADS=0: pure autograd, round-2 behaviour; NVFI_AUTO_OVERLAP=1: train-mode calls on the field's side streams - measured slower)
+        # the opt-in a plain autograd driver can switch on without touching its loop: gradients accumulated in place into the field's own flat buffer
+        # (NVFI_INPLACE_GRADS=0: the library default, pure autograd; NVFI_AUTO_OVERLAP=1: train-mode calls on the field's side streams - measured slower)
         model.nvfi.accumulate_grads_inplace = "arena" if os.environ.get("NVFI_INPLACE_GRADS", "1") != "0" else False
         model.nvfi.auto_overlap = os.environ.get("NVFI_AUTO_OVERLAP", "0") == "1"
         model.vel_loss_weight = None

@@ -87,4 +87,4 @@ __global__ void k_counters(const int* c, int nsteps, int64_t* out, const float* 
 __global__ void k_unpack_rgb(const float4* in, float* out, int64_t N);
 __global__ void k_pack_xyz4(const float* in, float4* out, int64_t N);
 int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, const int* count, int cap_tiles, int nrep,
-                     int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st);
+                     int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st, int fused_nslab = 0);

@@ -11,9 +11,11 @@
 // loads; per-ray scans/reductions are wave-level; the MLP contractions run on the MFMA engine.
 #include "common.h"
 #include "render.h"
+#include "fuse.h"
 #include "scatter.h"
 #include "pde.h"
 #include <stdlib.h>
+#include <mutex>
 
 // ================================================================ sampling + compaction
 __global__ void k_any_inside(nvfi_field_desc f, int64_t R, const float* __restrict__ o, int* flag) {
@@ -929,17 +931,30 @@ static SideStream g_side;
 // A caller that already overlaps several renders / the PDE term on its own streams (bench.py's fused driver) leaves the bit off.
 struct ForkStream {
     hipStream_t s = nullptr; hipEvent_t fork = nullptr, fork2 = nullptr, join = nullptr; int state = -1;
+    std::once_flag once;
     int get() {
-        if (state >= 0) return state;
-        state = 1;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) state = 0;
-        if (state && hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) state = 0;
-        if (state && hipEventCreateWithFlags(&fork2, hipEventDisableTiming) != hipSuccess) state = 0;
-        if (state && hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) state = 0;
+        // created on the device that is current at the first call, once (autograd runs backward nodes on per-device worker threads)
+        std::call_once(once, [this] {
+            int st = 1;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) st = 0;
+            if (st && hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) st = 0;
+            if (st && hipEventCreateWithFlags(&fork2, hipEventDisableTiming) != hipSuccess) st = 0;
+            if (st && hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) st = 0;
+            state = st;
+        });
         return state;
     }
 };
-static ForkStream g_fork;
+// one fork stream per device ordinal: a second device (or a second field on another device) in the same process gets its own stream and
+// events instead of launching its forked half on the first device's
+#define NVFI_MAX_DEVICES 16
+static ForkStream g_forks[NVFI_MAX_DEVICES];
+static ForkStream& fork_of_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NVFI_MAX_DEVICES) dev = 0;
+    return g_forks[dev];
+}
+#define g_fork (fork_of_current_device())
 static int scatter_mask() { static int m = -1; if (m < 0) { const char* e = getenv("NVFI_SCATTER_MASK"); m = e ? atoi(e) : 63; } return m; }
 
 
@@ -1478,13 +1493,24 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles; ra.gxk = P.gxk;
         static int split = -1;
         if (split < 0) { const char* e = getenv("NVFI_RK2_SPLIT_BWD"); split = e ? atoi(e) : 1; }
-        if (split) {   // vel_split.hip: same adjoint stash bit for bit
+        // NVFI_RK2_FUSE (default 1): vel_fuse.hip - the adjoint AND the four 128 x 128 weight gradients in one persistent kernel (no g_1..g_4
+        // stash, no second pass over the z stash); 0: k_rk2_split_bwd + k_wgrad_ring8 over the full adjoint stash
+        static int fuse = -1;
+        if (fuse < 0) { const char* e = getenv("NVFI_RK2_FUSE"); fuse = e ? atoi(e) : 1; }
+        float* vslabs = fork2 ? P.slabs2 : P.slabs;
+        int fused_nslab = 0;
+        if (split && fuse) {
+            FuseBwdArgs fa; memset(&fa, 0, sizeof(fa));
+            fa.r = ra; fa.slabs = vslabs; fa.layer_stride = (int64_t)NSLAB * SLAB_FLOATS; fa.slab_floats = SLAB_FLOATS;
+            if (pack_vel_x4_bwd(VW, P.vel_x4b, fa.t4, st)) return 1;
+            if (launch_rk2_fuse_bwd(fa, N, NSLAB, &fused_nslab, st)) return 1;
+        } else if (split) {   // vel_split.hip: same adjoint stash bit for bit
             SplitBwdArgs ba; ba.r = ra;
             if (pack_vel_x4_bwd(VW, P.vel_x4b, ba.t4, st)) return 1;
             if (launch_rk2_split_bwd(ba, N, st)) return 1;
         } else if (launch_rk2_bwd(ra, N, st)) return 1;
-        if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 3, (int)P.cap_tiles, 2 * nsteps, BM_SILU, fork2 ? P.slabs2 : P.slabs, NSLAB,
-                             grads->vW, grads->vb, 1.f, st)) return 1;
+        if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 3, (int)P.cap_tiles, 2 * nsteps, BM_SILU, vslabs, NSLAB,
+                             grads->vW, grads->vb, 1.f, st, fused_nslab)) return 1;
     }
     if (fork2) { HIPCK(hipEventRecord(g_fork.join, g_fork.s)); HIPCK(hipStreamWaitEvent(st, g_fork.join, 0)); }
     if (forked) { HIPCK(hipEventRecord(g_side.join, g_side.s)); HIPCK(hipStreamWaitEvent(st, g_side.join, 0)); }
@@ -1492,12 +1518,21 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
 }
 
 // velocity-net weight gradients from the (z, x0, g) stashes of nrep evaluations
+// fused_nslab > 0: the slabs of the four hidden layers were already written (fused_nslab of them each) by k_rk2_fuse_bwd - only the two
+// edge layers are contracted here, the reduce covers all six
 int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, const int* count, int cap_tiles, int nrep,
-                     int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st) {
+                     int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st, int fused_nslab) {
     WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
     const size_t zs = VEL_Z_REGS * REGF, gs = VEL_G_REGS * REGF, xs = VEL_X0_REGS * REGF;
     for (int l = 0; l < 6; ++l) {
         if (!gW[l] && !gb[l]) continue;
+        if (fused_nslab > 0 && l >= 1 && l <= 4) {
+            ReduceJob& Q = rj.j[rj.n++];
+            memset(&Q, 0, sizeof(Q));
+            Q.slabs = slabs + (size_t)l * nslab * SLAB_FLOATS; Q.nslab = fused_nslab; Q.MTA = 4; Q.KTB = 4; Q.gW = gW[l]; Q.gb = gb[l];
+            Q.out = 128; Q.in = 128; Q.row_kind = RK_NATURAL; Q.slot_kind = SK_HIDDEN; Q.scale = scale;
+            continue;
+        }
         WgradJob& J = wj.j[wj.n++];
         memset(&J, 0, sizeof(J));
         J.A = gst + (size_t)l * 64 * REGF; J.a_tile_stride = gs; J.a_regs = l < 5 ? 64 : 16; J.a_rep_stride = (size_t)cap_tiles * gs;

@@ -1,0 +1,562 @@
+// vel_fuse.hip - RK2 adjoint of the render warp WITH the velocity net's hidden-layer weight gradients formed in the same kernel
+// (reference: autograd of models/velocity_field.py:58-67 through models/tensorf_keyframe.py:575-611).
+//
+// k_rk2_split_bwd (vel_split.hip) writes every layer gradient g_l to a stash (336 rows per tile and evaluation) that k_wgrad_ring8 reads
+// back together with the forward's pre-activations to contract G_l = sum_samples g_l (x) act(z_{l-1}): 1.7 GB written + 1.7 GB re-read per
+// step, and two kernels that each own the matrix pipe at ~0.5 of its peak.  Here ONE persistent workgroup of TWELVE waves per CU does both:
+//
+//   * waves 0-3 ("adjoint" waves, one per SIMD, raised priority) run the dgrad chain of one 32-sample tile exactly like
+//     k_rk2_split_bwd<1>: wave w owns rows [32w, 32w+32) of every layer's input gradient, x4 transposed fragments from L2 into registers;
+//     the layer gradients g_l AND the layer inputs a_l = SiLU(z_l) (the sigmoid is shared with SiLU') go to LDS in the exchange layout,
+//     XOR-swizzled so that the same image serves the dgrad's B operand (one 16-byte read per four K steps, a lane = a sample) and the
+//     weight gradient's operands (a lane = a feature row, one 4-byte read per K step, conflict-free);
+//   * waves 4-11 ("contraction" waves, two per SIMD) hold the 4 x 16 output tiles of the four 128 x 128 weight gradients in registers for the
+//     whole launch (wave v: row tile v >> 1, column tiles 2 (v & 1), 2 (v & 1) + 1 of every layer = 128 accumulator registers) and contract
+//     the pair (g_l, a_{l-1}) of the tile as soon as both are complete - one phase behind the adjoint waves, under whose SiLU' / LDS /
+//     stash-load phases their MFMAs run;
+//   * one barrier per layer: three rotating g buffers and two a buffers (80 KB) make every buffer's last reader at least one barrier older
+//     than its next writer;
+//   * at the end every workgroup writes ONE slab per layer in k_wgrad_ring8's format: k_wgrad_reduce is unchanged.
+// The two edge layers (28 -> 128 and 128 -> 6; 16 of the 336 + 320 stash rows each way... 160 of 672 rows) still go through the stash and
+// k_wgrad_ring8: their gradients are 8 more accumulator tiles that do not fit beside the 128 registers above at three waves per SIMD.
+//
+// Numerics: every g_l is the number k_rk2_split_bwd forms (same operands, same K order); the 128 -> 28 input layer is contracted as four
+// K-quarters (one per adjoint wave) summed in wave order, and a weight gradient is summed over samples in another order than
+// k_wgrad_ring8's - differences of the order of two fp32 summation orders, as between two runs of the atomics.
+#include <stdlib.h>
+#include <stdio.h>
+#include "common.h"
+#include "vel.h"
+#include "pde.h"
+#include "fuse.h"
+
+#ifndef FUSE_THREADS
+#define FUSE_THREADS 768
+#endif
+#define FUSE_HR 33                                    // float4 per half row (32 samples of four consecutive p rows) + one float4 of padding
+#define FUSE_XB (16 * 2 * FUSE_HR)                    // float4 per exchange buffer: 16 row groups x 2 halves
+#define FUSE_NX 3
+#define FUSE_NY 2
+#define FUSE_PARK_FLOATS (16 * 64)                    // per adjoint wave: 10 record fields + the upstream gradient (4) x 64 lanes
+#define FUSE_LDS_BYTES ((FUSE_NX + FUSE_NY) * FUSE_XB * 16 + 4 * 16 * 64 * 4 + 4 * FUSE_PARK_FLOATS * 4)
+// Exchange layout: element (row p, sample s) of a 128-row x 32-sample image, p = 2 (16 w + r) + h for register r of adjoint wave w, lives in
+// float4 [(p >> 3) * 2 + (p & 1)] * 33 + s, component (p >> 1) & 3.  A lane of the dgrad (a sample) reads / writes whole float4s at
+// consecutive addresses; a lane of the weight gradient (a row p = 32 t + i) reads one float per sample at bank 4 ((2 (i >> 3) + (i & 1) + s) & 7)
+// + ((i >> 1) & 3): the 32 rows of a tile hit 32 different banks for every sample - the padding float4 is what spreads them.
+
+// LDS writes of this wave have landed, then the workgroup barrier; outstanding global loads (the next layer's z rows and weights) stay in
+// flight across it (a __syncthreads() would be free to wait for them)
+#define FUSE_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// A wave-uniform row-block pointer the optimiser cannot see through: every stash access of the block becomes SGPR base + lane offset +
+// immediate (left to itself, loop strength reduction keeps one 64-bit VGPR induction pointer per stash ROW across the layer loop: 32 registers)
+// (the asm sees a GLOBAL pointer: through a generic one the compiler falls back to flat_load / flat_store)
+typedef const __attribute__((address_space(1))) float* gcfp; typedef __attribute__((address_space(1))) float* gfp;
+__device__ __forceinline__ gcfp opaque_u(const float* p) { gcfp q = (gcfp)p; asm("" : "+s"(q)); return q; }
+__device__ __forceinline__ gfp opaque_u(float* p) { gfp q = (gfp)p; asm("" : "+s"(q)); return q; }
+
+// -DFUSE_TIMING: workgroup 0 accumulates shader-clock intervals per phase (adjoint wave 0: [0..5] MFMA part, [8..13] epilogue part,
+// [16..21] barrier wait, [24] bookkeeping between evaluations; contraction wave 0: [32..37] work, [40..45] barrier wait; [63] evaluations)
+#ifdef FUSE_TIMING
+#define FT_NOW() __builtin_amdgcn_s_memtime()
+#define FT_ADD(slot, t0) do { const unsigned long long n_ = FT_NOW(); ft[slot] += n_ - (t0); (t0) = n_; } while (0)
+#else
+#define FT_ADD(slot, t0) do { } while (0)
+#endif
+
+// LDS-DMA of one dword per lane: lane L's word at base + voff lands at lds_dst + 4 L, without passing through a VGPR - a prefetch that holds no
+// register and that the compiler can neither spill nor wait for (inline asm is outside its vmcnt bookkeeping: the reader waits itself).
+// M0 is written and restored inside the statement (wgrad_ring.hip: glds16).
+__device__ __forceinline__ void glds4(const float* base, int voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// ---------------------------------------------------------------- adjoint waves
+struct FuseA {
+    float4* X; float4* Y; float* bc;
+    int w, lane, h;
+    int pos;             // float4 index of this lane inside a row group: h * 33 + sample
+    int xw;              // X buffer that receives the next evaluation's g_4
+};
+#ifdef FUSE_TIMING
+struct FuseT { unsigned long long ft[64]; unsigned long long t0; };
+#define FT_ARG , FuseT& T
+#define FT_PASS , T
+#else
+#define FT_ARG
+#define FT_PASS
+#endif
+
+// one evaluation's adjoint: r4 = adjoint of the 6 outputs (D-layout registers 0..3), zs / gs its forward stash / adjoint stash (only the
+// g_0 and gw rows are written), zn = the forward stash of the NEXT evaluation this wave will run (its z_4 rows are prefetched) or NULL.
+// zp holds z_4 of THIS evaluation on entry and z_4 of the next one on exit.
+// w5 holds the T5 fragment on entry (requested by the previous evaluation, or by the caller for the first one) and that of the next evaluation
+// on exit (if zn); `hook()` is called once, at the end of phase 5: the caller issues its own prefetches (RK2 record of the next
+// evaluation) there.
+template <class Hook>
+__device__ __forceinline__ void fuse_velnet_bwd(FuseA& A, const float4* const* t4, const float (&r4)[4], const float* zs, float* gs,
+                                                const float* zn, f32x4v& w5, f32x4v (&wq)[16], float (&zp)[16], float (&ge)[16], Hook hook FT_ARG) {
+    const int w = A.w, lane = A.lane;
+    f32x16 acc;
+    float gv[16];
+#ifdef FUSE_TIMING
+    unsigned long long* ft = T.ft; unsigned long long& t0 = T.t0;
+    FT_ADD(24, t0);
+#endif
+    // ---- phase 0: 6 -> 128 (T5), g_4
+    // (the T4 fragment is requested here, not behind the previous evaluation's last MFMAs: 64 registers in flight across the bookkeeping
+    // between two evaluations made the compiler spill the prefetched record - and wait for it - right after its loads)
+    split_load16(t4[4] + (size_t)w * 16 * 64, lane, wq);
+    if (w == 0) {
+        gfp gw_rows = opaque_u(gs + (size_t)5 * 64 * REGF);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gw_rows[r * REGF + lane] = r < 4 ? r4[r] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+        const float a4[4] = {w5.x, w5.y, w5.z, w5.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = MFMA32(a4[k], r4[k], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gv[r] = acc[r] * act_d1<1>(zp[r]);
+    {
+        gcfp zr = opaque_u(zs + (size_t)(3 * 64 + 16 * w) * REGF);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+    }
+    int xc = A.xw;                                        // buffer of g_l for the dgrad of iteration l
+    {
+        float4* Xw = A.X + xc * FUSE_XB + (4 * w) * 2 * FUSE_HR + A.pos;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Xw[k * 2 * FUSE_HR] = make_float4(gv[4 * k], gv[4 * k + 1], gv[4 * k + 2], gv[4 * k + 3]);
+    }
+    FT_ADD(8, t0);
+    FUSE_BAR();
+    FT_ADD(16, t0);
+    // ---- phases 1..4: dgrad of layer l, then g_{l-1} and a_{l-1}
+    // (fully unrolled: with a loop, the compiler's s_waitcnt pass loses count of the z rows that are in flight across the back edge and waits
+    // for vmcnt(0) - i.e. for the weight fragment it has just requested - at the first use of a z row: 2 500 cycles per layer)
+#pragma unroll
+    for (int l = 4; l >= 1; --l) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const float4* Xr = A.X + xc * FUSE_XB + A.pos;
+            float4 b = Xr[0], bn;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                if (g + 1 < 16) bn = Xr[(g + 1) * 2 * FUSE_HR];
+                const float a4[4] = {wq[g].x, wq[g].y, wq[g].z, wq[g].w};
+                acc = MFMA32(a4[0], b.x, acc); acc = MFMA32(a4[1], b.y, acc); acc = MFMA32(a4[2], b.z, acc); acc = MFMA32(a4[3], b.w, acc);
+                b = bn;
+            }
+        }
+#ifdef FUSE_TIMING
+        asm volatile("s_nop 0" :: "v"(acc[0]));          // the interval ends when the last MFMA has delivered
+        FT_ADD(5 - l, t0);
+#endif
+        // the next layer's weights start their trip from L2 behind the last MFMA that reads the current ones
+        if (l >= 2) split_load16(t4[l - 1] + (size_t)w * 16 * 64, lane, wq);
+        else {
+            gcf4p b0 = (gcf4p)(t4[0] + (size_t)(4 * w) * 64);                                 // this wave's K quarter of the 128 -> 28 input layer
+            asm("" : "+s"(b0));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wq[k] = b0[k * 64 + lane];
+        }
+        float4* Yw = A.Y + (l & 1) * FUSE_XB + (4 * w) * 2 * FUSE_HR + A.pos;
+        if (l >= 2) {
+            xc = xc + 1 == FUSE_NX ? 0 : xc + 1;
+            float4* Xw = A.X + xc * FUSE_XB + (4 * w) * 2 * FUSE_HR + A.pos;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                     // four registers at a time: adjoint, activation, both float4s leave at once
+                float g4[4], a4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float z = zp[4 * k + c], s = fast_sigmoid(z);
+                    g4[c] = acc[4 * k + c] * (s * (1.f + z * (1.f - s)));     // act_d1<1>
+                    a4[c] = z * s;                                            // act_f<1>
+                }
+                Xw[k * 2 * FUSE_HR] = make_float4(g4[0], g4[1], g4[2], g4[3]);
+                Yw[k * 2 * FUSE_HR] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+            }
+            // (the scheduler would hoist these loads above the epilogue to hide their latency - they have a whole MFMA phase for that - and
+            // keep two generations of z rows live: 16 registers the kernel does not have)
+            __builtin_amdgcn_sched_barrier(0);
+            gcfp zr = opaque_u(zs + (size_t)((l - 2) * 64 + 16 * w) * REGF);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float z = zp[4 * k + c], s = fast_sigmoid(z);
+                    gv[4 * k + c] = acc[4 * k + c] * (s * (1.f + z * (1.f - s)));
+                    a4[c] = z * s;
+                }
+                Yw[k * 2 * FUSE_HR] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+            }
+        }
+        FT_ADD(8 + 5 - l, t0);
+        FUSE_BAR();
+        FT_ADD(16 + 5 - l, t0);
+    }
+    A.xw = A.xw + 1 == FUSE_NX ? 0 : A.xw + 1;            // four g buffers written: the rotation advances by 4 mod 3
+    // ---- phase 5: 128 -> 28 (T0), this wave's K quarter straight from its registers
+    {
+        f32x16 ao;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ao[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a4[4] = {wq[k].x, wq[k].y, wq[k].z, wq[k].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ao = MFMA32(a4[c], gv[4 * k + c], ao);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) A.bc[(w * 16 + r) * 64 + lane] = ao[r];
+        if (zn) {          // the next evaluation's first two fragments start their trip now
+            asm volatile("" :: "v"(ao[0]));
+            gcf4p b5 = (gcf4p)(t4[5] + (size_t)w * 64);
+            asm("" : "+s"(b5));
+            w5 = b5[lane];
+            // ... and its z_4 rows (not in phase 4: vmcnt completes in order, and the T0 fragment the compiler requests behind them there
+            // then waits for 16 rows from HBM in front of the MFMAs above)
+            gcfp zr = opaque_u(zn + (size_t)(4 * 64 + 16 * w) * REGF);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+        }
+    }
+    // the caller's prefetches (LDS-DMA, invisible to the compiler's vmcnt bookkeeping) go LAST in the phase: every counted wait the compiler
+    // places behind them is 10 too strict - in front of the T0 MFMAs that meant waiting for phase 4's stash stores and z rows (4 000 cycles)
+    __builtin_amdgcn_sched_barrier(0);
+    hook();
+    // g_0, the A operand of the input layer's weight gradient (k_wgrad_ring8), leaves last of all: vmcnt completes in order, so a wait for
+    // ANY load issued behind these 16 stores also waits for their acknowledgement from memory - in phase 4, in front of the T0 fragment, that
+    // was 4 000 cycles.  Behind them come the barrier and the bookkeeping between two evaluations; the next evaluation's first wait names them
+    // (vmcnt(16): everything older - the DMAs above - has landed, the stores may still be under way).
+    {
+        gfp gr = opaque_u(gs + (size_t)(16 * w) * REGF);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) STASH_ST(gr[r * REGF + lane], gv[r]);
+    }
+    FT_ADD(5, t0);
+    FUSE_BAR();
+    FT_ADD(21, t0);
+#ifdef FUSE_TIMING
+    ft[63] += 1;
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // sixteen partial sums in flight at a time, not all 64 (registers)
+        ge[r] = ((A.bc[r * 64 + lane] + A.bc[(16 + r) * 64 + lane]) + A.bc[(32 + r) * 64 + lane]) + A.bc[(48 + r) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// adjoint of the PositionEncoder at q = (x, y, z, t): vel_encode_slots + vel_encode_bwd of engine.h in one pass, four slots at a time (the two
+// library forms together keep 16 encoder slots and the temporaries of twelve argument reductions live at once: the register peak of the
+// whole adjoint role)
+__device__ __forceinline__ float4 fuse_encode_bwd(const float4& q, const float (&ge)[16], int h) {
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        __builtin_amdgcn_sched_barrier(0);
+        const float fr = (float)(1 << k);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float mine = trig_sel(comp4(q, c) * fr, h);      // sin (h = 0) or cos (h = 1)
+            const float other = __shfl_xor(mine, 32);
+            g[c] += (h ? -fr * other : fr * other) * ge[2 + 4 * k + c];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float r0 = ge[0], r1 = ge[1];
+    float gx = g[0] + (h ? 0.f : r0), gy = g[1] + (h ? r0 : 0.f), gz = g[2] + (h ? 0.f : r1), gt = g[3] + (h ? r1 : 0.f);
+    gx += __shfl_xor(gx, 32); gy += __shfl_xor(gy, 32); gz += __shfl_xor(gz, 32); gt += __shfl_xor(gt, 32);
+    return make_float4(gx, gy, gz, gt);
+}
+
+// RK2 record of one evaluation (the forward's k_rk2_split_uni wrote it): the point the network was evaluated at, its six outputs, the step's
+// gate / rejection flags.  Loaded RAW one evaluation ahead (inactive lanes read sample 0 and are masked when the record is consumed):
+// one straight-line block of ten loads off wave-uniform bases, no select - and therefore no wait - next to the loads.
+// every adjoint wave parks its OWN copy (identical data, 2.5 KB): no cross-wave dependency, the wave only has to wait for its own DMAs
+__device__ __forceinline__ void fuse_park_rec(const Rk2Args& ra, int s, int e, int ii, unsigned park_lds) {
+    const int po = e ? 3 : 0, wo = e ? 12 : 6;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float* fb = ra.rec + ((size_t)s * RK_NF + (k < 3 ? po + k : (k < 9 ? wo + k - 3 : 18))) * ra.cap;
+        glds4(fb, ii * 4, park_lds + k * 256);
+    }
+}
+
+__device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* X, float4* Y, float* bc, int w, int lane, int ntiles) {
+    const Rk2Args& ra = a.r;
+    FuseA A; A.X = X; A.Y = Y; A.bc = bc; A.w = w; A.lane = lane; A.h = lane >> 5; A.xw = 0;
+    const int h = A.h, j = lane & 31;
+    A.pos = h * FUSE_HR + j;
+#ifdef FUSE_TIMING
+    FuseT T;
+    for (int k = 0; k < 64; ++k) T.ft[k] = 0;
+    T.t0 = FT_NOW();
+#endif
+    const int count = __builtin_amdgcn_readfirstlane(*ra.count), G = gridDim.x;      // (an SGPR: as a VGPR it is spilled and reloaded in the hot phases)
+    const int nsteps = ra.nsteps;
+    const size_t zt = (size_t)VEL_Z_REGS * REGF, gt = (size_t)VEL_G_REGS * REGF;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    // everything an evaluation needs from memory is requested one evaluation (record, first fragments, z_4 rows) or one tile (upstream
+    // gradient) ahead: a dependent HBM round trip is 2-4 k cycles here, and the adjoint waves' serial chain is what paces the kernel
+    float zp[16];
+    f32x4v w5, wq[16];
+    // record of the next evaluation / upstream gradient of the next tile: parked in this wave's LDS area by LDS-DMA ([field][lane])
+    float* park = bc + 4 * 16 * 64 + w * FUSE_PARK_FLOATS;
+    const unsigned park_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(park));
+    int idx = tile * TILE + j;
+    bool active = idx < count;
+    bool first_eval = true;
+    {
+        const float* z0 = ra.zst + ((size_t)(2 * (nsteps - 1) + 1) * ra.cap_tiles + tile) * zt;
+        gcfp zr = opaque_u(z0 + (size_t)(4 * 64 + 16 * w) * REGF);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+        gcf4p b5 = (gcf4p)(a.t4[5] + (size_t)w * 64);
+        asm("" : "+s"(b5));
+        w5 = b5[lane];
+        const float4 gin0 = ra.gxk[ra.list[active ? idx : 0]];
+        park[10 * 64 + lane] = gin0.x; park[11 * 64 + lane] = gin0.y; park[12 * 64 + lane] = gin0.z;
+        fuse_park_rec(ra, nsteps - 1, 1, active ? idx : 0, park_lds);
+    }
+#pragma unroll 1
+    for (; tile < ntiles; tile += G) {
+        if (first_eval) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's DMAs into its parking area have landed
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        float g3[3] = {active ? park[10 * 64 + lane] : 0.f, active ? park[11 * 64 + lane] : 0.f, active ? park[12 * 64 + lane] : 0.f};     // upstream gradient of the warped position
+        const bool more_tiles = tile + G < ntiles;
+        const int idx_t = (tile + G) * TILE + j;                 // this lane's sample in the next tile
+        const bool active_t = more_tiles && idx_t < count;
+        int list_t = 0;
+#pragma unroll 1
+        for (int s = nsteps - 1; s >= 0; --s) {
+            const float dt = RK_DT(ra, s), tcur = RK_TC(ra, s);
+            float gacc[3] = {0.f, 0.f, 0.f}, gup[3] = {g3[0], g3[1], g3[2]};
+            bool rej = true;
+#pragma unroll 1
+            for (int e = 1; e >= 0; --e) {
+                const float coef = e ? -dt : -0.5f * dt;
+                const float te = e ? tcur - 0.5f * dt : tcur;
+                const size_t es = (size_t)(2 * s + e) * ra.cap_tiles + tile;
+                const bool last_of_tile = s == 0 && e == 0;
+                // the evaluation this wave runs next: (sn, en) of tile tn
+                const bool has_next = !last_of_tile || more_tiles;
+                const int sn = e == 1 ? s : (s > 0 ? s - 1 : nsteps - 1), en = e == 1 ? 0 : 1;
+                const int tn = last_of_tile ? tile + G : tile;
+                const int iin0 = last_of_tile ? (active_t ? idx_t : 0) : (active ? idx : 0);
+                const float* zn = has_next ? ra.zst + ((size_t)(2 * sn + en) * ra.cap_tiles + tn) * zt : nullptr;
+                if (last_of_tile && more_tiles) list_t = ra.list[iin0];      // (first half of the next tile's dependent pair of loads)
+                // this evaluation's record (DMA'd into the parking area during the previous evaluation's last phase, in front of its 16 g_0 stores)
+                if (first_eval) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                first_eval = false;
+                float p[3], wv[6];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[c] = active ? park[c * 64 + lane] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) wv[k] = active ? park[(3 + k) * 64 + lane] : 0.f;
+                const int flags = active ? __float_as_int(park[9 * 64 + lane]) : 7;
+                const bool gate = e ? (flags & 2) : (flags & 1);
+                rej = flags & 4;
+                float gvv[3], gw[6], gloc[3], r4[4], ge[16];
+                const bool on = active && !rej && !gate;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gvv[c] = on ? coef * gup[c] : 0.f;
+                gw[0] = gvv[0]; gw[1] = gvv[1]; gw[2] = gvv[2];
+                gw[3] = p[2] * gvv[1] - p[1] * gvv[2];
+                gw[4] = -p[2] * gvv[0] + p[0] * gvv[2];
+                gw[5] = p[1] * gvv[0] - p[0] * gvv[1];
+                gloc[0] = -wv[5] * gvv[1] + wv[4] * gvv[2];
+                gloc[1] = wv[5] * gvv[0] - wv[3] * gvv[2];
+                gloc[2] = -wv[4] * gvv[0] + wv[3] * gvv[1];
+                scatter6(gw, h, r4);
+                auto prefetch = [&]() {
+                    // (the sample index is re-derived from the lane id here, behind an asm the optimiser cannot see through: carried from the
+                    // top of the evaluation it is spilled, and a scratch reload in this phase waits - vmcnt(0) - for the 16 stash stores and
+                    // the 16 z rows phase 4 has just queued: 5 000 cycles)
+                    const int j2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 31;     // (two VALU instructions, no reload)
+                    const int in2 = tn * TILE + j2;
+                    const int iin = in2 < count ? in2 : 0;
+                    if (has_next) fuse_park_rec(ra, sn, en, iin, park_lds);
+                    if (last_of_tile && more_tiles) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) glds4(reinterpret_cast<const float*>(ra.gxk) + c, list_t * 16, park_lds + (10 + c) * 256);
+                    }
+                };
+                fuse_velnet_bwd(A, a.t4, r4, ra.zst + es * zt, ra.gst + es * gt, zn, w5, wq, zp, ge, prefetch FT_PASS);
+                const float4 gq = fuse_encode_bwd(make_float4(p[0], p[1], p[2], te), ge, h);
+                gloc[0] += gq.x; gloc[1] += gq.y; gloc[2] += gq.z;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { gacc[c] += gloc[c]; gup[c] = gloc[c]; }
+            }
+            if (active && !rej) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g3[c] = g3[c] + gacc[c] + 0.f;
+            }
+        }
+        idx = idx_t; active = active_t;
+    }
+#ifdef FUSE_TIMING
+    if (a.timing && blockIdx.x == 0 && w == 0 && lane == 0)
+        for (int k = 0; k < 64; ++k) if (k < 32 || k == 63) a.timing[k] = T.ft[k];
+#endif
+}
+
+// ---------------------------------------------------------------- contraction waves
+// the barrier of the contraction waves names the accumulators as in/out operands: an MFMA is a pure register operation that the
+// instruction selector is otherwise free to place behind any later barrier, with its 48 operands of the phase spilled across it
+#define FUSE_BAR_G() do { __builtin_amdgcn_sched_barrier(0);                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(G0a), "+v"(G0b), "+v"(G1a), "+v"(G1b), "+v"(G2a), "+v"(G2b), "+v"(G3a), "+v"(G3b) :: "memory"); \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+// G[L][t] += sum over the tile's 32 samples of g[32 ob + row][s] * a[32 (ib0 + t) + col][s]
+#define FUSE_TF (4 * 2 * FUSE_HR * 4)      // floats per 32-row tile of an exchange buffer
+#define FUSE_CONTRACT(L, XF, YF)                                                                                     \
+    do {                                                                                                             \
+        const float* xa_ = (XF) + ob * FUSE_TF + o; const float* yb_ = (YF) + ib0 * FUSE_TF + o;                     \
+        _Pragma("unroll") for (int st = 0; st < 16; ++st) {                                                          \
+            const float av_ = xa_[8 * st], b0_ = yb_[8 * st], b1_ = yb_[8 * st + FUSE_TF];                            \
+            G##L##a = MFMA32(av_, b0_, G##L##a); G##L##b = MFMA32(av_, b1_, G##L##b);                               \
+            asm("v_add_f32 %0, %0, %1" : "+v"(bs##L) : "v"(av_));   /* (plain C: the SLP vectoriser pairs the four sums into v_pk_add chains with moves and spills) */ \
+        }                                                                                                            \
+    } while (0)
+
+__device__ __forceinline__ void fuse_role_contract(const FuseBwdArgs& a, const float* Xf, const float* Yf, int v, int lane, int ntiles) {
+    const int i = lane & 31, kk = lane >> 5;
+    const int ob = v >> 1, ib0 = 2 * (v & 1);
+    // float offset of (row i of a 32-row tile, sample kk) in an exchange buffer
+    const int o = ((i >> 3) * 2 + (i & 1)) * (FUSE_HR * 4) + ((i >> 1) & 3) + 4 * kk;      // MFMA step st contracts sample 2 st + kk: + 8 st floats
+    f32x16 G0a, G0b, G1a, G1b, G2a, G2b, G3a, G3b;
+    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { G0a[r] = 0.f; G0b[r] = 0.f; G1a[r] = 0.f; G1b[r] = 0.f; G2a[r] = 0.f; G2b[r] = 0.f; G3a[r] = 0.f; G3b[r] = 0.f; }
+    const int G = gridDim.x;
+    const int nsteps = a.r.nsteps;
+    int xr = 0;                                           // X buffer holding g_4 of the current evaluation
+#ifdef FUSE_TIMING
+    unsigned long long ft[64]; for (int k = 0; k < 64; ++k) ft[k] = 0;
+    unsigned long long t0 = FT_NOW();
+#endif
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+#pragma unroll 1
+        for (int ev = 0; ev < 2 * nsteps; ++ev) {
+            const int x1 = xr + 1 == FUSE_NX ? 0 : xr + 1, x2 = x1 + 1 == FUSE_NX ? 0 : x1 + 1;
+            FT_ADD(32, t0); FUSE_BAR_G(); FT_ADD(40, t0);                   // g_4 written
+            FUSE_BAR_G(); FT_ADD(41, t0);                                   // g_3, a_3 written
+            FUSE_CONTRACT(3, Xf + xr * (FUSE_XB * 4), Yf);                   // layer 4: g_4 (x) a_3
+            FT_ADD(34, t0); FUSE_BAR_G(); FT_ADD(42, t0);                   // g_2, a_2
+            FUSE_CONTRACT(2, Xf + x1 * (FUSE_XB * 4), Yf + FUSE_XB * 4);     // layer 3
+            FT_ADD(35, t0); FUSE_BAR_G(); FT_ADD(43, t0);                   // g_1, a_1
+            FUSE_CONTRACT(1, Xf + x2 * (FUSE_XB * 4), Yf);                   // layer 2
+            FT_ADD(36, t0); FUSE_BAR_G(); FT_ADD(44, t0);                   // a_0
+            FUSE_CONTRACT(0, Xf + xr * (FUSE_XB * 4), Yf + FUSE_XB * 4);     // layer 1: g_1 sits in the buffer g_4 left
+            FT_ADD(37, t0); FUSE_BAR_G(); FT_ADD(45, t0);
+            xr = x1;
+        }
+    }
+#ifdef FUSE_TIMING
+    if (a.timing && blockIdx.x == 0 && v == 0 && lane == 0)
+        for (int k = 32; k < 48; ++k) a.timing[k] = ft[k];
+#endif
+    // one slab per layer and workgroup, in k_wgrad_ring8's format (rows / columns in p-space, bias sums behind the 128 x 128 block)
+#define FUSE_FLUSH(L)                                                                                                \
+    do {                                                                                                             \
+        float* S = a.slabs + (size_t)((L) + 1) * a.layer_stride + (size_t)blockIdx.x * a.slab_floats;                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                             \
+            const int row = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * kk;                                               \
+            S[(size_t)row * 128 + 32 * ib0 + i] = G##L##a[r];                                                        \
+            S[(size_t)row * 128 + 32 * (ib0 + 1) + i] = G##L##b[r];                                                  \
+        }                                                                                                            \
+        if ((v & 1) == 0) {                                                                                          \
+            float bsum = bs##L; bsum += __shfl_xor(bsum, 32);                                                        \
+            if (kk == 0) S[(size_t)128 * 128 + 32 * ob + i] = bsum;                                                  \
+        }                                                                                                            \
+    } while (0)
+    FUSE_FLUSH(0); FUSE_FLUSH(1); FUSE_FLUSH(2); FUSE_FLUSH(3);
+#undef FUSE_FLUSH
+}
+
+__global__ __launch_bounds__(FUSE_THREADS) void k_rk2_fuse_bwd(FuseBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* X = reinterpret_cast<float4*>(lds);
+    float4* Y = X + FUSE_NX * FUSE_XB;
+    float* bc = reinterpret_cast<float*>(Y + FUSE_NY * FUSE_XB);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int count = __builtin_amdgcn_readfirstlane(*a.r.count);
+    // whole 128-sample groups, as the forward stashed them
+    const int ntiles = (count + WG_SAMPLES - 1) / WG_SAMPLES * (WG_SAMPLES / TILE);
+#if defined(FUSE_ONLY_A)
+    if (true) {
+#elif defined(FUSE_ONLY_B)
+    if (false) {
+#else
+    if (wave < 4) {
+#endif
+        __builtin_amdgcn_s_setprio(3);
+        fuse_role_adjoint(a, X, Y, bc, wave, lane, ntiles);
+    } else {
+        fuse_role_contract(a, lds, lds + FUSE_NX * FUSE_XB * 4, wave - 4, lane, ntiles);
+    }
+}
+
+int launch_rk2_fuse_bwd(const FuseBwdArgs& a, int64_t cap_samples, int max_slabs, int* nslab_out, hipStream_t st) {
+    *nslab_out = 0;
+    const int64_t tiles = (cap_samples + TILE - 1) / TILE;
+    if (tiles <= 0) return 0;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t prop;
+        ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_fuse_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES));
+    }
+    int G = ncu < max_slabs ? ncu : max_slabs;
+    if ((int64_t)G > tiles) G = (int)tiles;
+    ProfScope ps(PK_RK2_BWD, st);
+#ifdef FUSE_TIMING
+    static unsigned long long* tbuf = nullptr; static int shots = 0;
+    if (!tbuf) { HIPCK(hipMalloc(&tbuf, 64 * 8)); }
+    FuseBwdArgs b = a; b.timing = tbuf;
+    HIPCK(hipMemsetAsync(tbuf, 0, 64 * 8, st));
+    hipLaunchKernelGGL(k_rk2_fuse_bwd, dim3((unsigned)G), dim3(FUSE_THREADS), FUSE_LDS_BYTES, st, b);
+    if (++shots % 8 == 0 && shots <= 64) {
+        unsigned long long h[64];
+        HIPCK(hipStreamSynchronize(st));
+        HIPCK(hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost));
+        const double n = h[63] ? (double)h[63] : 1.0;
+        fprintf(stderr, "[fuse timing] evals %llu | A mfma", h[63]);
+        for (int k = 0; k < 6; ++k) fprintf(stderr, " %.0f", h[k] / n);
+        fprintf(stderr, " | A epi");
+        for (int k = 0; k < 6; ++k) fprintf(stderr, " %.0f", h[8 + k] / n);
+        fprintf(stderr, " | A wait");
+        for (int k = 0; k < 6; ++k) fprintf(stderr, " %.0f", h[16 + k] / n);
+        fprintf(stderr, " | A between %.0f | B work", h[24] / n);
+        for (int k = 0; k < 6; ++k) fprintf(stderr, " %.0f", h[32 + k] / n);
+        fprintf(stderr, " | B wait");
+        for (int k = 0; k < 6; ++k) fprintf(stderr, " %.0f", h[40 + k] / n);
+        fprintf(stderr, "\n");
+    }
+#else
+    hipLaunchKernelGGL(k_rk2_fuse_bwd, dim3((unsigned)G), dim3(FUSE_THREADS), FUSE_LDS_BYTES, st, a);
+#endif
+    LAUNCHCK();
+    *nslab_out = G;
+    return 0;
+}

@@ -27,6 +27,21 @@ class Ray(torch.nn.Module):
             return buf
         return super().__getattr__(name)
 
+    def _apply(self, fn, *a, **k):
+        """`.to()` / `.cuda()` / `.float()` also move the not-yet-materialised near / far / t tensors (the reference registers them in
+        __init__, models/camera.py:38-44, so they follow the module; a pending tensor left behind would meet buffers on another device)"""
+        lazy = self.__dict__.get("_lazy")
+        if lazy:
+            for name in list(lazy):
+                if isinstance(lazy[name], torch.Tensor):
+                    lazy[name] = fn(lazy[name])
+        return super()._apply(fn, *a, **k)
+
+    def state_dict(self, *a, **k):
+        for name in list(self.__dict__.get("_lazy") or ()):      # the reference's keys: ray_origins, ray_directions, near, far, t
+            getattr(self, name)
+        return super().state_dict(*a, **k)
+
     def update_near_far(self, near, far):
         for k, v in (("near", near), ("far", far)):
             self.__dict__["_lazy"].pop(k, None)
@@ -86,12 +101,20 @@ class Camera(object):
             self._coords = torch.stack([ii, jj], dim=-1).reshape(-1, 2)
         return self._coords
 
+    @coords.setter
+    def coords(self, v):          # plain attributes in the reference (camera.py:96-101): a caller may assign them
+        self._coords = v
+
     @property
     def rays(self):
         if self._rays is None:
             ray_origins, ray_directions = self.get_ray_bundle()
             self._rays = Ray(ray_origins, ray_directions, self.near, self.far, self.t)
         return self._rays
+
+    @rays.setter
+    def rays(self, v):
+        self._rays = v
 
     def get_ray_bundle(self):
         X, Y = torch.meshgrid(torch.arange(self.width, dtype=self.pose.dtype, device=self.pose.device),

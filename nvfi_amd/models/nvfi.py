@@ -21,11 +21,16 @@ class NVFi(nn.Module):
 
     def train(self, mode=True):
         """train_nvfi.py:141-142 calls nvfi.train(); renderer.train() every iteration; walking ~180 sub-modules twice per step is 0.7 ms
-        of pure host time.  The mode of this subtree only ever changes through this method, so an unchanged mode returns at once."""
-        if self.training == bool(mode) and self.__dict__.get("_mode_walked") == bool(mode):
-            return self
+        of pure host time, so an unchanged mode returns at once.  "Unchanged" is checked on this module, on the field and on the field's
+        direct children (tests and drivers call model.nvfi.eval() / .train() on the inner field, and mask_field / alphaMask are attached
+        later): a handful of attribute reads, not the 180-module walk."""
+        mode = bool(mode)
+        if self.training == mode and self.__dict__.get("_mode_walked") == mode:
+            f = self._modules.get("nvfi")
+            if f is None or (f.training == mode and all(c.training == mode for c in f._modules.values() if c is not None)):
+                return self
         super().train(mode)
-        self.__dict__["_mode_walked"] = bool(mode)
+        self.__dict__["_mode_walked"] = mode
         return self
 
     def render_ray(self, t, ray_o, ray_d, white_bg=True, ndc_ray=False):

@@ -355,14 +355,17 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             raise NotImplementedError("contract_ray is out of scope")
         self.last_counters = None
         # Where the backward kernels put parameter gradients:
-        #   "arena" (default)  straight into p.grad, which the field backs with ONE persistent flat buffer that it zeroes once per
-        #                      iteration (when the driver's zero_grad(set_to_none=True) left every .grad None): no fresh 38 MB gradient
-        #                      tensors and no AccumulateGrad add per parameter and backward node.  p.grad tensors are therefore re-used
-        #                      across iterations (aliasing: keep a .clone() if you need last iteration's values) and autograd hooks on
-        #                      the parameters do not fire; torch.autograd.grad() callers want False.
+        #   False (default)    pure autograd: gradients are returned to the engine - torch.autograd.grad(), parameter hooks and
+        #                      post-accumulate-grad hooks (DDP, optimiser-in-backward, clipping hooks) behave as for any nn.Module
+        #   "arena" (opt-in: NVFI_INPLACE_GRADS=arena, field.accumulate_grads_inplace = "arena"; bench.py --mode dropin and
+        #                      tools/run_reference_driver.py switch it on) straight into p.grad, which the field backs with ONE persistent
+        #                      flat buffer that it zeroes once per iteration (when the driver's zero_grad(set_to_none=True) left every
+        #                      .grad None): no fresh 38 MB gradient tensors and no AccumulateGrad add per parameter and backward node.
+        #                      p.grad tensors are then re-used across iterations (aliasing: keep a .clone() if you need last iteration's
+        #                      values) and the engine is handed None for the parameters; a field with ANY autograd hook on a parameter
+        #                      falls back to pure autograd for that call
         #   True               same, but the caller owns p.grad (nvfi_amd.dist.GradBucket: every .grad is a view of its flat buffer)
-        #   False              pure autograd: gradients are returned to the engine (NVFI_INPLACE_GRADS=0)
-        self.accumulate_grads_inplace = "arena" if os.environ.get("NVFI_INPLACE_GRADS", "1") != "0" else False
+        self.accumulate_grads_inplace = "arena" if os.environ.get("NVFI_INPLACE_GRADS", "0") in ("1", "arena") else False
         # Opt-in (NVFI_AUTO_OVERLAP=1): train-mode render / PDE calls run on the field's own side streams (the caller's stream waits for
         # the results), so that the chains of an iteration - and their backward passes, which autograd runs on the stream of the forward -
         # can overlap on the device under a sequential driver.  MEASURED SLOWER under the reference's loop (bench.py --mode dropin:
@@ -581,6 +584,11 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         as it is when its layout matches the parameter's; otherwise None is returned and the call falls back to pure autograd.
         want_tail: return the flat view that covers the 24 velocity-net tensors instead (they are contiguous at the end)."""
         ps = self._arena_params()
+        # a hook on any parameter (tensor hooks, post-accumulate-grad hooks: DDP, optimiser-in-backward, clipping) only fires when the
+        # engine itself accumulates the gradient: such a field gets pure autograd
+        for p in ps:
+            if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+                return None
         key = tuple((id(p), tuple(p.shape), p.stride()) for p in ps)
         a = _rt(self).get("_arena")
         if a is None or a["key"] != key or a["flat"].device != ps[0].device:

@@ -195,3 +195,47 @@ def test_traffic_classes_match_the_committed_counter_pass(tmp_path):
     committed = json.load(open(os.path.join(prof, f"{tag}_traffic.json")))["bytes_per_launch"]
     assert committed == pytest.approx(fresh)
     assert committed["pde_prefilter"] > 1e6
+
+
+def test_train_short_circuit_sees_mode_changes_made_on_the_inner_field():
+    """NVFi.train() returns early for an unchanged mode (train_nvfi.py:141-142 calls it every iteration), but a mode set on the inner field -
+    model.nvfi.eval(), as tests and the golden scripts do - or on a module attached later must not survive the next model.train()"""
+    m, _ = make_model("A", "cpu")
+    m.train()
+    assert m.nvfi.training and m.nvfi.vel_net.training
+    m.train()                                   # the short-circuit path
+    m.nvfi.eval()                               # behind the wrapper's back
+    assert not m.nvfi.training and m.training
+    m.train()
+    assert m.nvfi.training and all(c.training for c in m.nvfi.modules())
+    m.eval(); m.eval()
+    m.nvfi.renderModule.train()                 # one direct child flipped
+    m.eval()
+    assert not any(c.training for c in m.modules())
+    m.train()
+    from nvfi_amd.models.mask_field import MaskField
+    m.nvfi.mask_field = MaskField(4).eval()     # attached later, in another mode
+    m.train()
+    assert m.nvfi.mask_field.training
+
+
+def test_gradient_arena_is_opt_in():
+    """the default autograd contract of a drop-in nn.Module: gradients go back to the engine (torch.autograd.grad, hooks); the in-place
+    arena is something a driver switches on (NVFI_INPLACE_GRADS=arena, bench.py --mode dropin, tools/run_reference_driver.py)"""
+    m, _ = make_model("A", "cpu")
+    assert m.nvfi.accumulate_grads_inplace is False
+    src = open(os.path.join(ROOT, "tools", "run_reference_driver.py")).read()
+    assert 'setdefault("NVFI_INPLACE_GRADS", "arena")' in src and "--pure-autograd" in src
+
+
+def test_ray_lazy_buffers_follow_the_module_and_camera_attributes_are_assignable():
+    from nvfi_amd.models import Ray, Camera
+    o, d = torch.zeros(5, 3), torch.ones(5, 3)
+    r = Ray(o, d, torch.full((5, 1), 2.0), 6.0, t=torch.full((5, 1), 0.25))
+    r2 = r.to(torch.float64)                                   # pending tensors are converted with the buffers
+    assert r2.near.dtype == torch.float64 and r2.t.dtype == torch.float64 and r2.far.dtype == torch.float64
+    assert set(Ray(o, d, 2.0, 6.0).state_dict()) == {"ray_origins", "ray_directions", "near", "far", "t"}
+    cam = Camera(torch.eye(4), 4, 6, 5.0, torch.zeros(4, 6, 3), 2.0, 6.0)
+    rays = cam.rays
+    cam.rays = rays; cam.coords = cam.coords                   # attributes in the reference, assignable here too
+    assert cam.rays is rays

@@ -267,6 +267,40 @@ def test_plane_regularisers(gold, models, kind):
     assert n == 9
 
 
+def test_default_autograd_contract_and_arena_hook_fallback(gold, models):
+    """by default the field behaves like any nn.Module under autograd - torch.autograd.grad returns the gradients and leaves .grad alone,
+    parameter hooks fire; with the opt-in arena a field that carries a hook on any parameter falls back to pure autograd by itself"""
+    model, meta = models["A"]
+    f = model.nvfi
+    assert f.accumulate_grads_inplace is False
+    ps = [f.density_plane_space[0], f.vel_net.weight_net[1].weight, f.renderModule.mlp[0].weight]
+
+    def loss_of():
+        torch.manual_seed(21)
+        out = _render(model, meta, gold, "A", 19.0 / 60.0, "train")
+        return out[0].mean() + 0.01 * out[1].mean()
+
+    model.zero_grad(set_to_none=True)
+    gs = torch.autograd.grad(loss_of(), ps)
+    assert all(g is not None and torch.isfinite(g).all() and g.abs().max() > 0 for g in gs)
+    assert all(p.grad is None for p in ps)
+    fired = []
+    h = ps[1].register_hook(lambda g: fired.append(float(g.abs().max())))
+    try:
+        for mode in (False, "arena"):
+            f.accumulate_grads_inplace = mode
+            model.zero_grad(set_to_none=True)
+            fired.clear()
+            loss_of().backward()
+            assert len(fired) == 1 and fired[0] > 0, (mode, fired)
+            for p, g in zip(ps, gs):
+                assert relerr(p.grad.cpu().numpy(), g.cpu().numpy()) < 2e-4
+    finally:
+        h.remove()
+        f.accumulate_grads_inplace = False
+        model.zero_grad(set_to_none=True)
+
+
 def test_inplace_gradient_accumulation_matches_autograd(gold, models):
     """accumulate_grads_inplace (kernels add into p.grad / GradBucket views) == ordinary autograd gradients"""
     from nvfi_amd.dist import GradBucket

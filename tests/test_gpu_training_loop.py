@@ -43,13 +43,13 @@ def test_three_training_iterations_match_the_reference(driver):
         optimizer = Adam(groups, betas=(0.9, 0.99))
         f.accumulate_grads_inplace = True
     else:
-        # "dropin": the field's defaults under a plain autograd driver (in-place gradient arena);
-        # "dropin-pure-autograd": gradients handed back to the autograd engine, everything on the caller's stream (round-2 behaviour)
+        # "dropin": a plain autograd driver with the opt-in gradient arena (what tools/run_reference_driver.py and bench.py --mode dropin switch on);
+        # "dropin-pure-autograd": the library default - gradients handed back to the autograd engine, everything on the caller's stream
         # "dropin-side-streams": + the opt-in auto_overlap (train-mode calls on the field's own streams, joined at the end of backward)
         if driver == "dropin-pure-autograd":
-            f.accumulate_grads_inplace, f.auto_overlap = False, False
+            assert f.accumulate_grads_inplace is False and not f.auto_overlap      # the library default
         else:
-            assert f.accumulate_grads_inplace == "arena" and not f.auto_overlap
+            f.accumulate_grads_inplace = "arena"                                     # what tools/run_reference_driver.py / bench.py --mode dropin switch on
             f.auto_overlap = driver == "dropin-side-streams"
         driver = "dropin"
         optimizer = torch.optim.Adam(groups, betas=(0.9, 0.99))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Run the reference's OWN training driver on the MI355X-native hot path.
 
-    python tools/run_reference_driver.py [--check] [--stub-missing] [--fused-adam] /path/to/NVFi/train_nvfi.py --config config/InDoorObj/bat.yaml --static_dynamic
+    python tools/run_reference_driver.py [--check] [--stub-missing] [--fused-adam] [--pure-autograd] /path/to/NVFi/train_nvfi.py --config config/InDoorObj/bat.yaml --static_dynamic
 
 Why a launcher: `python train_nvfi.py` puts the SCRIPT's directory at sys.path[0], ahead of PYTHONPATH, so `from models import *`
 (train_nvfi.py:16) would still resolve to the reference's own `models/` package.  This launcher runs the untouched script with
@@ -17,6 +17,10 @@ so `models` is the HIP-backed mirror and everything else the driver imports (`ut
                  `fused=True` - the same update rule in one pass per parameter group instead of torch's default ~60 multi-tensor launches, which
                  re-read the 38 MB of plane parameters, gradients and moments a dozen times (0.73 of the 8.0 ms of an iteration on an MI355X).
                  The driver's source is not touched; results differ from the default implementation by rounding only.  Off by default.
+--pure-autograd  leave the library default (parameter gradients handed back to the autograd engine).  WITHOUT this flag the launcher sets
+                 NVFI_INPLACE_GRADS=arena before `models` is imported: the kernels accumulate into a gradient arena that backs p.grad (no fresh
+                 38 MB gradient tensors per backward node; INTEGRATION.md section 3 states what that changes for a caller: .grad tensors are
+                 re-used across iterations, and a field with autograd hooks on a parameter falls back to pure autograd by itself).
 --stub-missing   register empty placeholder modules for optional third-party imports of the reference that are absent on this host
                  (wandb, lpips, imageio, cv2, torchvision: logging / metrics / dataset decoding, never the render or training math).  Off by default.
 """
@@ -92,7 +96,7 @@ def fused_adam_default():
     torch.optim.Adam = Adam
 
 
-FLAGS = ("--check", "--stub-missing", "--fused-adam")
+FLAGS = ("--check", "--stub-missing", "--fused-adam", "--pure-autograd")
 
 
 def main(argv):
@@ -101,6 +105,8 @@ def main(argv):
     if not rest or not os.path.isfile(rest[0]):
         raise SystemExit(__doc__)
     script, args = rest[0], rest[1:]
+    if "--pure-autograd" not in flags:
+        os.environ.setdefault("NVFI_INPLACE_GRADS", "arena")       # read when the field is constructed
     sdir = order_sys_path(script)
     stubs = stub_missing() if "--stub-missing" in flags else []
     where = resolve()
