@@ -93,6 +93,62 @@ def build_scene(device, G=199, S=128, use_vel=True, seed=233):
     return m
 
 
+def chessboard_cfg():
+    from nvfi_amd.utils import CfgNode
+    # values of config/InDoorSeg/chessboard.yaml that reach the hot path (reference lines 53, 64-68, 85-87, 101-103, 119-121, 137), restated
+    n = dict(model_name="TensorVMKeyframeTimeKplane", density_n_comp=[24, 24, 24], appearance_n_comp=[48, 48, 48], app_dim=32,
+             densityMode="Density", shadingMode="MLP_PE", alphaMask_thres=1e-4, rayMarch_weight_thres=1e-4, density_shift=-5,
+             distance_scale=10, pos_pe=6, view_pe=6, fea_pe=6, featureC=128, step_ratio=0.5, fea2denseAct="softplus",
+             max_n_samples=1024, num_keyframes=4, num_keyframes_end=4, tmax=0.75, use_vel=True,
+             sur_x=[-2.5, 2.5], sur_y=[-2.5, 2.5], sur_z=[0.02, 5.95])
+    return CfgNode(dict(nvfi=n))
+
+
+def build_scene_chessboard(device, final=True, seed=233):
+    """BASELINE configs[3] ('chessboard dynamic indoor scene'): the InDoorSeg box (x, y in +-3.03, z in [-0.03, 6.03]), surround-box velocity gate
+    with step rejection, K = 4 keyframes, no white background; a Gaussian blob in the density planes (the initial field is transparent) and a
+    velocity head scaled so that the gate is exercised - the recipe of tests/test_gpu_fullsize_chessboard.py.  final: the 64^3 field upsampled to
+    the LAST entry of the shipped voxel schedule, 199 x 199 x 200 (688 samples per ray: 1.4 M samples per 2048-ray render); else 64^3 / 219."""
+    from nvfi_amd.models import NVFi
+    from nvfi_amd.utils import N_to_reso
+    torch.manual_seed(seed)
+    aabb = torch.tensor([[-3.03, -3.03, -0.03], [3.03, 3.03, 6.03]])
+    m = NVFi(chessboard_cfg(), "cpu", aabb, [64, 64, 64], [0.8, 8.1])
+    f = m.nvfi
+    with torch.no_grad():
+        for i in range(3):
+            p = f.density_plane_space[i]
+            H, W = p.shape[-2:]
+            yy = torch.linspace(-1, 1, H)[:, None]; xx = torch.linspace(-1, 1, W)[None, :]
+            p.mul_((2.6 * torch.sqrt(torch.exp(-xx ** 2 / (2 * 0.35 ** 2)) * torch.exp(-yy ** 2 / (2 * 0.35 ** 2))))[None, None])
+        f.vel_net.weight_net[7][0].weight.mul_(4.0)
+        f.vel_net.weight_net[7][0].bias.add_(0.3)
+    m = m.to(device)
+    if final:
+        f.upsample_volume_grid(N_to_reso(7999998, f.aabb.cpu()), 4)
+        assert f.nSamples == 688, f.nSamples
+    else:
+        assert f.nSamples == 219, f.nSamples
+    return m
+
+
+def camera_bundle_chessboard(device, H=800, W=800, angle_x=0.6911112):
+    """800 x 800 pinhole camera on a sphere of radius 4 around the centre of the chessboard box (0, 0, 3) (assumed pose)"""
+    from nvfi_amd.models import Camera
+    focal = 0.5 * W / np.tan(0.5 * angle_x)
+    pose = pose_spherical(30.0, -30.0, 4.0)
+    pose[2, 3] += 3.0
+    cam = Camera(pose.to(device), H, W, focal, torch.zeros(1, 1, 3, device=device), 0.8, 8.1)
+    return cam.rays.ray_origins.reshape(-1, 3).contiguous(), cam.rays.ray_directions.reshape(-1, 3).contiguous()
+
+
+SCENES = {
+    # keyframes every tmax / (K - 1): bat 0.05 = 3 / 60, chessboard 0.25 = 15 / 60 (frame times are i / 60, i = 0..45)
+    "bat": dict(white_bg=True, kf_stride=3, K=16, near=1.0, far=8.0, pts=262144),
+    "chessboard": dict(white_bg=False, kf_stride=15, K=4, near=0.8, far=8.1, pts=131072),
+}
+
+
 def pose_spherical(theta, phi, radius):
     th, ph = np.deg2rad(theta), np.deg2rad(phi)
     tr = np.eye(4); tr[2, 3] = radius
@@ -130,12 +186,14 @@ def _shadow_groups(groups):
 class Step:
     """One training iteration of the hot path (mirrors train_nvfi.py:139-249 with --static_dynamic), optimised counterpart driver."""
 
-    def __init__(self, model, device, n_rays, n_pts, world, rank, workload, live=False):
+    def __init__(self, model, device, n_rays, n_pts, world, rank, workload, live=False, scene="bat"):
         from nvfi_amd.models import Renderer
         from nvfi_amd.utils import TVLoss
         from nvfi_amd.dist import GradBucket
         self.m, self.dev, self.n_rays, self.n_pts, self.world, self.rank = model, device, n_rays, n_pts, world, rank
         self.workload = workload
+        self.scene = SCENES[scene]
+        self.white_bg, self.kf = self.scene["white_bg"], self.scene["kf_stride"]
         self.ren = Renderer(model, 0, 0, n_rays)
         self.tv = TVLoss()
         groups = model.get_optparam_groups(0.02, 1e-3)
@@ -152,7 +210,7 @@ class Step:
             from nvfi_amd.optim import Adam
             self.opt = Adam(opt_groups, betas=(0.9, 0.99))
         self.fused_zero = not os.environ.get("NVFI_TORCH_ADAM")
-        self.o, self.d = camera_bundle(device)
+        self.o, self.d = camera_bundle(device) if scene == "bat" else camera_bundle_chessboard(device)
         self.gen = torch.Generator(device=device); self.gen.manual_seed(233 + rank)
         self.rng = np.random.default_rng(233 + rank)
         self.lr_factor = 0.1 ** (1 / 30000)
@@ -192,7 +250,7 @@ class Step:
         from nvfi_amd.models import Ray
         idx = torch.randint(0, self.o.shape[0], (self.n_rays,), device=self.dev, generator=self.gen)
         target = torch.rand(self.n_rays, 3, device=self.dev, generator=self.gen)
-        return Ray(self.o[idx], self.d[idx], 1.0, 8.0), target
+        return Ray(self.o[idx], self.d[idx], self.scene["near"], self.scene["far"]), target
 
     def __call__(self):
         m, f = self.m, self.m.nvfi
@@ -224,13 +282,13 @@ class Step:
             pde_term()
         if self.workload == "cfg3":
             i = int(self.rng.integers(0, 46))
-            while i % 3 == 0:                       # frame times i/60; keyframes every 0.05 = 3/60
+            while i % self.kf == 0:                 # frame times i/60; keyframes every 0.05 = 3/60 (bat), 0.25 = 15/60 (chessboard)
                 i = int(self.rng.integers(0, 46))
             rays, target = self.rays()
-            out = self.ren.render(i / 60.0, rays, white_background=True, mode="train")
+            out = self.ren.render(i / 60.0, rays, white_background=self.white_bg, mode="train")
             loss = loss + mse_loss(out[0], target)
             self.counters.append(f.last_counters)
-            t_key = 3 * int(self.rng.integers(0, 16)) / 60.0
+            t_key = self.kf * int(self.rng.integers(0, self.scene["K"])) / 60.0
         else:
             t_key = float(self.rng.integers(0, 46)) / 60.0   # radiance-only: continuous time rows
         rays, target = self.rays()
@@ -246,7 +304,7 @@ class Step:
             self._s_reg.wait_stream(main)
             with torch.cuda.stream(self._s_reg):
                 self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
-        out = self.ren.render(t_key, rays, white_background=True, mode="train")
+        out = self.ren.render(t_key, rays, white_background=self.white_bg, mode="train")
         loss = loss + mse_loss(out[0], target)
         self.counters.append(f.last_counters)
         if not self.fused_regs:
@@ -281,9 +339,9 @@ class Step:
         s_pde, s_r1 = self.streams
         start = torch.cuda.Event(); start.record(main)
         i = int(self.rng.integers(0, 46))
-        while i % 3 == 0:
+        while i % self.kf == 0:
             i = int(self.rng.integers(0, 46))
-        t_key = 3 * int(self.rng.integers(0, 16)) / 60.0
+        t_key = self.kf * int(self.rng.integers(0, self.scene["K"])) / 60.0
         multi = self.world > 1
         with torch.cuda.stream(s_pde):
             s_pde.wait_event(start)
@@ -298,21 +356,21 @@ class Step:
         with torch.cuda.stream(s_r1):
             s_r1.wait_event(start)
             rays, target = self.rays()
-            out = self.ren.render(i / 60.0, rays, white_background=True, mode="train")
+            out = self.ren.render(i / 60.0, rays, white_background=self.white_bg, mode="train")
             c1 = f.last_counters
             mse_loss(out[0], target).backward()
         if self.s_r2 is not None:
             with torch.cuda.stream(self.s_r2):
                 self.s_r2.wait_event(start)
                 rays, target = self.rays()
-                out = self.ren.render(t_key, rays, white_background=True, mode="train")
+                out = self.ren.render(t_key, rays, white_background=self.white_bg, mode="train")
                 c2 = f.last_counters
                 loss = mse_loss(out[0], target)
                 loss.backward()
             main.wait_stream(self.s_r2)
         else:
             rays, target = self.rays()
-            out = self.ren.render(t_key, rays, white_background=True, mode="train")
+            out = self.ren.render(t_key, rays, white_background=self.white_bg, mode="train")
             c2 = f.last_counters
             loss = mse_loss(out[0], target)
             loss.backward()
@@ -637,8 +695,103 @@ class DropinStep:
         return loss
 
 
-def cpu_baseline(model, workload, seconds_hint=20):
-    """Oracle (C restatement, OpenMP) on a bounded sample of the same step: 256+256 rays, P=32768."""
+class SegmStep:
+    """One iteration of the reference's segmentation training (train_segm.py:126-198) on the hot path: jittered 64^3 lattice -> density at
+    t = 0 -> occupied points -> integrate_pos to a random time in [min_t, tmax] (up to 30 RK2 steps per point) -> MaskField(3 -> 128 x 4 -> K,
+    softmax) forward + backward -> Adam.  The reference's rigid-fit / kNN-smoothness / entropy losses are PyTorch code that SURVEY section 8 leaves
+    out of scope; a stand-in of the same arity (a quadratic on the mask + the entropy term, test_maskfield.py's convergence test) drives the
+    backward, so the timed work is exactly rows a-6 / a-9 / a-19: point pipeline + MaskField training kernels."""
+
+    def __init__(self, model, device, n_sample_res=64, n_object=8, fp16=False):
+        from nvfi_amd.models import MaskField
+        self.f = model.nvfi
+        self.f.eval()
+        self.res = n_sample_res
+        torch.manual_seed(233)
+        self.mf = MaskField(n_layer=4, n_dim=128, input_dim=3, skips=[], mask_dim=n_object).to(device)
+        self.mf.mfma_fp16 = bool(fp16)
+        self.opt = torch.optim.Adam(self.mf.parameters(), lr=0.005, betas=(0.9, 0.999), fused=True)
+        self.points, self.steps_rk = 0, 0
+
+    def __call__(self):
+        from nvfi_amd.utils.segm_utils import segm_points
+        f = self.f
+        xyz, flow, t = segm_points(f, self.res, min_t=0.5, alpha_scale=10.0)
+        mask = self.mf(xyz)
+        target = (flow / (flow.norm(dim=1, keepdim=True) + 1e-9))[:, :1]
+        loss = ((mask[:, :1] - target) ** 2).mean() - 1e-3 * (mask * torch.log(mask + 1e-8)).sum(1).mean()
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        self.points += int(xyz.shape[0])
+        dt_max = 0.5 * f.tmax / (f.num_keyframes - 1)
+        self.steps_rk += int(xyz.shape[0]) * int(np.ceil(t / dt_max - 1e-6))
+        return loss
+
+
+def segm_main(args, device):
+    """`--workload segm`: BASELINE configs[4]'s single-GPU share (train_segm.py's MaskField step on the chessboard-like field); prints its own line.
+    NVFI_MASK_FP16=1 / NVFI_VEL_FP16=1|2 select the fp16-input MFMA modes (stated in `dtype`)."""
+    from nvfi_amd import _lib
+    model = build_scene_chessboard(device, final=False)          # train_segm.py works on the trained field's t = 0 volume; n_sample_res = 64
+    fp16 = os.environ.get("NVFI_MASK_FP16", "0") == "1"
+    step = SegmStep(model, device, 64, 8, fp16)
+    for _ in range(max(args.prime, 3)):
+        step()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    step.points = step.steps_rk = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pts, evals = step.points / args.steps, 2.0 * step.steps_rk / args.steps
+    mf_flop = pts * 3 * 2 * (3 * 128 + 3 * 128 * 128 + 128 * 8)          # forward + dgrad + wgrad GEMMs
+    flop = evals * VEL_FLOP + mf_flop
+    vel16 = model.nvfi.vel_fp16
+    out = {"metric": "MaskField training points/sec (train_segm.py step: density lattice + RK2 advection + MaskField fwd/bwd + Adam)",
+           "value": pts * args.steps / dt, "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" + (" (MaskField: fp16-input MFMA, fp32 accumulation)" if fp16 else "") + (f" (integrate_pos: vel_fp16={vel16})" if vel16 else ""),
+           "data": "synthetic",
+           "config": {"workload": "train_segm.py:126-198 on the chessboard-like field (configs[4], one GPU's share): 64^3 jittered lattice, occupied points "
+                                  "advected to t in [0.5, 0.75] (K = 4: 4-6 RK2 steps), MaskField 3 -> 128 x 4 -> 8 softmax, stand-in loss, torch Adam(fused)",
+                      "points_per_step": pts, "velocity_net_evaluations_per_step": evals},
+           "roofline": {"bound": "mfma", "kernel": "whole step (k_rk2 integrate_pos + k_maskfield_fwd/bwd + k_wgrad)", "achieved": flop / (dt / args.steps) / 1e12,
+                        "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": flop / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA, "traffic": None,
+                        "gflop_per_step": {"integrate_pos": evals * VEL_FLOP / 1e9, "maskfield": mf_flop / 1e9}}}
+    if not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = segm_cpu_baseline(model, step)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(out))
+
+
+def segm_cpu_baseline(model, step):
+    """the oracle's MaskField forward + parameter gradients (plain C, OpenMP) on a bounded sample of the step's points; the advection is not in
+    the sample (the oracle's integrate_pos is the same net evaluated point by point: it is timed by the cfg3 baseline)"""
+    from oracle import oracle as orc
+    threads = min(64, os.cpu_count() or 1)
+    orc.set_threads(threads)
+    N = 32768
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+    g = rng.standard_normal((N, 8)).astype(np.float32)
+    ps = [p.detach().cpu().numpy() for p in step.mf.parameters()]
+    orc.maskfield(ps, pts[:1024], g[:1024])
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < 8 and n < 3:
+        orc.maskfield(ps, pts, g); n += 1
+    dt = (time.perf_counter() - t0) / n
+    return dict(value=N / dt, unit="points/s", cores=threads, kind="port",
+                sample=f"oracle/nvfi_oracle.c orc_maskfield (OpenMP x{threads}): forward + parameter gradients of {N} points, {n} reps (MaskField part of the step only)")
+
+
+def cpu_baseline(model, workload, seconds_hint=20, scene="bat"):
+    """Oracle (C restatement, OpenMP) on a bounded sample of the same step: 256+256 rays, P=32768 (chessboard at 688 samples per ray: 64+64 rays, P=16384)."""
     from oracle import oracle as orc
     f = model.nvfi
     sd = {k[len("nvfi."):]: v.detach().cpu().contiguous().numpy() for k, v in model.state_dict().items() if not k.startswith("nvfi.vel.vel_net.")}
@@ -646,25 +799,30 @@ def cpu_baseline(model, workload, seconds_hint=20):
                 near=f.near_far[0], far=f.near_far[1], step_ratio=f.step_ratio, max_n_samples=f.max_n_samples,
                 density_shift=f.density_shift, distance_scale=f.distance_scale, alphaMask_thres=f.alphaMask_thres,
                 rayMarch_weight_thres=f.rayMarch_weight_thres, stepSize=f._step_host, nSamples=f.nSamples, use_sur=0, eps=0.03)
+    sc = SCENES[scene]
+    if scene == "chessboard":
+        meta.update(use_sur=1, sur_bounds=f.vel.bounds.detach().float().cpu().numpy().reshape(2, 3))
+        del meta["eps"]
     fs = orc.FieldSpec(sd, meta)
     # 64 threads is the oracle's sweet spot on the GPU box's 256-thread host (measured: 644 rays/s at 64, 300 at 256 on this sample)
     threads = min(64, os.cpu_count() or 1)
     orc.set_threads(threads)
-    o, d = camera_bundle("cpu")
+    o, d = camera_bundle("cpu") if scene == "bat" else camera_bundle_chessboard("cpu")
     rng = np.random.default_rng(5)
-    R, P = 256, 32768
+    R, P = (256, 32768) if scene == "bat" else (64, 16384)
+    t_non, t_key = (19 / 60.0, 0.30) if scene == "bat" else (22 / 60.0, 0.25)
     def one_render(t):
         idx = rng.integers(0, o.shape[0], R)
         oo, dd = o[idx].numpy(), d[idx].numpy()
         u = rng.uniform(0, 1, (R, 1)).astype(np.float32)
-        r = orc.render(fs, oo, dd, t, u=u, train=True, white_bg=True, keep_ctx=True, use_vel=(workload == "cfg3"))
+        r = orc.render(fs, oo, dd, t, u=u, train=True, white_bg=sc["white_bg"], keep_ctx=True, use_vel=(workload == "cfg3"))
         tg = rng.uniform(0, 1, (R, 3)).astype(np.float32)
         r.backward(fs, g_rgb=2 * (r.rgb - tg) / (R * 3))
         r.free()
     def step():
         if workload == "cfg3":
-            one_render(19 / 60.0)
-        one_render(0.30)
+            one_render(t_non)
+        one_render(t_key)
         if workload == "cfg3":
             mn, mx = fs.aabb
             pts = rng.uniform(0, 1, (P, 3)).astype(np.float32) * (mx - mn) + mn
@@ -680,7 +838,7 @@ def cpu_baseline(model, workload, seconds_hint=20):
     dt = (time.perf_counter() - t0) / n
     rays = R * (2 if workload == "cfg3" else 1)
     return dict(value=rays / dt, unit="rays/s", cores=threads, kind="port",
-                sample=f"oracle/nvfi_oracle.c (OpenMP x{threads}) on 1/8 of the step: {R} rays per render"
+                sample=f"oracle/nvfi_oracle.c (OpenMP x{threads}) on 1/{2048 // R} of the step: {R} rays per render"
                        + (f" x2 renders + PDE with P={P}" if workload == "cfg3" else "") + f", fwd+bwd, {n} reps")
 
 
@@ -712,13 +870,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "chessboard", "segm"],
+                    help="cfg3: BASELINE configs[2] (headline); cfg2: configs[1] radiance-only; chessboard: configs[3]'s single-GPU share (the cfg3 loop on the "
+                         "InDoorSeg box at its final 199x199x200 grid: K = 4, surround-box gate, no white background, 688 samples/ray, P = 131072); "
+                         "segm: configs[4]'s single-GPU share (train_segm.py's MaskField step)")
+    ap.add_argument("--chessboard-init-res", action="store_true", help="chessboard at the initial 64^3 grid (219 samples/ray) instead of the final one")
     ap.add_argument("--mode", default="fused", choices=["fused", "dropin"])
     ap.add_argument("--live", action="store_true", help="apply the optimiser updates to the field itself (non-stationary workload)")
     ap.add_argument("--host-rays", action="store_true", help="dropin mode: rebuild the 800x800 Camera and np.random.choice the batch on the host, as the reference does")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="strong: the GLOBAL batch (rays, collocation points) is fixed and split over the ranks")
     ap.add_argument("--rays", type=int, default=2048)
-    ap.add_argument("--pts", type=int, default=262144)
+    ap.add_argument("--pts", type=int, default=None, help="PDE collocation points per step (default: the scene's vel_reg_n_pts: 262144 bat, 131072 chessboard)")
     ap.add_argument("--grid", type=int, default=199)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the separate profiled pass (default: min(steps, 5); 0: none)")
@@ -739,6 +901,8 @@ def main():
         # command line the driver uses with torch.distributed.run in front
         sys.exit(_spawn_ranks(args.gpus, ndev, backend))
     graph_line = None
+    if args.workload in ("chessboard", "segm"):
+        args.graph = "off"           # (the captured iteration is the bat loop's)
     if (args.graph == "auto" and args.mode == "fused" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("NVFI_TORCH_ADAM")
             and not os.environ.get("NVFI_BENCH_CHILD")):
         # auto: measure BOTH launch modes of the same step and report the faster one (both values go into the line).  The hipGraph replay
@@ -785,11 +949,22 @@ def main():
         world = dist.get_world_size()
     from nvfi_amd import _lib
     L = _lib.lib()
+    scene = "bat"
+    if args.workload == "segm":
+        if world > 1 or args.mode != "fused":
+            raise SystemExit("--workload segm is a single-process step")
+        return segm_main(args, device)
+    if args.workload == "chessboard":
+        scene, args.workload = "chessboard", "cfg3"          # the same loop on another field
+        if args.mode != "fused":
+            raise SystemExit("--workload chessboard runs the fused driver")
+    if args.pts is None:
+        args.pts = SCENES[scene]["pts"]
 
     n_rays, n_pts = args.rays, args.pts
     if args.scaling == "strong":           # 256 rays and P/8 points per GPU at 8 GPUs
         n_rays, n_pts = max(1, args.rays // world), max(128, args.pts // world)
-    model = build_scene(device, args.grid, args.samples, use_vel=True)
+    model = build_scene(device, args.grid, args.samples, use_vel=True) if scene == "bat" else build_scene_chessboard(device, final=not args.chessboard_init_res)
     if args.workload == "cfg2":
         model.nvfi.use_vel = False
     if args.mode == "dropin":
@@ -797,7 +972,7 @@ def main():
             raise SystemExit("--mode dropin is the single-process reference loop")
         step = DropinStep(model, device, n_rays, n_pts, world, rank, args.workload, live=args.live, host_rays=args.host_rays)
     else:
-        step = Step(model, device, n_rays, n_pts, world, rank, args.workload, live=args.live)
+        step = Step(model, device, n_rays, n_pts, world, rank, args.workload, live=args.live, scene=scene)
 
     def barrier():
         if world > 1:
@@ -909,12 +1084,15 @@ def main():
                   "split16band": "f32 (opt-in: PDE occupancy prefilter with fp32 products emulated by two binary16 terms per operand on the fp16 MFMA, fp32 re-evaluation band)"
                   }.get(os.environ.get("NVFI_PDE_PREFILTER", "fp32"), "f32"),
         "data": "synthetic",
-        "config": {"workload": ("bat.yaml + velocity field + PDE divergence loss (configs[2]): 199^3 grid, K=16, 128 samples/ray, "
-                                "2 renders x 2048 rays + PDE on 262144 collocation points + plane regularisers + Adam, per GPU"
+        "config": {"workload": (f"chessboard.yaml (configs[3], one GPU's share): InDoorSeg box, {'x'.join(str(int(g)) for g in model.nvfi.gridSize.tolist())} grid, K=4, surround-box velocity gate, "
+                                f"no white background, {model.nvfi.nSamples} samples/ray, 2 renders x {n_rays} rays + PDE on {n_pts} collocation points + plane regularisers + Adam, per GPU"
+                                if scene == "chessboard" else
+                                "bat.yaml + velocity field + PDE divergence loss (configs[2]): 199^3 grid, K=16, 128 samples/ray, "
+                                f"2 renders x {n_rays} rays + PDE on {n_pts} collocation points + plane regularisers + Adam, per GPU"
                                 if args.workload == "cfg3" else
                                 "bat.yaml radiance-only (configs[1]): 199^3 grid, 128 samples/ray, 2048-ray batches of the 800x800 frame"),
                    "rays_per_step_per_gpu": n_rays * renders, "pde_points_per_gpu": n_pts if args.workload == "cfg3" else 0,
-                   "grid": args.grid, "samples_per_ray": args.samples, "parallelism": f"ray-sharded x{world}",
+                   "grid": [int(g) for g in model.nvfi.gridSize.tolist()], "samples_per_ray": int(model.nvfi.nSamples), "parallelism": f"ray-sharded x{world}",
                    "driver": args.mode,
                    "launch": ("one hipGraph replay per iteration (three captured streams; frame times, loss weights, learning rates and jitter read from a device record uploaded per iteration)"
                               if use_graph else "eager launches"),
@@ -926,31 +1104,68 @@ def main():
         out["config"]["graph_capture_attempts_ms"] = [round(x, 3) for x in run.capture_ms]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(model, args.workload)
+            out["cpu_baseline"] = cpu_baseline(model, args.workload, scene=scene)
         except Exception as e:  # the baseline is a report, never a reason to lose the bench line
             out["cpu_baseline"] = {"error": repr(e)}
         ref = _load_json(f"{PROFILE_TAG}_cpu_bridge.json")
-        if ref and "reference" in ref:      # the reference itself (PyTorch CPU) on that same sample, measured in the build container
+        if ref and "reference" in ref and scene == "bat":      # the reference itself (PyTorch CPU) on that same sample, measured in the build container
             out["reference_cpu"] = dict(ref["reference"], host=ref.get("host"), oracle_on_that_host=ref.get("oracle", {}).get("value"),
                                         source=f"profiles/{PROFILE_TAG}_cpu_bridge.json (tools/cpu_bridge.py; /root/reference cannot run on the GPU box)")
     # Other lines of the same build, measured here so that they are recorded with the headline (each in its own process, same K / W, no
     # roofline pass); none of them is `value`.
-    default_invocation = (rank == 0 and world == 1 and args.mode == "fused" and args.workload == "cfg3" and not args.live and not args.no_extras
+    default_invocation = (rank == 0 and world == 1 and args.mode == "fused" and args.workload == "cfg3" and scene == "bat" and not args.live and not args.no_extras
                           and not os.environ.get("NVFI_BENCH_CHILD") and os.environ.get("NVFI_PDE_PREFILTER", "fp32") == "fp32")
     if default_invocation:
         import subprocess
-        def extra(extra_args, env=None, steps_factor=1):
+        def extra(extra_args, env=None, steps_factor=1, scene_args=True, profile=False, timeout=300, full=False):
             # (the radiance-only step is 0.8 ms: K = 20 steps are a 16 ms timed region, shorter than the clock ramp of an idle GPU - 10 K there)
-            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps * steps_factor), "--warmup", str(args.warmup * steps_factor), "--no-cpu-baseline",
-                   "--profile-steps", "0", "--no-extras", "--rays", str(args.rays), "--pts", str(args.pts), "--grid", str(args.grid),
-                   "--samples", str(args.samples)] + extra_args
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps * steps_factor), "--warmup", str(args.warmup * steps_factor),
+                   "--profile-steps", "5" if (profile or full) else "0", "--no-extras"] + ([] if full else ["--no-cpu-baseline"])
+            if scene_args:
+                cmd += ["--rays", str(args.rays), "--pts", str(args.pts), "--grid", str(args.grid), "--samples", str(args.samples)]
+            cmd += extra_args
             try:
-                r = subprocess.run(cmd, env=dict(os.environ, NVFI_BENCH_CHILD="1", **(env or {})), stdout=subprocess.PIPE, text=True, timeout=300)
+                r = subprocess.run(cmd, env=dict(os.environ, NVFI_BENCH_CHILD="1", **(env or {})), stdout=subprocess.PIPE, text=True, timeout=timeout)
                 ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
                 d = json.loads(ln[-1])
-                return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "launch": d["config"]["launch"].split(" (")[0]}
+                e = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "launch": d["config"].get("launch", "eager launches").split(" (")[0]}
+                if profile:
+                    e["_line"] = d
+                if full:        # a workload of its own: its roofline and CPU baseline travel with it
+                    r_ = d.get("roofline") or {}
+                    e["roofline"] = {k: r_.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic") if k in r_}
+                    e["cpu_baseline"] = d.get("cpu_baseline")
+                    e["workload"] = d["config"]["workload"]
+                return e
             except Exception as e:
                 return {"error": repr(e)}
+
+        def strong_shard():
+            """the step one of 8 ranks runs under --scaling strong (256 rays per render, 32768 collocation points), on this one GPU: its time, its
+            per-class times and launch count, and what they project for the 8-GPU step"""
+            e = extra(["--rays", str(max(1, args.rays // 8)), "--pts", str(max(128, args.pts // 8)), "--grid", str(args.grid), "--samples", str(args.samples),
+                       "--graph", "off"], scene_args=False, profile=True)
+            d = e.pop("_line", None)
+            if d is None:
+                return e
+            pc = (d.get("roofline") or {}).get("per_class", {})
+            e["per_class_ms"] = {k: round(v["ms_per_step"], 4) for k, v in pc.items() if v.get("launches_per_step")}
+            e["kernel_class_launches_per_step"] = sum(v.get("launches_per_step", 0) for v in pc.values())
+            e["serial_ms_per_step"] = (d.get("work_per_step") or {}).get("ms_per_step_profiled_serial")
+            # projection for 8 GPUs, strong scaling: the shard step + the gradient exchange of the flat buffer.  Ring all-reduce of S bytes over N
+            # ranks moves 2 (N - 1) / N x S per link direction; ONE ring at the 153 GB/s of one xGMI link is the conservative figure (RCCL can
+            # stripe rings over the 7 links of the fully connected node).  The head of the buffer (planes + render MLP, 38 MB) is exchanged under
+            # the PDE chain, so the exposed part lies between 0 and the whole transfer.
+            nbytes = 4.0 * sum(p.numel() for p in model.parameters())
+            t_ar = 2.0 * 7.0 / 8.0 * nbytes / 153e9 * 1e3
+            t1, t8 = out["ms_per_step"], d["ms_per_step"]
+            e["projection_8gpu_strong"] = {
+                "gradient_bytes": nbytes, "ring_allreduce_ms_one_link": t_ar,
+                "step_ms_if_exchange_hidden": t8, "step_ms_if_exchange_exposed": t8 + t_ar,
+                "speedup_over_1gpu": [t1 / (t8 + t_ar), t1 / t8], "efficiency": [t1 / (t8 + t_ar) / 8.0, t1 / t8 / 8.0],
+                "note": "a PROJECTION from one-GPU measurements (this pool has one GPU per box); north_star's target is >= 6x at 8 GPUs"}
+            return e
+
         out["extras"] = {
             "dropin": dict(extra(["--mode", "dropin"]), what="the loop body of the reference's train_nvfi.py:139-249 verbatim on the `models` alias (plain autograd, "
                            "torch.optim.Adam, reference-signature regularisers, the per-iteration .item() waits): what tools/run_reference_driver.py gets"),
@@ -965,6 +1180,14 @@ def main():
             "optin_fp16band_prefilter": dict(extra(["--graph", "off"], {"NVFI_PDE_PREFILTER": "fp16band"}),
                                              what="opt-in (NOT the headline): fp16-input pre-pass of the PDE occupancy prefilter with an fp32 re-evaluation band; "
                                                   "identical kept set on every test field, no proof"),
+            "live": dict(extra(["--live", "--graph", "off"]), what="the optimiser moves the field it renders (train_nvfi.py:243), as in real training: on random targets the blob "
+                         "thickens and the PDE kept set grows 34 k -> 114 k points within these steps, so the step is slower than the stationary headline (same kernels)"),
+            "strong_shard_1of8": dict(strong_shard(), what="the fused step at 1/8 of the global batch (--rays 256 --pts 32768: what each of 8 ranks runs under --scaling strong), one GPU"),
+            "chessboard": dict(extra(["--workload", "chessboard"], scene_args=False, timeout=600, full=True),
+                               what="BASELINE configs[3], one GPU's share: the same loop on the InDoorSeg chessboard box at its final 199x199x200 grid (K = 4, surround-box gate "
+                                    "with step rejection, no white background, 688 samples per ray, P = 131072)"),
+            "segm": dict(extra(["--workload", "segm"], scene_args=False, full=True),
+                         what="BASELINE configs[4], one GPU's share: train_segm.py's MaskField step (64^3 lattice -> occupied points -> integrate_pos -> MaskField fwd + bwd + Adam); points/s"),
         }
     if graph_line is not None:
         modes = {"hipgraph_replay": {"value": graph_line["value"], "ms_per_step": graph_line["ms_per_step"]},

@@ -132,6 +132,15 @@ def pde_rank_weight(n_kept_local):
     return 0.0 if tot == 0 else dist.get_world_size() * float(n_kept_local) / tot
 
 
+def shard_weight(n_local, n_global, world=None):
+    """W * n_r / N: the factor that turns a mean over THIS rank's shard (n_r items) into its share of the mean over all N items under the
+    averaging all-reduce.  1.0 for equal shards - what bench.py uses (rays // world) - and what a shard_range split of a count that does
+    not divide by the world size needs (the first ranks hold one item more)."""
+    if world is None:
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    return 1.0 if n_global == 0 else world * float(n_local) / float(n_global)
+
+
 def shard_range(n, rank, world):
     """Contiguous shard [lo, hi) of n items for this rank (remainder spread over the first ranks)."""
     base, rem = divmod(n, world)

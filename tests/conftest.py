@@ -53,6 +53,15 @@ def outfrac(a, b, rtol, floor=1e-3):
 
 
 GRAD_STATS = []     # (max-norm rel, rel L2, out-of-tolerance fraction at 20 x the bound, size): printed at the end of a GPU run
+MIXED_STATS = []    # the same for comparisons of a REDUCED-PRECISION mode with the fp32 golden (a direction check, bound 0.2): reported on
+                    # its own line so that it cannot hide a regression of an fp32 comparison in the summary
+
+
+def relerr_mixed(a, b):
+    """relerr for an fp16-input mode against the fp32 reference: recorded under its own label (round-3 verdict)"""
+    m, l2 = maxrel(a, b), rel_l2(a, b)
+    MIXED_STATS.append((m, l2, outfrac(a, b, 1e-2), int(np.asarray(b).size)))
+    return max(m, l2)
 
 
 def relerr(a, b):
@@ -87,6 +96,10 @@ def pytest_terminal_summary(terminalreporter):
         s = np.array([(m, l, o) for m, l, o, _ in GRAD_STATS])
         terminalreporter.write_line(f"gradient comparisons: {len(GRAD_STATS)} tensors; worst max-norm rel {s[:, 0].max():.2e}, worst rel L2 {s[:, 1].max():.2e}, "
                                     f"worst fraction outside 1e-2 element-wise (floor 1e-3 of the peak) {s[:, 2].max():.2e}")
+    if MIXED_STATS:
+        s = np.array([(m, l, o) for m, l, o, _ in MIXED_STATS])
+        terminalreporter.write_line(f"fp16-mode vs fp32-golden direction checks (separate from the line above): {len(MIXED_STATS)} tensors; worst max-norm rel "
+                                    f"{s[:, 0].max():.2e}, worst rel L2 {s[:, 1].max():.2e}")
     if OUT_STATS:
         w = max(OUT_STATS)
         terminalreporter.write_line(f"assert_grad: {len(OUT_STATS)} tensors; worst fraction outside 20 x tol element-wise: {w[0]:.2e} ({w[2]}, {w[1]} elements)")

@@ -6,9 +6,21 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_contract
+from conftest import assert_grad
+from helpers import assert_contract, named_grads
 
 pytestmark = pytest.mark.gpu
+
+
+def _field_spec(model):
+    from oracle import oracle as orc
+    f = model.nvfi
+    sd = {k[len("nvfi."):]: v.detach().cpu().contiguous().numpy() for k, v in model.state_dict().items() if not k.startswith("nvfi.vel.vel_net.")}
+    meta = dict(aabb=f.aabb.cpu().numpy(), gridSize=np.array(f.gridSize.tolist()), num_keyframes=f.num_keyframes, tmax=f.tmax,
+                near=f.near_far[0], far=f.near_far[1], step_ratio=f.step_ratio, max_n_samples=f.max_n_samples,
+                density_shift=f.density_shift, distance_scale=f.distance_scale, alphaMask_thres=f.alphaMask_thres,
+                rayMarch_weight_thres=f.rayMarch_weight_thres, stepSize=f._step_host, nSamples=f.nSamples, use_sur=0, eps=0.03)
+    return orc.FieldSpec(sd, meta)
 
 
 @pytest.fixture(scope="module")
@@ -26,28 +38,78 @@ def _rays(o, d, n, seed):
 
 
 def test_fullsize_slice_matches_oracle(scene):
+    """the headline field (BASELINE configs[2]: bat 199^3, K = 16, 128 samples per ray) on a 256-ray train-mode slice at a non-keyframe
+    time: rgb / depth / acc under the 1e-4 contract AND the backward - the eleven parameter gradients test_render_vs_oracle_bigger checks
+    on the small fields (planes of both branches, basis_mat, render MLP, velocity net through the RK2 adjoint) - against the oracle's"""
     from oracle import oracle as orc
-    import bench
     model, o, d = scene
     f = model.nvfi
-    ro, rd = _rays(o, d, 256, 1)
-    u = torch.rand(256, 1)
+    R = 256
+    ro, rd = _rays(o, d, R, 1)
+    u = torch.rand(R, 1)
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    tg = torch.rand(R, 3, device="cuda", generator=g)
     f.train()
+    model.zero_grad(set_to_none=True)
     f.jitter_override = u
     try:
         out = f(19.0 / 60.0, ro, rd, True)
     finally:
         f.jitter_override = None
-    sd = {k[len("nvfi."):]: v.detach().cpu().contiguous().numpy() for k, v in model.state_dict().items() if not k.startswith("nvfi.vel.vel_net.")}
-    meta = dict(aabb=f.aabb.cpu().numpy(), gridSize=np.array(f.gridSize.tolist()), num_keyframes=f.num_keyframes, tmax=f.tmax,
-                near=f.near_far[0], far=f.near_far[1], step_ratio=f.step_ratio, max_n_samples=f.max_n_samples,
-                density_shift=f.density_shift, distance_scale=f.distance_scale, alphaMask_thres=f.alphaMask_thres,
-                rayMarch_weight_thres=f.rayMarch_weight_thres, stepSize=f._step_host, nSamples=f.nSamples, use_sur=0, eps=0.03)
-    fs = orc.FieldSpec(sd, meta)
+    (torch.nn.functional.mse_loss(out[0], tg) + 0.01 * out[1].mean()).backward()
+    fs = _field_spec(model)
     orc.set_threads(8)
-    ref = orc.render(fs, ro.cpu().numpy(), rd.cpu().numpy(), 19.0 / 60.0, u=u.numpy(), train=True, white_bg=True)
+    ref = orc.render(fs, ro.cpu().numpy(), rd.cpu().numpy(), 19.0 / 60.0, u=u.numpy(), train=True, white_bg=True, keep_ctx=True)
     for i, (nm, r) in enumerate((("rgb", ref.rgb), ("depth", ref.depth), ("acc", ref.acc))):     # the 1e-4 contract, flip-band rays counted
         assert_contract(out[i].detach().cpu().numpy(), r, nm, label="hip bat 199^3/128")
+    gref = ref.backward(fs, g_rgb=2 * (ref.rgb - tg.cpu().numpy()) / (R * 3), g_depth=np.full(R, 0.01 / R, np.float32))
+    ref.free()
+    gh = named_grads(model)
+    for pn in ("density_plane_space.0", "density_plane_time.2", "app_plane_space.1", "app_plane_time.0", "basis_mat.weight",
+               "renderModule.mlp.0.weight", "renderModule.mlp.2.bias", "renderModule.mlp.4.weight",
+               "vel_net.weight_net.1.weight", "vel_net.weight_net.4.0.weight", "vel_net.weight_net.7.0.bias"):
+        assert_grad(gh[pn], gref[pn], 5e-4, "bat199:" + pn)
+    model.zero_grad(set_to_none=True)
+
+
+@pytest.mark.parametrize("P", [4096, 32768])
+def test_fullsize_pde_slice_matches_oracle(scene, P):
+    """the PDE term of the headline field on a slice of collocation points the oracle finishes in seconds: kept set, loss, the forward-mode
+    Jacobians of the first kept points (on the intersection of the two kept sets) and the gradients of BOTH velocity nets
+    (reference models/nvfi.py:42-84), as test_chessboard_pde_slice_matches_oracle does for configs[3]"""
+    from oracle import oracle as orc
+    model, o, d = scene
+    f = model.nvfi
+    fs = _field_spec(model)
+    orc.set_threads(8)
+    g = torch.Generator(device="cuda"); g.manual_seed(6 + P)
+    mn, mx = f.aabb
+    pts = torch.rand(P, 3, device="cuda", generator=g) * (mx - mn) + mn
+    tt = torch.rand(P, 1, device="cuda", generator=g)
+    model.zero_grad(set_to_none=True)
+    f.pde_debug = 64
+    try:
+        lv = model.get_vel_loss(points=pts, t=tt)
+    finally:
+        f.pde_debug = 0
+    ref = orc.pde_loss(fs, pts.cpu().numpy(), tt.cpu().numpy(), n_jac=64)
+    kept = f.last_pde_kept.cpu().numpy().astype(bool)
+    assert ref["n_kept"] > P // 40, ref["n_kept"]
+    assert np.mean(kept != ref["kept"]) < 2e-3                 # alpha within rounding of the 1e-4 threshold may flip
+    ours_ids, ref_ids = np.nonzero(kept)[0][:64], np.nonzero(ref["kept"])[0][:64]
+    common, io, ir = np.intersect1d(ours_ids, ref_ids, return_indices=True)
+    assert len(common) >= 56, len(common)
+    np.testing.assert_allclose(f.last_pde_jac.cpu().numpy()[io, :3], ref["jac"][ir, :3], rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(float(lv.detach()), ref["loss"], rtol=5e-4)
+    lv.backward()
+    gh = named_grads(model)
+    n = 0
+    for k, r in ref["grads"].items():
+        if k.startswith("vel_net.") and r is not None and np.any(r):
+            assert_grad(gh[k], r, 1e-3, f"bat199:pde{P}:" + k)
+            n += 1
+    assert n >= 20, n          # weights and biases of both six-layer nets (the acceleration net's last layers included)
+    model.zero_grad(set_to_none=True)
 
 
 def test_fullsize_composite_identities_and_sharding(scene):
