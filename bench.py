@@ -1038,6 +1038,11 @@ def main():
         flops = {"rk2_fwd": E * VEL_FLOP, "rk2_bwd": E * VEL_FLOP, "app_fwd": M * APP_FLOP, "app_bwd": M * APP_FLOP,
                  "wgrad": E * VEL_FLOP + M * APP_FLOP + kept * 6 * VEL_FLOP, "pde_fwd": kept * 6 * VEL_FLOP,
                  "pde_bwd": kept * 6 * VEL_FLOP, "pde_prefilter": pre_evals * VEL_FLOP}
+        if os.environ.get("NVFI_RK2_FUSE", "1") != "0" and os.environ.get("NVFI_RK2_SPLIT_BWD", "1") != "0":
+            # vel_fuse.hip: the RK2 adjoint also forms the four 128 x 128 weight gradients of the render warp (2 * 4 * 128^2 FLOP per evaluation);
+            # the wgrad class keeps the two edge layers of that launch
+            flops["rk2_bwd"] += E * 131072.0
+            flops["wgrad"] -= E * 131072.0
         if pre_mode in ("fp16band", "split16band"):      # opt-in: the class is an fp16-MFMA pass + a short fp32 list; no fp32-MFMA figure applies to it
             del flops["pde_prefilter"]
         times = {CLASSES[i]: (tot[i], cnt[i]) for i in range(min(ncls, len(CLASSES)))}

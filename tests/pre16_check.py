@@ -46,8 +46,33 @@ def run(name, model, N, out, seed):
     out[f"{name}:ms"] = np.float64(ev[0].elapsed_time(ev[1]) / 5)
 
 
+def flips_run(path, total):
+    """kept masks of `total` random collocation points of the bench field in batches of 2^20 (forward only), packed to bits"""
+    import bench
+    model = bench.build_scene(torch.device("cuda"))
+    f = model.nvfi
+    rng = np.random.default_rng(77)
+    aabb = f.aabb.detach().cpu().numpy()
+    B = 1 << 20
+    masks, band = [], 0
+    with torch.no_grad():
+        for _ in range((total + B - 1) // B):
+            pts = (rng.uniform(0, 1, (B, 3)) * (aabb[1] - aabb[0]) + aabb[0]).astype(np.float32)
+            t = rng.uniform(0, 1, (B, 1)).astype(np.float32)
+            f.pde_debug = 1
+            try:
+                model.get_vel_loss(points=torch.from_numpy(pts).cuda(), t=torch.from_numpy(t).cuda())
+            finally:
+                f.pde_debug = 0
+            masks.append(np.packbits(f.last_pde_kept.cpu().numpy().astype(bool)))
+            band += int(f.last_pde_counters.cpu().numpy()[5])
+    np.savez(path, kept=np.concatenate(masks), band=np.int64(band), n=np.int64(len(masks) * B))
+
+
 def main():
     path = sys.argv[1]
+    if "--flips" in sys.argv:
+        return flips_run(path, int(sys.argv[sys.argv.index("--flips") + 1]))
     N = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else 262144
     out = {}
     for kind in ("A", "B"):

@@ -46,6 +46,26 @@ def test_fp16band_prefilter_keeps_exactly_the_fp32_set(tmp_path, n, extra, mode)
                 assert relerr(b[k], a[k]) < 2e-5, k
 
 
+def test_split16band_flip_count_on_ten_million_points(tmp_path):
+    """the flip counter of VERDICT r3 item 6: 10^7 collocation points of the bench field (199^3 bat) through the fp32 prefilter and through
+    split16band - every keep / drop decision compared.  split16band stays opt-in whatever this counts: a rigorous a-posteriori bound on its
+    position error is ~10^6 x the measured error (tests/studies/split16_bound_study.py), so identity of the kept set can be observed, not proven."""
+    n = 10 * (1 << 20)
+    out = {}
+    for mode in ("fp32", "split16band"):
+        path = str(tmp_path / f"flips_{mode}.npz")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pre16_check.py"), path, "--flips", str(n)], env=dict(os.environ, NVFI_PDE_PREFILTER=mode),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[mode] = np.load(path)
+    a, b = np.unpackbits(out["fp32"]["kept"]), np.unpackbits(out["split16band"]["kept"])
+    flips = int((a != b).sum())
+    print(f"bench field: {int(out['fp32']['n'])} points, kept {int(a.sum())}; split16band re-evaluated {int(out['split16band']['band'])} in fp32 "
+          f"({100.0 * int(out['split16band']['band']) / int(out['fp32']['n']):.3f} %); flips against the fp32 prefilter: {flips}")
+    assert int(out["fp32"]["n"]) >= 10 ** 7 and int(a.sum()) > 10 ** 6
+    assert flips == 0, flips
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("n", [37, 1000])
 def test_fp16band_ragged_point_counts(tmp_path, n, mode):

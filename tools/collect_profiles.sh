@@ -2,7 +2,7 @@
 # Runs on the GPU box (through gpurun): rocprofv3 passes of bench.py, summarised into gpurun_out/<tag>_*.
 # usage: tools/collect_profiles.sh <tag>      (e.g. r02)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -20,6 +20,11 @@ NVFI_DROPIN_FUSED_ADAM=1 python $REPO/bench.py --no-extras --mode dropin --no-cp
 NVFI_SPLIT_VOUT=0 NVFI_SPLIT_NT=2 python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_prefilter_out_on_mfma.json 2>/dev/null
 python $REPO/bench.py --no-extras --workload cfg2 --no-cpu-baseline > $OUT/${TAG}_bench_line_cfg2.json 2>/dev/null
 NVFI_WGRAD=engine python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_wgrad_engine.json 2>/dev/null
+# round 4: the round-3 pair of kernels (k_rk2_split_bwd + k_wgrad_ring8 over the full adjoint stash) instead of vel_fuse.hip, same box; the other BASELINE configs
+NVFI_RK2_FUSE=0 python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_rk2_unfused.json 2>/dev/null
+python $REPO/bench.py --workload chessboard > $OUT/${TAG}_bench_line_chessboard.json 2>/dev/null
+python $REPO/bench.py --workload segm > $OUT/${TAG}_bench_line_segm.json 2>/dev/null
+python $REPO/bench.py --no-extras --graph off --no-cpu-baseline --rays 256 --pts 32768 > $OUT/${TAG}_bench_line_strong_shard_1of8.json 2>/dev/null
 # other kernel selections: opt-in fp16-input pre-pass with the fp32 band; the engine kernels of vel.hip instead of vel_split.hip
 NVFI_PDE_PREFILTER=fp16band python $REPO/bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_line_fp16band.json 2>/dev/null
 NVFI_PDE_PREFILTER=split16band python $REPO/bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_line_split16band.json 2>/dev/null
