@@ -260,6 +260,23 @@ __device__ __forceinline__ void stash_store_acc(float* base, int lane, const f32
         for (int r = 0; r < 16; ++r) STASH_ST(base[(16 * m + r) * REGF + lane], acc[m][r]);
 }
 
+// ReLU masks of a hidden layer for the backward pass: bit s of the lane's pair of words = (activation register s > 0).  The adjoint of a
+// ReLU layer needs only the signs - 1 KB per tile and layer instead of the 32 KB of activation rows (which stay: the weight gradient contracts them)
+__device__ __forceinline__ void relu_mask_store(unsigned* dst, int lane, const float* x) {
+    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) { lo |= x[s] > 0.f ? 1u << s : 0u; hi |= x[32 + s] > 0.f ? 1u << s : 0u; }
+    dst[lane] = lo; dst[64 + lane] = hi;
+}
+// g[s] = bit s of the mask ? acc[s] : 0   (acc in four 16-register tiles)
+__device__ __forceinline__ void relu_mask_apply(const unsigned* mk, int lane, const f32x16* acc, float* g) {
+    const unsigned mlo = mk[lane], mhi = mk[64 + lane];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[16 * m + r] = (((m < 2 ? mlo : mhi) >> ((16 * m + r) & 31)) & 1u) ? acc[m][r] : 0.f;
+}
+
 // ---------------------------------------------------------------- velocity-basis nets
 // fragments of one 6-layer net (28-128-128-128-128-128-6), forward and transposed (dgrad)
 struct VelFrags {

@@ -25,7 +25,9 @@ struct MkArgs {
     const float* xyz; float* out;        // (N,3) -> (N,mask_dim)
     const float* g_out;                  // backward: d loss / d mask (N,mask_dim)
     float* stash_f; float* stash_b;
+    unsigned* relu_mask;                 // [tile][hidden layer 0..3][lo | hi][64 lanes]: signs of the post-ReLU activations (the adjoint reads these, not the rows)
 };
+#define MK_MASK_WORDS (4 * 128)
 
 template <bool STASH>
 __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_fwd(MkArgs a) {
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_fwd(MkArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { xa[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) st[(16 + 16 * m + r) * REGF + lane] = xa[16 * m + r]; }
     });
+    if (STASH) relu_mask_store(a.relu_mask + (size_t)tile * MK_MASK_WORDS, lane, xa);
     __syncthreads();
     stage_frag(lds_w, lds_b, a.W.f[1], MK_FH, a.W.b[1], 128);
     __syncthreads();
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_fwd(MkArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { xb[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) st[(80 + 16 * m + r) * REGF + lane] = xb[16 * m + r]; }
     });
+    if (STASH) relu_mask_store(a.relu_mask + (size_t)tile * MK_MASK_WORDS + 128, lane, xb);
     __syncthreads();
     stage_frag(lds_w, lds_b, a.W.f[2], MK_FH, a.W.b[2], 128);
     __syncthreads();
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_fwd(MkArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { xa[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) st[(144 + 16 * m + r) * REGF + lane] = xa[16 * m + r]; }
     });
+    if (STASH) relu_mask_store(a.relu_mask + (size_t)tile * MK_MASK_WORDS + 256, lane, xa);
     __syncthreads();
     stage_frag(lds_w, lds_b, a.W.f[3], MK_FH, a.W.b[3], 128);
     __syncthreads();
@@ -72,6 +77,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_fwd(MkArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { xb[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) st[(208 + 16 * m + r) * REGF + lane] = xb[16 * m + r]; }
     });
+    if (STASH) relu_mask_store(a.relu_mask + (size_t)tile * MK_MASK_WORDS + 384, lane, xb);
     __syncthreads();
     stage_frag(lds_w, lds_b, a.W.f[4], MK_F4, a.W.b[4], 32);
     __syncthreads();
@@ -130,13 +136,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_bwd(MkArgs a) {
     layer_mfma<4, 16>(lds_w, lane, g, acc);
 #pragma unroll 1
     for (int l = 3; l >= 1; --l) {
-        // acc = gradient wrt h_{l+1}: mask with the stashed activation, stash as g_z_{l+1}, push through W_{l+1}^T
-        const float* hh = stf + (size_t)(16 + 64 * l) * REGF;
+        // acc = gradient wrt h_{l+1}: mask with the SIGNS of the stashed activation (two words per lane instead of 64 rows), stash as
+        // g_z_{l+1}, push through W_{l+1}^T
         float* gz = stb + (size_t)(16 + 64 * (3 - l)) * REGF;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[16 * m + r] = hh[(16 * m + r) * REGF + lane] > 0.f ? acc[m][r] : 0.f;
+        relu_mask_apply(a.relu_mask + (size_t)tile * MK_MASK_WORDS + 128 * l, lane, acc, g);
         stash_store<64>(gz, lane, g);
         __syncthreads();
         stage_frag(lds_w, lds_b, a.W.t[l], MK_FH, nullptr, 0);
@@ -145,12 +148,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_bwd(MkArgs a) {
         layer_mfma<4, 64>(lds_w, lane, g, acc);
     }
     {   // g_z1 (no further propagation: the points carry no gradient, train_segm.py:137-170 runs them under no_grad)
-        const float* hh = stf + (size_t)16 * REGF;
         float* gz = stb + (size_t)(16 + 64 * 3) * REGF;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[16 * m + r] = hh[(16 * m + r) * REGF + lane] > 0.f ? acc[m][r] : 0.f;
+        relu_mask_apply(a.relu_mask + (size_t)tile * MK_MASK_WORDS, lane, acc, g);
         stash_store<64>(gz, lane, g);
     }
 }
@@ -189,6 +188,7 @@ struct Mk16Args {
     Mk16Frags W; int mask_dim; int64_t N;
     const float* xyz; float* out; const float* g_out;
     float* stash_f; float* stash_b;
+    unsigned* relu_mask;
 };
 
 __device__ __forceinline__ void stage16(h8_t* lds_w, const h8_t* __restrict__ frag, int n8, float* lds_b, const float* __restrict__ bias, int nb) {
@@ -239,6 +239,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_fwd16(Mk16Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { xa[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) st[(16 + 16 * m + r) * REGF + lane] = xa[16 * m + r]; }
     });
+    if (STASH) relu_mask_store(a.relu_mask + (size_t)tile * MK_MASK_WORDS, lane, xa);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
         __syncthreads();
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_fwd16(Mk16Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { xb[16 * m + r] = fmaxf(acc[r], 0.f); if (STASH) sl[(16 * m + r) * REGF + lane] = xb[16 * m + r]; }
         });
+        if (STASH) relu_mask_store(a.relu_mask + (size_t)tile * MK_MASK_WORDS + 128 * l, lane, xb);
 #pragma unroll
         for (int k = 0; k < 64; ++k) xa[k] = xb[k];
     }
@@ -313,10 +315,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_bwd16(Mk16Args a) {
     });
 #pragma unroll 1
     for (int l = 3; l >= 1; --l) {
-        const float* hh = stf + (size_t)(16 + 64 * l) * REGF;
         float* gz = stb + (size_t)(16 + 64 * (3 - l)) * REGF;
+        {
+            const unsigned* mk = a.relu_mask + (size_t)tile * MK_MASK_WORDS + 128 * l;
+            const unsigned mlo = mk[lane], mhi = mk[64 + lane];
 #pragma unroll
-        for (int k = 0; k < 64; ++k) g[k] = hh[k * REGF + lane] > 0.f ? gn[k] : 0.f;
+            for (int k = 0; k < 64; ++k) g[k] = (((k < 32 ? mlo : mhi) >> (k & 31)) & 1u) ? gn[k] : 0.f;
+        }
         stash_store<64>(gz, lane, g);
         __syncthreads();
         stage16(lds_w, a.W.t[l], 4 * 8 * 64, lds_b, nullptr, 0);
@@ -328,24 +333,28 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_maskfield_bwd16(Mk16Args a) {
         });
     }
     {
-        const float* hh = stf + (size_t)16 * REGF;
         float* gz = stb + (size_t)(16 + 64 * 3) * REGF;
+        {
+            const unsigned* mk = a.relu_mask + (size_t)tile * MK_MASK_WORDS;
+            const unsigned mlo = mk[lane], mhi = mk[64 + lane];
 #pragma unroll
-        for (int k = 0; k < 64; ++k) g[k] = hh[k * REGF + lane] > 0.f ? gn[k] : 0.f;
+            for (int k = 0; k < 64; ++k) g[k] = (((k < 32 ? mlo : mhi) >> (k & 31)) & 1u) ? gn[k] : 0.f;
+        }
         stash_store<64>(gz, lane, g);
     }
 }
 
 __global__ void k_set_int(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 
-struct MkPlan { float* frag; float* stash_f; float* stash_b; float* slabs; int* count; int64_t tiles; int64_t total; };
+struct MkPlan { float* frag; float* stash_f; float* stash_b; float* slabs; unsigned* relu; int* count; int64_t tiles; int64_t total; };
 static void plan_mask(int64_t N, int train, void* ws, MkPlan* P) {
     Bump B{(char*)ws, 0, 0};
     P->tiles = (N + WG_SAMPLES - 1) / WG_SAMPLES * 4;
     P->frag = B.take<float>(MK_FRAG_FLOATS);
     P->count = B.take<int>(16);
-    P->stash_f = P->stash_b = P->slabs = nullptr;
+    P->stash_f = P->stash_b = P->slabs = nullptr; P->relu = nullptr;
     if (train) {
+        P->relu = B.take<unsigned>(P->tiles * (int64_t)MK_MASK_WORDS);
         P->stash_f = B.take<float>(P->tiles * (int64_t)(MK_F_ROWS * REGF));
         P->stash_b = B.take<float>(P->tiles * (int64_t)(MK_B_ROWS * REGF));
         P->slabs = B.take<float>((int64_t)MK_NSLAB * MK_SLAB_FLOATS * 5);
@@ -448,7 +457,7 @@ extern "C" int nvfi_maskfield_fwd(const nvfi_mask_desc* m, int64_t N, const floa
     if (mode & NVFI_MASK_FP16) {
         Mk16Args h; memset(&h, 0, sizeof(h));
         if (mask_frags16(m, P.frag, &h.W, train != 0, st)) return 1;
-        h.mask_dim = m->mask_dim; h.N = N; h.xyz = xyz; h.out = mask_out; h.stash_f = P.stash_f; h.stash_b = P.stash_b;
+        h.mask_dim = m->mask_dim; h.N = N; h.xyz = xyz; h.out = mask_out; h.stash_f = P.stash_f; h.stash_b = P.stash_b; h.relu_mask = P.relu;
         if (train) hipLaunchKernelGGL(k_maskfield_fwd16<true>, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, h);
         else hipLaunchKernelGGL(k_maskfield_fwd16<false>, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, h);
         LAUNCHCK();
@@ -456,7 +465,7 @@ extern "C" int nvfi_maskfield_fwd(const nvfi_mask_desc* m, int64_t N, const floa
     }
     MkArgs a; memset(&a, 0, sizeof(a));
     if (mask_frags(m, P.frag, &a.W, train != 0, st)) return 1;
-    a.mask_dim = m->mask_dim; a.N = N; a.xyz = xyz; a.out = mask_out; a.stash_f = P.stash_f; a.stash_b = P.stash_b;
+    a.mask_dim = m->mask_dim; a.N = N; a.xyz = xyz; a.out = mask_out; a.stash_f = P.stash_f; a.stash_b = P.stash_b; a.relu_mask = P.relu;
     if (train) hipLaunchKernelGGL(k_maskfield_fwd<true>, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
     else hipLaunchKernelGGL(k_maskfield_fwd<false>, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);
     LAUNCHCK();
@@ -479,12 +488,12 @@ extern "C" int nvfi_maskfield_bwd(const nvfi_mask_desc* m, int64_t N, const floa
         for (int l = 0; l < 5; ++l) { const int MT = l < 4 ? 4 : 1, NS = l == 0 ? 2 : 64; a.W.f[l] = p; p += MT * NS * 64; a.W.b[l] = p; p += 128; }
         for (int l = 1; l < 5; ++l) { const int NS = l < 4 ? 64 : 16; a.W.t[l] = p; p += 4 * NS * 64; }
     }
-    a.mask_dim = m->mask_dim; a.N = N; a.g_out = g_mask; a.stash_f = P.stash_f; a.stash_b = P.stash_b;
+    a.mask_dim = m->mask_dim; a.N = N; a.g_out = g_mask; a.stash_f = P.stash_f; a.stash_b = P.stash_b; a.relu_mask = P.relu;
     const unsigned wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
     if (mode & NVFI_MASK_FP16) {
         Mk16Args h; memset(&h, 0, sizeof(h));
         mask_frag16_ptrs(P.frag, &h.W, m);
-        h.mask_dim = m->mask_dim; h.N = N; h.g_out = g_mask; h.stash_f = P.stash_f; h.stash_b = P.stash_b;
+        h.mask_dim = m->mask_dim; h.N = N; h.g_out = g_mask; h.stash_f = P.stash_f; h.stash_b = P.stash_b; h.relu_mask = P.relu;
         hipLaunchKernelGGL(k_maskfield_bwd16, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, h);
     } else
     hipLaunchKernelGGL(k_maskfield_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, a);

@@ -360,13 +360,6 @@ __device__ __forceinline__ void app_gather_to_scratch(const nvfi_field_desc& f, 
     }
 }
 
-// ReLU masks of a hidden layer for the backward pass: bit s of the lane's pair of words = (activation register s > 0)
-__device__ __forceinline__ void relu_mask_store(unsigned* dst, int lane, const float* x) {
-    unsigned lo = 0u, hi = 0u;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) { lo |= x[s] > 0.f ? 1u << s : 0u; hi |= x[32 + s] > 0.f ? 1u << s : 0u; }
-    dst[lane] = lo; dst[64 + lane] = hi;
-}
 template <bool STASH>
 __global__ __launch_bounds__(WG_THREADS, 2) void k_app_fwd(AppArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];

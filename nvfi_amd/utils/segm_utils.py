@@ -6,17 +6,20 @@ import numpy as np
 import torch
 
 
-def sample_volume_points(volume_bounds, n_sample_point=64, perturb=False):
+def sample_volume_points(volume_bounds, n_sample_point=64, perturb=False, device=None):
     """utils/point_util.py:4-21: one jittered (or centred) point per cell of an n^3 lattice over volume_bounds (3,2) -> (n,n,n,3).
-    The random draw is made on the CPU generator, as in the reference."""
+    The random draw is made on the CPU generator, as in the reference (n x 3 numbers).  device: build the n^3 lattice THERE from the n x 3
+    per-axis coordinates (same values; the reference builds it on the host and copies 3 MB per iteration)."""
     t_vals = torch.linspace(0.0, 1.0, steps=n_sample_point + 1).unsqueeze(1)
-    vb = volume_bounds.detach().cpu().float()
+    vb = volume_bounds.detach().cpu().float() if not isinstance(volume_bounds, (list, tuple)) else torch.tensor(volume_bounds, dtype=torch.float32)
     xyz_vals = vb[:, 0] * (1 - t_vals) + vb[:, 1] * t_vals
     lower, upper = xyz_vals[:-1], xyz_vals[1:]
     if perturb:
         points = lower + (upper - lower) * torch.rand(n_sample_point, 3)
     else:
         points = 0.5 * (lower + upper)
+    if device is not None:
+        points = points.to(device)
     x, y, z = torch.meshgrid(points[:, 0], points[:, 1], points[:, 2], indexing="ij")
     return torch.stack([x, y, z], 3)
 
@@ -36,8 +39,9 @@ def balanced_sample(xyz, object_bounds):
 def segm_points(kplane, n_sample_res, min_t, alpha_scale=10.0, object_bounds=None, t=None, dists=0.01):
     """train_segm.py:127-170.  Returns (xyz (N,3) normalised keyframe-0 points, flow (N,3), t) for one iteration."""
     device = kplane.aabb.device
-    volume_bounds = kplane.aabb.reshape(2, 3).transpose(0, 1)
-    xyz = sample_volume_points(volume_bounds, n_sample_res, perturb=True).to(device).reshape(-1, 3)
+    ab = kplane._aabb_host                       # host copy of the box (no device read per iteration)
+    volume_bounds = [[ab[0], ab[3]], [ab[1], ab[4]], [ab[2], ab[5]]]
+    xyz = sample_volume_points(volume_bounds, n_sample_res, perturb=True, device=device).reshape(-1, 3)
     xyz = kplane.normalize_coord(xyz)
     t0 = torch.zeros(xyz.shape[0], 1, device=device)
     sigma_feature = kplane.compute_densityfeature(torch.cat([xyz, kplane.normalize_time_coord(t0)], dim=1))
