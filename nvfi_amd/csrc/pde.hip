@@ -745,14 +745,20 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     LAUNCHCK();
     // The kept count stays on the device (L.kcount): the jet passes are launched with worst-case grids and size themselves from it.
     // Only a caller that asks for host_info (diagnostics; the Python mirror's `return 0.` decision, nvfi.py:66) pays a synchronisation.
-    if (host_info) {
+    // A split call (nvfi_pde_loss_split: the reference's loop) waits LATER - once the Jacobian forward and the value are queued on `stream` and the
+    // adjoint half on the other one: the host's wait then covers the prefilter AND the forward (the caller's own wait for the value, `if loss_vel > 0`,
+    // returns at once) and the device does not idle between the prefilter and the jets while the host wakes up (30-140 us per iteration in a trace).
+    const bool defer_host = host_info && t_bwd_stream && P <= L.chunk && grads;
+    auto read_host_info = [&]() -> int {
         int hcnt[PDE_MAX_CLASS + 16];
         HIPCK(hipMemcpyAsync(hcnt, L.cls_count, sizeof(hcnt), hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         int64_t evals = 0;
         for (int c = 0; c < PDE_MAX_CLASS; ++c) evals += 2ll * c * hcnt[c];
         host_info[0] = hcnt[PDE_MAX_CLASS]; host_info[1] = evals;
-    }
+        return 0;
+    };
+    if (host_info && !defer_host) { if (read_host_info()) return 1; }
     if (kept_out) HIPCK(hipMemcpyAsync(kept_out, L.flags, (size_t)P, hipMemcpyDeviceToDevice, st));
     bool finished = false;
     for (int64_t first = 0; first < P; first += L.chunk) {
@@ -798,6 +804,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
             LAUNCHCK();
             hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, sb, L.kcount, first, cap, L.dcount);
             if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, sb)) return 1;
+            if (defer_host) { if (read_host_info()) return 1; }
         }
         LAUNCHCK();
     }
