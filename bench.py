@@ -53,7 +53,7 @@ APP_FLOP = 64768           # 2*(48*32 + 110*128 + 128^2 + 128*3)
 PEAK_FP32_MFMA = 157.3     # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 PEAK_HBM_GBS = 8000.0      # GB/s, MI355X_MICROARCH.md (HBM3E)
 CLASSES = ["rk2_fwd", "rk2_bwd", "app_fwd", "app_bwd", "wgrad", "pde_fwd", "pde_bwd", "density_fwd", "density_bwd", "pde_prefilter", "density_scatter", "app_scatter", "other"]
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def bat_cfg(S=128, use_vel=True):
@@ -1193,6 +1193,9 @@ def main():
                                     "with step rejection, no white background, 688 samples per ray, P = 131072)"),
             "segm": dict(extra(["--workload", "segm"], scene_args=False, full=True),
                          what="BASELINE configs[4], one GPU's share: train_segm.py's MaskField step (64^3 lattice -> occupied points -> integrate_pos -> MaskField fwd + bwd + Adam); points/s"),
+            "segm_fp16_mfma": dict(extra(["--workload", "segm"], {"NVFI_MASK_FP16": "1", "NVFI_VEL_FP16": "1"}, scene_args=False),
+                                   what="the same step with configs[4]'s 'fp16 MFMA MLP': MaskField forward / adjoint on v_mfma_f32_32x32x16_f16 (fp32 accumulation, fp32 stashes and "
+                                        "weight gradients) and integrate_pos on the fp16-input inference kernel; opt-in, stated in dtype"),
         }
     if graph_line is not None:
         modes = {"hipgraph_replay": {"value": graph_line["value"], "ms_per_step": graph_line["ms_per_step"]},

@@ -83,8 +83,9 @@ class _MseFn(__import__("torch").autograd.Function):
 
 def mse_loss(x, target):
     """torch.nn.functional.mse_loss(x, target) (mean reduction) for CUDA fp32 tensors of a training batch: one launch forward, one backward.
-    Falls back to torch for anything else (other dtypes / devices / sizes above 2^22)."""
+    The kernel is ONE workgroup (a 2048-ray batch is 6144 values: launch-bound, not bandwidth-bound), so it is used for batch-sized inputs only;
+    anything else - other dtypes / devices, more than 65536 values (a full image would run on one CU) - goes to torch."""
     import torch
-    if x.is_cuda and x.dtype == torch.float32 and target.dtype == torch.float32 and x.shape == target.shape and 0 < x.numel() <= (1 << 22):
+    if x.is_cuda and x.dtype == torch.float32 and target.dtype == torch.float32 and x.shape == target.shape and 0 < x.numel() <= (1 << 16):
         return _MseFn.apply(x, target)
     return torch.nn.functional.mse_loss(x, target)

@@ -24,6 +24,7 @@ NVFI_WGRAD=engine python $REPO/bench.py --no-extras --graph off --no-cpu-baselin
 NVFI_RK2_FUSE=0 python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_rk2_unfused.json 2>/dev/null
 python $REPO/bench.py --workload chessboard > $OUT/${TAG}_bench_line_chessboard.json 2>/dev/null
 python $REPO/bench.py --workload segm > $OUT/${TAG}_bench_line_segm.json 2>/dev/null
+NVFI_MASK_FP16=1 NVFI_VEL_FP16=1 python $REPO/bench.py --workload segm --no-cpu-baseline > $OUT/${TAG}_bench_line_segm_fp16_mfma.json 2>/dev/null
 python $REPO/bench.py --no-extras --graph off --no-cpu-baseline --rays 256 --pts 32768 > $OUT/${TAG}_bench_line_strong_shard_1of8.json 2>/dev/null
 # other kernel selections: opt-in fp16-input pre-pass with the fp32 band; the engine kernels of vel.hip instead of vel_split.hip
 NVFI_PDE_PREFILTER=fp16band python $REPO/bench.py --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_line_fp16band.json 2>/dev/null
