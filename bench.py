@@ -1087,7 +1087,9 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": {"fp16band": "f32 (opt-in: fp16-input pre-pass of the PDE occupancy prefilter, fp32 re-evaluation band)",
                   "split16band": "f32 (opt-in: PDE occupancy prefilter with fp32 products emulated by two binary16 terms per operand on the fp16 MFMA, fp32 re-evaluation band)"
-                  }.get(os.environ.get("NVFI_PDE_PREFILTER", "fp32"), "f32"),
+                  }.get(os.environ.get("NVFI_PDE_PREFILTER", "fp32"), "f32")
+                 + (" (opt-in: FORWARD of the training renders' velocity warp on the fp16-input MFMA, fp32 accumulation and stashes; adjoint, weight gradients, "
+                    "PDE term and render MLP fp32)" if os.environ.get("NVFI_VEL_FP16_TRAIN", "0") == "1" else ""),
         "data": "synthetic",
         "config": {"workload": (f"chessboard.yaml (configs[3], one GPU's share): InDoorSeg box, {'x'.join(str(int(g)) for g in model.nvfi.gridSize.tolist())} grid, K=4, surround-box velocity gate, "
                                 f"no white background, {model.nvfi.nSamples} samples/ray, 2 renders x {n_rays} rays + PDE on {n_pts} collocation points + plane regularisers + Adam, per GPU"
@@ -1185,6 +1187,10 @@ def main():
             "optin_fp16band_prefilter": dict(extra(["--graph", "off"], {"NVFI_PDE_PREFILTER": "fp16band"}),
                                              what="opt-in (NOT the headline): fp16-input pre-pass of the PDE occupancy prefilter with an fp32 re-evaluation band; "
                                                   "identical kept set on every test field, no proof"),
+            "optin_fp16_forward_warp": dict(extra(["--graph", "off"], {"NVFI_VEL_FP16_TRAIN": "1"}),
+                                            what="opt-in (NOT the headline; the reference's counterpart is --disable_fp32, train_nvfi.py:96,144): the velocity warp of training renders "
+                                                 "evaluates VelBasis FORWARD with fp16-input MFMAs (fp32 accumulation, fp32 stashes); adjoint and weight gradients stay fp32 MFMA on "
+                                                 "those stashes; digit-level parity with the oracle in the same arithmetic"),
             "live": dict(extra(["--live", "--graph", "off"]), what="the optimiser moves the field it renders (train_nvfi.py:243), as in real training: on random targets the blob "
                          "thickens and the PDE kept set grows 34 k -> 114 k points within these steps, so the step is slower than the stationary headline (same kernels)"),
             "strong_shard_1of8": dict(strong_shard(), what="the fused step at 1/8 of the global batch (--rays 256 --pts 32768: what each of 8 ranks runs under --scaling strong), one GPU"),

@@ -39,7 +39,10 @@ typedef struct nvfi_field_desc {
                               * terms per operand, three MFMAs, ~2^-21 relative per product): 1 = every NO-GRAD back-advection (nvfi_integrate_pos,
                               * the warp of eval-mode renders, nvfi_compute_alpha) evaluates VelBasis with fp16-input MFMAs (weights and layer
                               * inputs rounded to binary16, fp32 accumulation) - the counterpart of the reference's autocast switch
-                              * --disable_fp32 (train_nvfi.py:96,144) for inference; training renders, the PDE term and all gradients stay fp32 */
+                              * --disable_fp32 (train_nvfi.py:96,144) for inference; training renders, the PDE term and all gradients stay fp32.
+                              * Bit 2 (+4, round 4, opt-in): the velocity warp of TRAINING renders runs its FORWARD on the one-term fp16-input MFMA too
+                              * (pre-activations stashed in fp32; the adjoint and the weight gradients stay fp32 MFMA on those stashes - the
+                              * arithmetic of a forward under autocast with an fp32 backward; the PDE term and the render MLP stay fp32) */
     int32_t am_dims[3];      /* alpha volume W,H,D */
     float aabb[6];           /* min xyz, max xyz */
     float near_, far_, step_size;

@@ -56,12 +56,12 @@ extern "C" int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const flo
     if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
     PackJobs jobs; jobs.n = 0;
     Rk2Args a; memset(&a, 0, sizeof(a));
-    if (!f->vel_fp16) {
+    if (!(f->vel_fp16 & 3)) {
         if (pack_vel_frags(f->vW, f->vb, fv, &a.Wv, &jobs)) return 3;
         if (launch_pack(jobs, st)) return 1;
     }
     hipLaunchKernelGGL(k_pack_xt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, x, xw);
-    if (f->vel_fp16) {      // opt-in fp16-input inference mode (pre16.hip): the fragment region of the workspace holds the fp16 image
+    if (f->vel_fp16 & 3) {      // opt-in fp16-input inference mode (pre16.hip): the fragment region of the workspace holds the fp16 image
         static_assert(VEL_FRAG_FLOATS * 4 >= 2 * PRE16_IMAGE_BYTES, "fragment region holds the fp16 images (hi + lo)");
         Rk16Args h; memset(&h, 0, sizeof(h));
         h.img = fv; h.P = N; h.xw = xw; h.xout3 = xk; h.pt_t = t; h.pt_base = base; h.dt_max = dt_max_of(*f); h.max_steps = 4096;
@@ -121,7 +121,7 @@ extern "C" int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const flo
             a.dt[n] = dt; a.tcur[n] = tc;
             off = off - dt; tc = tc - dt; ++n;
         }
-        if (f->vel_fp16) {  // opt-in fp16-input inference mode (pre16.hip)
+        if (f->vel_fp16 & 3) {  // opt-in fp16-input inference mode (pre16.hip)
             Rk16Args h; memset(&h, 0, sizeof(h));
             h.img = fv; h.P = N; h.xw = xw; h.xout = xw; h.nsteps = n;
             for (int k = 0; k < n; ++k) { h.dt[k] = a.dt[k]; h.tcur[k] = a.tcur[k]; }

@@ -96,8 +96,11 @@ struct Rk16Args {
     const float4* xw; float4* xout; float* xout3;
     const float* pt_t; const float* pt_base; float dt_max; int max_steps;
     int nsteps; float dt[64]; float tcur[64]; const float* sched;
+    // training stash (uniform mode, vel_fp16 bit 2): the forward's pre-activations / encoder slots / per-(step, sample) records in exactly the
+    // layout k_rk2_split_uni<STASH> writes, so the fp32 adjoint (k_rk2_fuse_bwd / k_rk2_split_bwd) and k_wgrad_ring8 read them unchanged
+    float* zst; float* x0st; float* rec; int64_t cap; int64_t cap_tiles;
 };
-int launch_rk2_inf16(const nvfi_field_desc* f, Rk16Args a, bool uniform, hipStream_t st);
+int launch_rk2_inf16(const nvfi_field_desc* f, Rk16Args a, bool uniform, hipStream_t st, bool stash = false);
 int launch_pde_band(const nvfi_field_desc* f, int64_t P, const int* perm, const float* sig, const uint8_t* near, float band, uint8_t* flags,
                     int* cnt, hipStream_t st);
 int launch_pde_band_map(int64_t P, const int* bcount, const int* perm, int* blist, hipStream_t st);

@@ -115,30 +115,36 @@ __device__ __forceinline__ void put_h8(h8_t* B, int g, float v) {
 // gated VelBasis.get_vel weights (velocity_field.py:77-93) of the wave's 32 points; out4 as velnet_forward (engine.h).
 // The activations live ONLY as MFMA operands: the epilogue of a layer writes act(z) straight into the (hi [, lo]) binary16 operand registers
 // of the next layer - two operand sets alternate, no fp32 activation array exists (the split mode needs its registers for the second terms).
+// zst / x0st (training stash, or NULL): the fp32 pre-activations of the five hidden layers (row 64 l + 16 m + r of the tile's z block - the D
+// layout of a 32x32 MFMA is the same for fp16 and fp32 inputs, so this IS the engine's stash layout) and the encoder slots
 template <bool SPLIT = false>
-__device__ __forceinline__ void velnet16(const h8_t* W, const h8_t* Wlo, const float* bias, int lane, int h, const float4& q, float* out4) {
+__device__ __forceinline__ void velnet16(const h8_t* W, const h8_t* Wlo, const float* bias, int lane, int h, const float4& q, float* out4,
+                                         float* zst = nullptr, float* x0st = nullptr) {
     constexpr int NB = SPLIT ? 16 : 8;
     h8_t Ba[NB], Bb[NB];
     {
         float x0[16];
         vel_encode_slots(q, h, x0);
+        if (x0st) stash_store<16>(x0st, lane, x0);
 #pragma unroll
         for (int g = 0; g < 16; ++g) put_h8<2, SPLIT>(Ba, g, x0[g]);
     }
     layer16p<4, 2, SPLIT>(W + P16_L0, Wlo + P16_L0, bias, lane, h, Ba, [&](int m, const f32x16& acc) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) put_h8<8, SPLIT>(Bb, 16 * m + r, act_f<1>(acc[r]));
+        for (int r = 0; r < 16; ++r) { if (zst) STASH_ST(zst[(size_t)(16 * m + r) * REGF + lane], acc[r]); put_h8<8, SPLIT>(Bb, 16 * m + r, act_f<1>(acc[r])); }
     });
 #pragma unroll 1
     for (int it = 0; it < 2; ++it) {
         const int l = 1 + 2 * it;
+        float* z1 = zst ? zst + (size_t)l * 64 * REGF : nullptr;
+        float* z2 = zst ? zst + (size_t)(l + 1) * 64 * REGF : nullptr;
         layer16p<4, 8, SPLIT>(W + P16_LH(l), Wlo + P16_LH(l), bias + 128 * l, lane, h, Bb, [&](int m, const f32x16& acc) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) put_h8<8, SPLIT>(Ba, 16 * m + r, act_f<1>(acc[r]));
+            for (int r = 0; r < 16; ++r) { if (z1) STASH_ST(z1[(size_t)(16 * m + r) * REGF + lane], acc[r]); put_h8<8, SPLIT>(Ba, 16 * m + r, act_f<1>(acc[r])); }
         });
         layer16p<4, 8, SPLIT>(W + P16_LH(l + 1), Wlo + P16_LH(l + 1), bias + 128 * (l + 1), lane, h, Ba, [&](int m, const f32x16& acc) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) put_h8<8, SPLIT>(Bb, 16 * m + r, act_f<1>(acc[r]));
+            for (int r = 0; r < 16; ++r) { if (z2) STASH_ST(z2[(size_t)(16 * m + r) * REGF + lane], acc[r]); put_h8<8, SPLIT>(Bb, 16 * m + r, act_f<1>(acc[r])); }
         });
     }
     layer16p<1, 8, SPLIT>(W + P16_L5, Wlo + P16_L5, bias + 128 * 5, lane, h, Bb, [&](int, const f32x16& acc) {
@@ -215,7 +221,9 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_pre16(Pre16Args a) {
 // as the prefilter pre-pass above, with the two time modes of k_rk2_fwd: per-point (t, base) or a uniform step schedule.
 // Training renders, the PDE regulariser and every gradient stay fp32.  tests/test_gpu_vel_fp16.py checks it against a CPU restatement
 // in the same arithmetic (binary16-rounded operands, fp32 accumulation).
-template <bool UNI, bool SPLIT>
+// STASH (uniform mode only): the training render's warp - the z / x0 stashes and the per-(step, sample) records of k_rk2_split_uni<STASH>
+// (vel_split.hip), whole 128-sample groups (the adjoint and the weight-gradient kernels walk every tile of the last, ragged group)
+template <bool UNI, bool SPLIT, bool STASH = false>
 __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_inf16(Rk16Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_inf16(Rk16Args a) {
     if (a.count) { const int64_t c = *a.count; P = c < P ? c : P; }
     const int64_t tile = (int64_t)blockIdx.x * (P16_THREADS / 64) + (threadIdx.x >> 6);
     const int64_t i = tile * TILE + (lane & 31);
-    if (tile * TILE >= P) return;                       // wave-uniform; no barrier follows
+    if (tile * TILE >= (STASH ? (P + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES : P)) return;     // wave-uniform; no barrier follows
     const bool active = i < P;
     const int64_t n = active ? (a.list ? (int64_t)a.list[i] : i) : 0;
     const float4 q0 = active ? a.xw[n] : zero4();
@@ -252,18 +260,34 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_inf16(Rk16Args a) {
             dt = off > 0.f ? m : (off < 0.f ? -m : 0.f);
         }
         float o4[4], w1[6], w2[6], v1[3], v2[3];
-        velnet16<SPLIT>(W, Wlo, bias, lane, h, make_float4(x, y, z, tcur), o4);
+        float *z1 = nullptr, *z2 = nullptr, *x1 = nullptr, *x2 = nullptr;
+        if (STASH) {
+            const size_t e1 = (size_t)(2 * s) * a.cap_tiles + tile, e2 = (size_t)(2 * s + 1) * a.cap_tiles + tile;
+            z1 = a.zst + e1 * (VEL_Z_REGS * REGF); z2 = a.zst + e2 * (VEL_Z_REGS * REGF);
+            x1 = a.x0st + e1 * (VEL_X0_REGS * REGF); x2 = a.x0st + e2 * (VEL_X0_REGS * REGF);
+        }
+        velnet16<SPLIT>(W, Wlo, bias, lane, h, make_float4(x, y, z, tcur), o4, z1, x1);
         gather6(o4, h, w1);
         vel_from_w(w1, x, y, z, v1);
-        if (gated_out(a.f, x, y, z)) { v1[0] = v1[1] = v1[2] = 0.f; }
+        const bool g1 = gated_out(a.f, x, y, z);
+        if (g1) { v1[0] = v1[1] = v1[2] = 0.f; }
         const float hdt = 0.5f * dt;
         const float px = x - hdt * v1[0], py = y - hdt * v1[1], pz = z - hdt * v1[2];
-        velnet16<SPLIT>(W, Wlo, bias, lane, h, make_float4(px, py, pz, tcur - hdt), o4);
+        velnet16<SPLIT>(W, Wlo, bias, lane, h, make_float4(px, py, pz, tcur - hdt), o4, z2, x2);
         gather6(o4, h, w2);
         vel_from_w(w2, px, py, pz, v2);
-        if (gated_out(a.f, px, py, pz)) { v2[0] = v2[1] = v2[2] = 0.f; }
+        const bool g2 = gated_out(a.f, px, py, pz);
+        if (g2) { v2[0] = v2[1] = v2[2] = 0.f; }
         const float nx = x - dt * v2[0], ny = y - dt * v2[1], nz = z - dt * v2[2];
         const bool rej = a.f.gate_sur && gated_out(a.f, nx, ny, nz);
+        if (STASH && active && h == 0) {
+            float* rc = a.rec + (size_t)s * RK_NF * a.cap + i;
+            rc[0 * a.cap] = x; rc[1 * a.cap] = y; rc[2 * a.cap] = z;
+            rc[3 * a.cap] = px; rc[4 * a.cap] = py; rc[5 * a.cap] = pz;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { rc[(6 + k) * a.cap] = w1[k]; rc[(12 + k) * a.cap] = w2[k]; }
+            rc[18 * a.cap] = __int_as_float((g1 ? 1 : 0) | (g2 ? 2 : 0) | (rej ? 4 : 0));
+        }
         if (live) {
             if (!rej) { x = nx; y = ny; z = nz; }
             if (!UNI) { off = off - dt; tcur = tcur - dt; }
@@ -275,9 +299,10 @@ __global__ __launch_bounds__(P16_THREADS, 1) void k_rk2_inf16(Rk16Args a) {
     }
 }
 
-int launch_rk2_inf16(const nvfi_field_desc* f, Rk16Args a, bool uniform, hipStream_t st) {
+int launch_rk2_inf16(const nvfi_field_desc* f, Rk16Args a, bool uniform, hipStream_t st, bool stash) {
     static bool attr = false;
     if (!attr) {
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
         HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
         HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
         HIPCK(hipFuncSetAttribute((const void*)k_rk2_inf16<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PRE16_IMAGE_BYTES));
@@ -285,7 +310,7 @@ int launch_rk2_inf16(const nvfi_field_desc* f, Rk16Args a, bool uniform, hipStre
         attr = true;
     }
     if (a.P <= 0) return 0;
-    const bool split = f->vel_fp16 == 2;      // two binary16 terms per operand (fp32 products emulated): the lo image follows the hi image
+    const bool split = !stash && (f->vel_fp16 & 3) == 2;      // two binary16 terms per operand (fp32 products emulated): the lo image follows the hi image
     a.img_lo = split ? (char*)a.img + PRE16_IMAGE_BYTES : nullptr;
     Pack16VelArgs pk;
     for (int l = 0; l < 6; ++l) { pk.W[l] = f->vW[l]; pk.b[l] = f->vb[l]; }
@@ -293,10 +318,13 @@ int launch_rk2_inf16(const nvfi_field_desc* f, Rk16Args a, bool uniform, hipStre
     pk.img_lo = reinterpret_cast<h8_t*>(a.img_lo);
     hipLaunchKernelGGL(k_pack_vel16, dim3((P16_H8 + 255) / 256), dim3(256), 0, st, pk);
     a.f = *f;
-    const int64_t tiles = (a.P + TILE - 1) / TILE;
+    const int64_t tiles = stash ? (a.P + WG_SAMPLES - 1) / WG_SAMPLES * (WG_SAMPLES / TILE) : (a.P + TILE - 1) / TILE;
     const unsigned wgs = (unsigned)((tiles + P16_THREADS / 64 - 1) / (P16_THREADS / 64));
     ProfScope ps(PK_RK2_FWD, st);
-    if (uniform) {
+    if (stash) {
+        if (!uniform) return nvfi_fail(2, "the fp16-input training stash exists for the uniform (render) warp only");
+        hipLaunchKernelGGL((k_rk2_inf16<true, false, true>), dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
+    } else if (uniform) {
         if (split) hipLaunchKernelGGL((k_rk2_inf16<true, true>), dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
         else hipLaunchKernelGGL((k_rk2_inf16<true, false>), dim3(wgs), dim3(P16_THREADS), PRE16_IMAGE_BYTES, st, a);
     } else {

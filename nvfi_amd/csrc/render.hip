@@ -1147,7 +1147,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->xpre = B.take<float>(N);
     P->vel_frag = B.take<float>(VEL_FRAG_FLOATS);
     P->vel_x4 = nsteps > 0 ? B.take<float>(VEL_X4F_FLOATS) : nullptr;
-    P->img16 = (nsteps > 0 && !train && f->vel_fp16) ? (void*)B.take<float4>(2 * PRE16_IMAGE_BYTES / 16) : nullptr;   // fp16 inference images (hi, lo)
+    P->img16 = (nsteps > 0 && ((!train && (f->vel_fp16 & 3)) || (train && (f->vel_fp16 & 4)))) ? (void*)B.take<float4>(2 * PRE16_IMAGE_BYTES / 16) : nullptr;   // fp16 images (hi, lo)
     P->vel_x4b = (nsteps > 0 && train) ? B.take<float>(VEL_X4B_FLOATS) : nullptr;
     P->render_frag = B.take<float>(RENDER_FRAG_FLOATS);
     P->maskv = (flags & NVFI_WANT_MASK) ? B.take<float>(N * 32) : nullptr;
@@ -1270,12 +1270,14 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
         // the feature-split layout of vel_split.hip (NVFI_RK2_SPLIT=0: k_rk2_fwd of vel.hip; same stash, same numbers bit for bit)
         static int split = -1;
         if (split < 0) { const char* e = getenv("NVFI_RK2_SPLIT"); split = e ? atoi(e) : 1; }
-        if (f->vel_fp16 && !train) {
-            // opt-in fp16-input inference mode (pre16.hip): eval-mode renders only; the x4 fragment region holds the fp16 image
+        if (((f->vel_fp16 & 3) && !train) || ((f->vel_fp16 & 4) && train)) {
+            // opt-in fp16-input modes (pre16.hip): eval-mode renders (bits 0-1), and - bit 2 - the FORWARD of a training render's warp, which
+            // writes the same stash as k_rk2_split_uni<STASH> (the adjoint and the weight gradients stay fp32 MFMA)
             Rk16Args h; memset(&h, 0, sizeof(h));
             h.img = P.img16; h.P = N; h.count = P.counters + 3; h.list = P.rlist; h.xw = P.xw; h.xout = P.xw; h.nsteps = nsteps; h.sched = sched;
+            h.zst = P.zst; h.x0st = P.x0st; h.rec = P.rec; h.cap = N; h.cap_tiles = P.cap_tiles;
             for (int s = 0; s < nsteps; ++s) { h.dt[s] = dts[s]; h.tcur[s] = tcs[s]; }
-            if (launch_rk2_inf16(f, h, true, st)) return 1;
+            if (launch_rk2_inf16(f, h, true, st, train)) return 1;
         } else if (split) {
             SplitUniArgs ua; ua.r = ra;
             if (pack_vel_x4_fwd(VW, P.vel_x4, ua.f4, st)) return 1;

@@ -112,6 +112,7 @@ class _RenderFn(torch.autograd.Function):
         field._last_call = (R, t, flags)
         if flags & _lib.NVFI_TRAIN:
             ctx.field, ctx.t, ctx.flags, ctx.ws, ctx.t_on_device = field, t, flags, ws, t_dev is not None
+            ctx.vel_fp16 = int(desc.vel_fp16)      # the workspace layout depends on it: the backward plans with the forward's value
             ctx.save_for_backward(rays_o, rays_d, weights, *params)
         ctx.mark_non_differentiable(counters)
         ctx.set_materialize_grads(False)     # unused outputs (depth, acc, the R x S weights) arrive as None, not as zero tensors
@@ -123,6 +124,7 @@ class _RenderFn(torch.autograd.Function):
         rays_o, rays_d, weights, *params = ctx.saved_tensors
         field = ctx.field
         desc = field._desc(params)
+        desc.vel_fp16 = ctx.vel_fp16
         need = ctx.needs_input_grad[6:]
         inplace = field.accumulate_grads_inplace
         if inplace == "arena":
@@ -441,6 +443,10 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         # Training renders, the PDE term and all gradients stay fp32 whatever this says.
         # True / 1: one binary16 term per MFMA operand; 2 / "split": two terms (fp32 products emulated, ~2^-21 relative per product, 2.4x fp32 speed)
         self.vel_fp16 = {"0": False, "1": True, "2": 2, "split": 2}.get(os.environ.get("NVFI_VEL_FP16", "0"), False)
+        # opt-in (round 4; the reference's counterpart: --disable_fp32 autocasts the forward of every nn.Linear, train_nvfi.py:96,144): the velocity
+        # warp of TRAINING renders evaluates VelBasis forward with fp16-input MFMAs (fp32 accumulation, fp32 stashes); its adjoint and the
+        # weight gradients stay fp32 MFMA on those stashes, the PDE term and the render MLP stay fp32.  Never the default, never the headline.
+        self.vel_fp16_train = os.environ.get("NVFI_VEL_FP16_TRAIN", "0") == "1"
         self.register_load_state_dict_post_hook(lambda m, k: m.update_stepSize(m.gridSize.tolist()))
 
     # ------------------------------------------------------------------ construction
@@ -576,7 +582,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         d.K = int(self.num_keyframes)
         d.Cd, d.Ca, d.app_dim = int(self.density_n_comp[0]), int(self.app_n_comp[0]), int(self.app_dim)
         d.shading = 1 if self.shadingMode == "SH" else 0
-        d.vel_fp16 = 2 if self.vel_fp16 in (2, "split", "split16") else (1 if self.vel_fp16 else 0)
+        d.vel_fp16 = (2 if self.vel_fp16 in (2, "split", "split16") else (1 if self.vel_fp16 else 0)) | (4 if getattr(self, "vel_fp16_train", False) else 0)
         d.n_samples = int(self.nSamples)
         d.use_vel = int(self.use_vel)
         gsur, lo, hi = self._gate()

@@ -167,3 +167,59 @@ def test_gpu_split16_inference_meets_the_fp32_contract(gold, fields):
                         "-k", "render_eval or integrate_pos or cfg1_matches"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     print(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["A", "B"])
+def test_gpu_training_render_with_fp16_forward_warp_matches_the_fp16_oracle(gold, fields, kind):
+    """round 4, opt-in `field.vel_fp16_train` (nvfi_field_desc.vel_fp16 bit 2): the velocity warp of a TRAINING render evaluates VelBasis
+    forward with fp16-input MFMAs (fp32 accumulation, fp32 stashes); the adjoint and the weight gradients stay fp32 on those stashes - the
+    arithmetic of the reference's autocast forward (--disable_fp32, train_nvfi.py:96,144) with an fp32 backward, which is exactly what the
+    oracle does under set_vel_fp16 (fp16 forward, reverse mode in fp32 on the stashed pre-activations).  Render under the 1e-4 contract,
+    every gradient - planes through the warped positions, render MLP, velocity net through the RK2 adjoint - within 1e-3."""
+    from oracle import oracle as orc
+    from conftest import assert_grad
+    model, meta = make_model(kind)
+    f = model.nvfi
+    fs = fields[kind]
+    rng = np.random.default_rng(17)
+    R = 384
+    o, d = gold[f"{kind}:rays_o"][:R], gold[f"{kind}:rays_d"][:R]
+    R = o.shape[0]
+    u = rng.uniform(0, 1, (R, 1)).astype(np.float32)
+    tg = rng.uniform(0, 1, (R, 3)).astype(np.float32)
+    t = 19.0 / 60.0
+
+    def run(fp16):
+        f.train()
+        f.vel_fp16_train = fp16
+        model.zero_grad(set_to_none=True)
+        f.jitter_override = torch.from_numpy(u.copy())
+        try:
+            out = f(t, torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), True)
+        finally:
+            f.jitter_override = None
+            f.vel_fp16_train = False       # (the backward plans its workspace with the forward's setting, whatever the field says by then)
+        (torch.nn.functional.mse_loss(out[0], torch.from_numpy(tg).cuda()) + 0.01 * out[1].mean()).backward()
+        return [x.detach().cpu().numpy() for x in out[:3]], named_grads(model)
+
+    out32, g32 = run(False)
+    out16, g16 = run(True)
+    orc.set_vel_fp16(True)
+    try:
+        ref = orc.render(fs, o, d, t, u=u, train=True, white_bg=True, keep_ctx=True)
+        gref = ref.backward(fs, g_rgb=2 * (ref.rgb - tg) / (R * 3), g_depth=np.full(R, 0.01 / R, np.float32))
+        ref.free()
+    finally:
+        orc.set_vel_fp16(False)
+    assert_contract(out16[0], ref.rgb, "rgb", label=f"fp16-forward training warp {kind}")
+    assert_contract(out16[1], ref.depth, "depth", label=f"fp16-forward training warp {kind}")
+    n = 0
+    for pn in ("density_plane_space.0", "app_plane_space.1", "app_plane_time.0", "basis_mat.weight", "renderModule.mlp.0.weight",
+               "vel_net.weight_net.1.weight", "vel_net.weight_net.4.0.weight", "vel_net.weight_net.6.0.weight", "vel_net.weight_net.7.0.bias"):
+        assert_grad(g16[pn], gref[pn], 1e-3, f"fp16train:{kind}:{pn}")
+        n += 1
+    # and it IS another arithmetic than the fp32 path (fp16-sized differences in the velocity-net gradients), which must be untouched by the switch
+    dv = np.abs(g16["vel_net.weight_net.4.0.weight"] - g32["vel_net.weight_net.4.0.weight"]).max() / np.abs(g32["vel_net.weight_net.4.0.weight"]).max()
+    assert 1e-6 < dv < 5e-2, dv
+    print(f"[{kind}] fp16-forward training warp: {n} gradients within 1e-3 of the fp16 oracle; velocity-net gradient differs from the fp32 path by {dv:.2e} (max-norm)")
