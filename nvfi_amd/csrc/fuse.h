@@ -27,3 +27,43 @@ __device__ __forceinline__ void split_load16(const float4* a4, int lane, f32x4v 
         for (int k = 0; k < 4; ++k) wq[4 * q + k] = b[k * 64 + lane];
     }
 }
+
+// ---------------------------------------------------------------- shared by the fused adjoint + weight-gradient kernels (vel_fuse.hip, pde_fuse.hip)
+#define FUSE_HR 33                                    // float4 per half row (32 samples of four consecutive p rows) + one float4 of padding
+#define FUSE_XB (16 * 2 * FUSE_HR)                    // float4 per exchange buffer: 16 row groups x 2 halves
+#define FUSE_TF (4 * 2 * FUSE_HR * 4)                 // floats per 32-row tile of an exchange buffer
+// LDS writes of this wave have landed, then the workgroup barrier; outstanding global loads (the next layer's z rows and weights) stay in
+// flight across it (a __syncthreads() would be free to wait for them)
+#define FUSE_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// A wave-uniform row-block pointer the optimiser cannot see through: every stash access of the block becomes SGPR base + lane offset +
+// immediate (left to itself, loop strength reduction keeps one 64-bit VGPR induction pointer per stash ROW across the layer loop: 32 registers)
+// (the asm sees a GLOBAL pointer: through a generic one the compiler falls back to flat_load / flat_store)
+typedef const __attribute__((address_space(1))) float* gcfp; typedef __attribute__((address_space(1))) float* gfp;
+__device__ __forceinline__ gcfp opaque_u(const float* p) { gcfp q = (gcfp)p; asm("" : "+s"(q)); return q; }
+__device__ __forceinline__ gfp opaque_u(float* p) { gfp q = (gfp)p; asm("" : "+s"(q)); return q; }
+
+// LDS-DMA of one dword per lane: lane L's word at base + voff lands at lds_dst + 4 L, without passing through a VGPR - a prefetch that holds no
+// register and that the compiler can neither spill nor wait for (inline asm is outside its vmcnt bookkeeping: the reader waits itself).
+// M0 is written and restored inside the statement (wgrad_ring.hip: glds16).
+__device__ __forceinline__ void glds4(const float* base, int voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+
+// ---------------------------------------------------------------- pde_fuse.hip: adjoint of the PDE Jacobian program + the hidden-layer weight gradients
+struct PdeFuseArgs {
+    const float4* t4[6];       // x4 transposed fragments of weight_net (t4[1..4]: 4 tiles x 64 steps, t4[5]: 4 tiles x 4 steps)
+    const int* kcount; int64_t first, cap;     // device count of kept points; this pass handles [first, first + cap)
+    float* stash; const float* seeds;
+    float* slabs;              // slab of hidden layer L (0..3 = weight layers 1..4) and workgroup g at slabs + L * layer_stride + g * slab_floats
+    int64_t layer_stride;      // floats
+    int slab_floats;           // 128 * 128 + 128
+    unsigned long long* timing; // -DPF_TIMING builds only
+};
+int launch_pde_fuse_bwd(const PdeFuseArgs& a, int64_t cap_points, int max_slabs, int* nslab_out, hipStream_t st);

@@ -16,6 +16,7 @@
 #include "vel.h"
 #include "render.h"
 #include "pde.h"
+#include "fuse.h"
 #include "scatter.h"
 
 // ---------------------------------------------------------------- prefilter
@@ -668,6 +669,10 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     // fused jet kernels (pde_jet.hip; NVFI_PDE_JET=0 keeps the column kernels for every column): x4 copies of the v-net fragments
     static int use_jet = -1;
     if (use_jet < 0) { const char* e = getenv("NVFI_PDE_JET"); use_jet = e ? atoi(e) : 1; }
+    // NVFI_PDE_FUSE (default 1): pde_fuse.hip - weight_net's Jacobian adjoint and its four 128 x 128 weight gradients in one persistent kernel
+    // (no gz_1..gz_4 stash, no second pass over the z / zd stash); 0: k_pde_jet_bwd + k_wgrad_ring8 over the full adjoint stash
+    static int pde_fuse = -1;
+    if (pde_fuse < 0) { const char* e = getenv("NVFI_PDE_FUSE"); pde_fuse = e ? atoi(e) : 1; }
     // prefilter mode: fp32 (default: the feature-split kernel of vel_split.hip) | engine32 (k_rk2_fwd of vel.hip: the same numbers bit for
     // bit, ~4 % slower) | fp16band (pre16.hip: fp16-input pass + fp32 re-evaluation of the unsafe points)
     // split16band (opt-in, pre16.hip): the pre-pass with fp32 products emulated by two binary16 terms per operand (three fp16 MFMAs), and a
@@ -792,9 +797,20 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
                 sb = t_bwd_stream;
                 finished = true;
             }
+            int fused_nslab = 0;
+            float* fused_slabs = L.slabs + (size_t)14 * PDE_NSLAB * (128 * 128 + 128);      // sets 14..17 (launch_pde_wgrad uses at most 10 beside them)
             {
                 ProfScope ps(PK_PDE_BWD, sb);
-                if (use_jet) {
+                if (use_jet && pde_fuse && grads->vW[1] && grads->vW[2] && grads->vW[3] && grads->vW[4]) {
+                    // pde_fuse.hip: the adjoint of weight_net's five columns AND its four hidden-layer weight gradients in one persistent kernel;
+                    // the acceleration net's adjoint keeps k_pde_jet_bwd's trailing workgroups (a launch with zero jet tiles)
+                    if (launch_pde_jet_bwd(ja, 0, wgs, sb)) return 1;
+                    PdeFuseArgs fa; memset(&fa, 0, sizeof(fa));
+                    for (int l = 0; l < 6; ++l) fa.t4[l] = t4[l];
+                    fa.kcount = L.kcount; fa.first = first; fa.cap = cap; fa.stash = L.stash; fa.seeds = L.seeds;
+                    fa.slabs = fused_slabs; fa.layer_stride = (int64_t)PDE_NSLAB * (128 * 128 + 128); fa.slab_floats = 128 * 128 + 128;
+                    if (launch_pde_fuse_bwd(fa, cap, PDE_NSLAB, &fused_nslab, sb)) return 1;
+                } else if (use_jet) {
                     if (launch_pde_jet_bwd(ja, (unsigned)(cap / TILE), wgs, sb)) return 1;
                 } else {
                     hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, sb, ja);
@@ -803,7 +819,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
             }
             LAUNCHCK();
             hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, sb, L.kcount, first, cap, L.dcount);
-            if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, sb)) return 1;
+            if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, sb, fused_nslab, fused_slabs)) return 1;
             if (defer_host) { if (read_host_info()) return 1; }
         }
         LAUNCHCK();
@@ -823,7 +839,9 @@ extern "C" int nvfi_pde_loss(const nvfi_field_desc* f, int64_t P, const float* p
 }
 
 // weight gradients of both nets from one chunk's stash
-int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st) {
+// fused_nslab > 0: the slabs of weight_net's four hidden layers were already written (fused_nslab of them each, value + tangent columns
+// summed) by k_pde_fuse_bwd - only its two edge layers and the acceleration net are contracted here, the reduce covers everything
+int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st, int fused_nslab, const float* fused_slabs) {
     const size_t ts = (size_t)PDE_TILE_ROWS * REGF;
     const size_t slab = (size_t)PDE_NSLAB * (128 * 128 + 128);
     // k_wgrad reads the sample count from device memory (dcount, set by k_pde_pass_count: no host sync); ntiles is the capacity
@@ -833,6 +851,13 @@ int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, 
             float* gW = net == 0 ? G->vW[l] : G->aW[l];
             float* gb = net == 0 ? G->vb[l] : G->ab[l];
             if (!gW && !gb) continue;
+            if (net == 0 && fused_nslab > 0 && l >= 1 && l <= 4) {
+                ReduceJob& Q = rj.j[rj.n++];
+                memset(&Q, 0, sizeof(Q));
+                Q.slabs = fused_slabs + (size_t)(l - 1) * slab; Q.nslab = fused_nslab; Q.MTA = 4; Q.KTB = 4; Q.gW = gW; Q.gb = gb;
+                Q.out = 128; Q.in = 128; Q.row_kind = RK_NATURAL; Q.slot_kind = SK_HIDDEN; Q.scale = 1.f;
+                continue;
+            }
             const int npass = net == 0 ? 2 : 1;    // weight_net: value column + 4 tangent columns
             float* sl[2] = {nullptr, nullptr};
             for (int pass = 0; pass < npass; ++pass) {

@@ -1,0 +1,396 @@
+// pde_fuse.hip - adjoint of the PDE regulariser's Jacobian program WITH the velocity net's hidden-layer weight gradients formed in the
+// same kernel (reference: the second-order backward of the functorch Jacobian inside NVFi.get_vel_loss, models/nvfi.py:68-84, through
+// VelBasis.weight_net, models/velocity_field.py:58-67).
+//
+// k_pde_jet_bwd (pde_jet.hip) writes the layer gradients of all five columns (value, d/dx, d/dy, d/dz, d/dt) to the stash - 1 680 rows
+// per 32-point tile - and k_wgrad_ring8 reads them back together with z / zd_j (the z image five times per layer) to contract
+//     G_l = sum_points [ gz_l (x) SiLU(z_{l-1})  +  sum_j gzd_l^j (x) (SiLU'(z_{l-1}) zd_{l-1}^j) ].
+// Here ONE persistent workgroup of TWELVE waves per CU does both, in the role split of vel_fuse.hip:
+//
+//   * waves 0-3 ("adjoint" waves, one per SIMD, raised priority): wave w owns rows [32w, 32w+32) of every layer.  The five columns of a
+//     tile are processed ONE AT A TIME per layer (k_pde_jet_bwd keeps all five in 400 registers of a two-waves-per-SIMD workgroup; at
+//     three waves per SIMD a wave has 168): phase (l, 0) is the value column's dgrad - its epilogue forms SiLU(z_l) (the layer input of
+//     the value column), SiLU'(z_l), SiLU''(z_l) ONCE per layer and keeps the two derivatives in registers -, phases (l, 1..4) are the
+//     tangent columns: gzd_l^j = SiLU' * ga_j to LDS, the tangent layer input SiLU' * zd_l^j to LDS, and the second-derivative correction
+//     SiLU'' * zd_l^j * ga_j accumulated into the value column's gradient, which leaves for LDS with the last tangent column;
+//   * waves 4-11 ("contraction" waves, two per SIMD) hold the 4 x 16 output tiles of the four 128 x 128 gradients for the whole launch
+//     (128 accumulator registers) and contract the pair (layer gradient of column c at layer l+1, layer input of column c at layer l) one
+//     phase behind the adjoint waves;
+//   * one barrier per phase, 21 per tile.  LDS: six rotating images for the tangent columns' gradients (an image is written in phase t,
+//     read as the dgrad's B operand in phase t+5 and contracted in phase t+6; there are four tangent writes in five phases), one for the
+//     value column's (written with the last tangent column, read in the next two phases), two alternating images of layer inputs: 9 x 16.5 KB;
+//   * at the end every workgroup writes one slab per hidden layer in k_wgrad_ring8's format: k_wgrad_reduce is unchanged.
+// Still through the stash and k_wgrad_ring8: the two edge layers (28 -> 128: gz_0 of the five columns is stored as before; 128 -> 6: the
+// seed rows) and the ReLU acceleration net, whose adjoint stays in k_pde_jet_bwd's trailing workgroups (launched with zero jet tiles).
+//
+// Numerics: every ga / gzd is the number k_pde_jet_bwd forms (same operands, same K order); the value column's gradient adds the four
+// corrections one after the other instead of pairwise, and a weight gradient is summed over points in another order than
+// k_wgrad_ring8's - differences of the order of two fp32 summation orders.
+#include <stdlib.h>
+#include <stdio.h>
+#include "common.h"
+#include "vel.h"
+#include "pde.h"
+#include "fuse.h"
+
+#define PF_THREADS 768
+#define PF_NT 6                                       // rotating images of the tangent columns' layer gradients
+#define PF_V PF_NT                                    // image of the value column's layer gradient
+#define PF_Y0 (PF_NT + 1)                             // two alternating images of layer inputs
+#define PF_IMAGES (PF_NT + 3)
+#define PF_LDS_BYTES (PF_IMAGES * FUSE_XB * 16)
+
+#ifdef PF_TIMING
+#define PT_NOW() __builtin_amdgcn_s_memtime()
+#define PT_ADD(slot, t0) do { const unsigned long long n_ = PT_NOW(); pt[slot] += n_ - (t0); (t0) = n_; } while (0)
+#else
+#define PT_ADD(slot, t0) do { } while (0)
+#endif
+
+__device__ __forceinline__ int pf_count(const PdeFuseArgs& a) {
+    const int64_t c = (int64_t)(*a.kcount) - a.first;
+    return c <= 0 ? 0 : (c > a.cap ? (int)a.cap : (int)c);
+}
+__device__ __forceinline__ int pf_inc(int s, int by) { s += by; return s >= PF_NT ? s - PF_NT : s; }
+
+// ---------------------------------------------------------------- adjoint waves
+struct PfA {
+    float4* S;           // the nine images
+    int w, lane, pos;    // pos: float4 index of this lane inside a row group (h * 33 + sample)
+};
+
+// dgrad of one column: acc = T^T fragment (registers) x layer gradient image (LDS)
+__device__ __forceinline__ void pf_dgrad(const PfA& A, int img, const f32x4v (&wq)[16], f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float4* Xr = A.S + img * FUSE_XB + A.pos;
+    float4 b = Xr[0], bn;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        if (g + 1 < 16) bn = Xr[(g + 1) * 2 * FUSE_HR];
+        const float a4[4] = {wq[g].x, wq[g].y, wq[g].z, wq[g].w};
+        acc = MFMA32(a4[0], b.x, acc); acc = MFMA32(a4[1], b.y, acc); acc = MFMA32(a4[2], b.z, acc); acc = MFMA32(a4[3], b.w, acc);
+        b = bn;
+    }
+}
+// this wave's 16 registers of an image
+__device__ __forceinline__ void pf_put(const PfA& A, int img, const float (&v)[16]) {
+    float4* Xw = A.S + img * FUSE_XB + (4 * A.w) * 2 * FUSE_HR + A.pos;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Xw[k * 2 * FUSE_HR] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
+
+// address of this wave's first float4 of an image (its four row groups follow at a stride of 2 * FUSE_HR)
+__device__ __forceinline__ float4* pf_rows(const PfA& A, int img) { return A.S + img * FUSE_XB + (4 * A.w) * 2 * FUSE_HR + A.pos; }
+
+// value column at layer L (3..0): reads image PF_V, writes the layer input SiLU(z_L) to image yimg; leaves SiLU', SiLU'' and the first term
+// of the value column's gradient in registers
+template <int L>
+__device__ __forceinline__ void pf_value_phase(const PfA& A, const float* T, const f32x4v (&wq)[16], int yimg,
+                                               float (&d1)[16], float (&d2)[16], float (&gzv)[16]) {
+    float zr[16];
+    {
+        gcfp zp = opaque_u(T + (size_t)(PDE_Z + L * 64 + 16 * A.w) * REGF);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zr[r] = STASH_LD(zp[r * REGF + A.lane]);
+    }
+    f32x16 acc;
+    pf_dgrad(A, PF_V, wq, acc);
+    float4* Yw = pf_rows(A, yimg);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                         // four registers at a time: the float4 leaves as soon as it is complete
+        float a4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int r = 4 * k + c;
+            const float z = zr[r], s = fast_sigmoid(z), oms = 1.f - s;
+            a4[c] = z * s;
+            d1[r] = s * (1.f + z * oms);
+            d2[r] = s * oms * (2.f + z * (1.f - 2.f * s));
+            gzv[r] = d1[r] * acc[r];
+        }
+        Yw[k * 2 * FUSE_HR] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+    }
+}
+
+// tangent column J (1..4) at layer L (3..0): reads image rimg; writes gzd to image wimg (L > 0) or to the stash (L = 0: the A operand of
+// the input layer's weight gradient), the tangent layer input to image yimg; LAST (J = 4): the value column's gradient leaves too, and the
+// next layer's weights start their trip from L2 behind the last MFMA that reads the current ones
+template <int L, bool LAST>
+__device__ __forceinline__ void pf_tangent_phase(const PfA& A, const PdeFuseArgs& a, float* T, f32x4v (&wq)[16], int J, int rimg, int wimg, int yimg,
+                                                 const float (&d1)[16], const float (&d2)[16], float (&gzv)[16]) {
+    float zd[16];
+    {
+        gcfp zp = opaque_u(T + (size_t)(PDE_ZD + 320 * (J - 1) + L * 64 + 16 * A.w) * REGF);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zd[r] = STASH_LD(zp[r * REGF + A.lane]);
+    }
+    f32x16 acc;
+    pf_dgrad(A, rimg, wq, acc);
+    if (LAST && L >= 1) {
+        asm volatile("" :: "v"(acc[0]));
+        split_load16(a.t4[L] + (size_t)A.w * 16 * 64, A.lane, wq);
+    }
+    float4* Yw = pf_rows(A, yimg);
+    float4* Xw = pf_rows(A, wimg);
+    float4* Vw = pf_rows(A, PF_V);
+    gfp gp = opaque_u(T + (size_t)(PDE_GA + 336 * J + 16 * A.w) * REGF);
+    gfp gv = opaque_u(T + (size_t)(PDE_GA + 16 * A.w) * REGF);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float g4[4], a4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int r = 4 * k + c;
+            const float ga = acc[r];
+            g4[c] = d1[r] * ga;
+            a4[c] = d1[r] * zd[r];
+            gzv[r] = gzv[r] + d2[r] * zd[r] * ga;
+        }
+        Yw[k * 2 * FUSE_HR] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+        if (L > 0) {
+            Xw[k * 2 * FUSE_HR] = make_float4(g4[0], g4[1], g4[2], g4[3]);
+            if (LAST) Vw[k * 2 * FUSE_HR] = make_float4(gzv[4 * k], gzv[4 * k + 1], gzv[4 * k + 2], gzv[4 * k + 3]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) STASH_ST(gp[(4 * k + c) * REGF + A.lane], g4[c]);
+            if (LAST) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) STASH_ST(gv[(4 * k + c) * REGF + A.lane], gzv[4 * k + c]);
+            }
+        }
+    }
+}
+
+template <int L>
+__device__ __forceinline__ void pf_layer(const PfA& A, const PdeFuseArgs& a, float* T, f32x4v (&wq)[16], int& rs,
+                                         float (&d1)[16], float (&d2)[16], float (&gzv)[16]) {
+    // phases tau = 1 + 5 (3 - L) + k; the layer inputs alternate between the two Y images by the parity of tau
+    constexpr int tau0 = 1 + 5 * (3 - L);
+    pf_value_phase<L>(A, T, wq, PF_Y0 + (tau0 & 1), d1, d2, gzv);
+    FUSE_BAR();
+#pragma unroll 1
+    for (int k = 1; k <= 3; ++k) {
+        pf_tangent_phase<L, false>(A, a, T, wq, k, rs, pf_inc(rs, 4), PF_Y0 + ((tau0 + k) & 1), d1, d2, gzv);
+        rs = pf_inc(rs, 1);
+        FUSE_BAR();
+    }
+    pf_tangent_phase<L, true>(A, a, T, wq, 4, rs, pf_inc(rs, 4), PF_Y0 + ((tau0 + 4) & 1), d1, d2, gzv);
+    rs = pf_inc(rs, 1);
+    FUSE_BAR();
+}
+
+__device__ __forceinline__ void pf_role_adjoint(const PdeFuseArgs& a, float4* S, int w, int lane, int ntiles) {
+    PfA A; A.S = S; A.w = w; A.lane = lane;
+    const int h = lane >> 5, j = lane & 31;
+    A.pos = h * FUSE_HR + j;
+    const int G = gridDim.x;
+    const size_t cs = a.cap;
+    int rs = 0;                                           // tangent image the next tangent phase reads
+    f32x4v wq[16];
+    float d1[16], d2[16], gzv[16];
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+        float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
+        const int i = tile * TILE + j;
+        const bool ok = i < (int)a.cap;
+        // ---- phase 0: the five columns at layer 4 (6 -> 128: four MFMAs per column), all from registers
+        {
+            f32x4v w5;
+            {
+                gcf4p b5 = (gcf4p)(a.t4[5] + (size_t)w * 64);
+                asm("" : "+s"(b5));
+                w5 = b5[lane];
+            }
+            // adjoint seeds of the 6 outputs per column, in D-layout registers 0..3: lanes of half h hold outputs 4h .. 4h+3 (k_pde_seeds)
+            // (loaded unconditionally off one wave-uniform base with 32-bit lane offsets - a predicated load becomes a branch per value with a
+            // spilled 64-bit address each -, the rows a half does not own and the points beyond the capacity are zeroed afterwards)
+            float sd[5][4];
+            {
+                gcfp sp = opaque_u(a.seeds);
+                const int capi = (int)a.cap, ii = ok ? i : 0;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const int sbase = c == 0 ? 0 : 6 * c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = sbase + (h ? (k < 2 ? 4 + k : 5) : k);
+                        sd[c][k] = sp[row * capi + ii];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 5; ++c)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sd[c][k] = (ok && (k < 2 || h == 0)) ? sd[c][k] : 0.f;
+            }
+            float zr[16];
+            {
+                gcfp zp = opaque_u(T + (size_t)(PDE_Z + 4 * 64 + 16 * w) * REGF);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zr[r] = STASH_LD(zp[r * REGF + lane]);
+            }
+            // rows gw of each column's adjoint image (A operand of the output layer's weight gradient): wave c & 3 stores column c
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+                if (w == (c & 3)) {
+                    float* gw_rows = T + (size_t)(PDE_GA + 336 * c + 320) * REGF;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? sd[c][s] : 0.f;
+                }
+            const float a4[4] = {w5.x, w5.y, w5.z, w5.w};
+            {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = MFMA32(a4[k], sd[0][k], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float z = zr[r], s = fast_sigmoid(z), oms = 1.f - s;
+                    d1[r] = s * (1.f + z * oms);
+                    d2[r] = s * oms * (2.f + z * (1.f - 2.f * s));
+                    gzv[r] = d1[r] * acc[r];
+                }
+            }
+#pragma unroll 1
+            for (int k = 1; k <= 4; ++k) {
+                float zd[16];
+                {
+                    gcfp zp = opaque_u(T + (size_t)(PDE_ZD + 320 * (k - 1) + 4 * 64 + 16 * w) * REGF);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zd[r] = STASH_LD(zp[r * REGF + lane]);
+                }
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                {
+                    float s4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s4[q] = k == 1 ? sd[1][q] : (k == 2 ? sd[2][q] : (k == 3 ? sd[3][q] : sd[4][q]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = MFMA32(a4[q], s4[q], acc);
+                }
+                float gz[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ga = acc[r];
+                    gz[r] = d1[r] * ga;
+                    gzv[r] = gzv[r] + d2[r] * zd[r] * ga;
+                }
+                pf_put(A, pf_inc(rs, k - 1), gz);
+            }
+            pf_put(A, PF_V, gzv);
+            split_load16(a.t4[4] + (size_t)w * 16 * 64, lane, wq);
+            FUSE_BAR();
+        }
+        pf_layer<3>(A, a, T, wq, rs, d1, d2, gzv);
+        pf_layer<2>(A, a, T, wq, rs, d1, d2, gzv);
+        pf_layer<1>(A, a, T, wq, rs, d1, d2, gzv);
+        pf_layer<0>(A, a, T, wq, rs, d1, d2, gzv);
+    }
+}
+
+// ---------------------------------------------------------------- contraction waves
+// (the barrier names the accumulators as in/out operands: see FUSE_BAR_G in vel_fuse.hip)
+#define PF_BAR_G() do { __builtin_amdgcn_sched_barrier(0);                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(G0a), "+v"(G0b), "+v"(G1a), "+v"(G1b), "+v"(G2a), "+v"(G2b), "+v"(G3a), "+v"(G3b) :: "memory"); \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PF_XBF (FUSE_XB * 4)               // floats per image
+// G[L][t] += sum over the tile's 32 points of g[32 ob + row][s] * a[32 (ib0 + t) + col][s]; BIAS: the value column's gradient also sums into the bias
+#define PF_CONTRACT(L, XIMG, YIMG, BIAS)                                                                             \
+    do {                                                                                                             \
+        const float* xa_ = Sf + (XIMG) * PF_XBF + ob * FUSE_TF + o; const float* yb_ = Sf + (YIMG) * PF_XBF + ib0 * FUSE_TF + o; \
+        _Pragma("unroll") for (int st = 0; st < 16; ++st) {                                                          \
+            const float av_ = xa_[8 * st], b0_ = yb_[8 * st], b1_ = yb_[8 * st + FUSE_TF];                            \
+            G##L##a = MFMA32(av_, b0_, G##L##a); G##L##b = MFMA32(av_, b1_, G##L##b);                               \
+            if (BIAS) asm("v_add_f32 %0, %0, %1" : "+v"(bs##L) : "v"(av_));                                          \
+        }                                                                                                            \
+    } while (0)
+// the contraction waves' intervals of layer L, one phase behind the adjoint waves: value pair, tangent pairs 1..3; the pair of the fourth
+// tangent column is contracted in the first interval of the next layer (or of the next tile)
+#define PF_C_LAYER(L, TAU0)                                                                                          \
+    do {                                                                                                             \
+        PF_CONTRACT(L, PF_V, PF_Y0 + ((TAU0) & 1), 1); PF_BAR_G();                                                    \
+        PF_CONTRACT(L, rs, PF_Y0 + (((TAU0) + 1) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();                            \
+        PF_CONTRACT(L, rs, PF_Y0 + (((TAU0) + 2) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();                            \
+        PF_CONTRACT(L, rs, PF_Y0 + (((TAU0) + 3) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();                            \
+    } while (0)
+
+__device__ __forceinline__ void pf_role_contract(const PdeFuseArgs& a, const float* Sf, int v, int lane, int ntiles) {
+    const int i = lane & 31, kk = lane >> 5;
+    const int ob = v >> 1, ib0 = 2 * (v & 1);
+    // float offset of (row i of a 32-row tile, sample kk) in an image
+    const int o = ((i >> 3) * 2 + (i & 1)) * (FUSE_HR * 4) + ((i >> 1) & 3) + 4 * kk;      // MFMA step st contracts sample 2 st + kk: + 8 st floats
+    f32x16 G0a, G0b, G1a, G1b, G2a, G2b, G3a, G3b;
+    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { G0a[r] = 0.f; G0b[r] = 0.f; G1a[r] = 0.f; G1b[r] = 0.f; G2a[r] = 0.f; G2b[r] = 0.f; G3a[r] = 0.f; G3b[r] = 0.f; }
+    const int G = gridDim.x;
+    int rs = 0;                                           // tangent image of the next tangent pair
+    bool pending = false;                                 // the fourth tangent pair of the previous tile's layer 0 (image rs, Y image 0)
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+        if (pending) { PF_CONTRACT(0, rs, PF_Y0 + 0, 0); rs = pf_inc(rs, 1); }
+        PF_BAR_G();                                       // phase 0 of the adjoint waves
+        PF_BAR_G();                                       // (3, 0)
+        PF_C_LAYER(3, 1);
+        PF_CONTRACT(3, rs, PF_Y0 + ((1 + 4) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();       // (2, 0)
+        PF_C_LAYER(2, 6);
+        PF_CONTRACT(2, rs, PF_Y0 + ((6 + 4) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();       // (1, 0)
+        PF_C_LAYER(1, 11);
+        PF_CONTRACT(1, rs, PF_Y0 + ((11 + 4) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();      // (0, 0)
+        PF_C_LAYER(0, 16);
+        pending = true;
+    }
+    if (pending) PF_CONTRACT(0, rs, PF_Y0 + 0, 0);
+    // one slab per layer and workgroup, in k_wgrad_ring8's format (rows / columns in p-space, bias sums behind the 128 x 128 block)
+#define PF_FLUSH(L)                                                                                                  \
+    do {                                                                                                             \
+        float* Sl = a.slabs + (size_t)(L) * a.layer_stride + (size_t)blockIdx.x * a.slab_floats;                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                             \
+            const int row = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * kk;                                               \
+            Sl[(size_t)row * 128 + 32 * ib0 + i] = G##L##a[r];                                                       \
+            Sl[(size_t)row * 128 + 32 * (ib0 + 1) + i] = G##L##b[r];                                                 \
+        }                                                                                                            \
+        if ((v & 1) == 0) {                                                                                          \
+            float bsum = bs##L; bsum += __shfl_xor(bsum, 32);                                                        \
+            if (kk == 0) Sl[(size_t)128 * 128 + 32 * ob + i] = bsum;                                                 \
+        }                                                                                                            \
+    } while (0)
+    PF_FLUSH(0); PF_FLUSH(1); PF_FLUSH(2); PF_FLUSH(3);
+#undef PF_FLUSH
+}
+
+__global__ __launch_bounds__(PF_THREADS) void k_pde_fuse_bwd(PdeFuseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int count = __builtin_amdgcn_readfirstlane(pf_count(a));
+    // whole 128-point groups, as the forward stashed them
+    const int ntiles = (count + WG_SAMPLES - 1) / WG_SAMPLES * (WG_SAMPLES / TILE);
+    if (wave < 4) {
+        __builtin_amdgcn_s_setprio(3);
+        pf_role_adjoint(a, reinterpret_cast<float4*>(lds), wave, lane, ntiles);
+    } else {
+        pf_role_contract(a, lds, wave - 4, lane, ntiles);
+    }
+}
+
+int launch_pde_fuse_bwd(const PdeFuseArgs& a, int64_t cap_points, int max_slabs, int* nslab_out, hipStream_t st) {
+    *nslab_out = 0;
+    const int64_t tiles = (cap_points + TILE - 1) / TILE;
+    if (tiles <= 0) return 0;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t prop;
+        ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        HIPCK(hipFuncSetAttribute((const void*)k_pde_fuse_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS_BYTES));
+    }
+    int G = ncu < max_slabs ? ncu : max_slabs;
+    if ((int64_t)G > tiles) G = (int)tiles;
+    hipLaunchKernelGGL(k_pde_fuse_bwd, dim3((unsigned)G), dim3(PF_THREADS), PF_LDS_BYTES, st, a);
+    LAUNCHCK();
+    *nslab_out = G;
+    return 0;
+}

@@ -33,8 +33,6 @@
 #ifndef FUSE_THREADS
 #define FUSE_THREADS 768
 #endif
-#define FUSE_HR 33                                    // float4 per half row (32 samples of four consecutive p rows) + one float4 of padding
-#define FUSE_XB (16 * 2 * FUSE_HR)                    // float4 per exchange buffer: 16 row groups x 2 halves
 #define FUSE_NX 3
 #define FUSE_NY 2
 #define FUSE_PARK_FLOATS (16 * 64)                    // per adjoint wave: 10 record fields + the upstream gradient (4) x 64 lanes
@@ -44,17 +42,6 @@
 // consecutive addresses; a lane of the weight gradient (a row p = 32 t + i) reads one float per sample at bank 4 ((2 (i >> 3) + (i & 1) + s) & 7)
 // + ((i >> 1) & 3): the 32 rows of a tile hit 32 different banks for every sample - the padding float4 is what spreads them.
 
-// LDS writes of this wave have landed, then the workgroup barrier; outstanding global loads (the next layer's z rows and weights) stay in
-// flight across it (a __syncthreads() would be free to wait for them)
-#define FUSE_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-// A wave-uniform row-block pointer the optimiser cannot see through: every stash access of the block becomes SGPR base + lane offset +
-// immediate (left to itself, loop strength reduction keeps one 64-bit VGPR induction pointer per stash ROW across the layer loop: 32 registers)
-// (the asm sees a GLOBAL pointer: through a generic one the compiler falls back to flat_load / flat_store)
-typedef const __attribute__((address_space(1))) float* gcfp; typedef __attribute__((address_space(1))) float* gfp;
-__device__ __forceinline__ gcfp opaque_u(const float* p) { gcfp q = (gcfp)p; asm("" : "+s"(q)); return q; }
-__device__ __forceinline__ gfp opaque_u(float* p) { gfp q = (gfp)p; asm("" : "+s"(q)); return q; }
-
 // -DFUSE_TIMING: workgroup 0 accumulates shader-clock intervals per phase (adjoint wave 0: [0..5] MFMA part, [8..13] epilogue part,
 // [16..21] barrier wait, [24] bookkeeping between evaluations; contraction wave 0: [32..37] work, [40..45] barrier wait; [63] evaluations)
 #ifdef FUSE_TIMING
@@ -63,18 +50,6 @@ __device__ __forceinline__ gfp opaque_u(float* p) { gfp q = (gfp)p; asm("" : "+s
 #else
 #define FT_ADD(slot, t0) do { } while (0)
 #endif
-
-// LDS-DMA of one dword per lane: lane L's word at base + voff lands at lds_dst + 4 L, without passing through a VGPR - a prefetch that holds no
-// register and that the compiler can neither spill nor wait for (inline asm is outside its vmcnt bookkeeping: the reader waits itself).
-// M0 is written and restored inside the statement (wgrad_ring.hip: glds16).
-__device__ __forceinline__ void glds4(const float* base, int voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
 
 // ---------------------------------------------------------------- adjoint waves
 struct FuseA {
@@ -425,7 +400,6 @@ __device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(G0a), "+v"(G0b), "+v"(G1a), "+v"(G1b), "+v"(G2a), "+v"(G2b), "+v"(G3a), "+v"(G3b) :: "memory"); \
         __builtin_amdgcn_sched_barrier(0); } while (0)
 // G[L][t] += sum over the tile's 32 samples of g[32 ob + row][s] * a[32 (ib0 + t) + col][s]
-#define FUSE_TF (4 * 2 * FUSE_HR * 4)      // floats per 32-row tile of an exchange buffer
 #define FUSE_CONTRACT(L, XF, YF)                                                                                     \
     do {                                                                                                             \
         const float* xa_ = (XF) + ob * FUSE_TF + o; const float* yb_ = (YF) + ib0 * FUSE_TF + o;                     \
