@@ -1043,6 +1043,10 @@ def main():
             # the wgrad class keeps the two edge layers of that launch
             flops["rk2_bwd"] += E * 131072.0
             flops["wgrad"] -= E * 131072.0
+        if os.environ.get("NVFI_PDE_FUSE", "1") != "0" and os.environ.get("NVFI_PDE_JET", "1") != "0":
+            # pde_fuse.hip: the Jacobian adjoint also forms weight_net's four 128 x 128 weight gradients for the five columns of every kept point
+            flops["pde_bwd"] += kept * 5 * 131072.0
+            flops["wgrad"] -= kept * 5 * 131072.0
         if pre_mode in ("fp16band", "split16band"):      # opt-in: the class is an fp16-MFMA pass + a short fp32 list; no fp32-MFMA figure applies to it
             del flops["pde_prefilter"]
         times = {CLASSES[i]: (tot[i], cnt[i]) for i in range(min(ncls, len(CLASSES)))}

@@ -39,18 +39,32 @@
 #define PF_Y0 (PF_NT + 1)                             // two alternating images of layer inputs
 #define PF_IMAGES (PF_NT + 3)
 #define PF_LDS_BYTES (PF_IMAGES * FUSE_XB * 16)
+#ifndef PF_P0_FIRST
+#define PF_P0_FIRST 4                                 // tangent columns whose layer-4 rows phase 0 requests together with z_4
+#endif
 
+// -DPF_TIMING: workgroup 0 accumulates shader-clock intervals (adjoint wave 0: [0] phase 0 work, [1] value-phase dgrad, [2] value-phase
+// epilogue, [3] tangent-phase dgrad, [4] tangent-phase epilogue, [8..12] the barrier waits behind them; contraction wave 0: [16] work,
+// [17] barrier waits; [31] tiles)
 #ifdef PF_TIMING
+struct PfT { unsigned long long pt[32]; unsigned long long t0; };
 #define PT_NOW() __builtin_amdgcn_s_memtime()
-#define PT_ADD(slot, t0) do { const unsigned long long n_ = PT_NOW(); pt[slot] += n_ - (t0); (t0) = n_; } while (0)
+#define PT_ADD(T_, slot) do { const unsigned long long n_ = PT_NOW(); (T_).pt[slot] += n_ - (T_).t0; (T_).t0 = n_; } while (0)
+#define PT_MFMA_DONE(acc) asm volatile("s_nop 0" :: "v"((acc)[0]))
 #else
-#define PT_ADD(slot, t0) do { } while (0)
+struct PfT { };
+#define PT_ADD(T_, slot) do { } while (0)
+#define PT_MFMA_DONE(acc) do { } while (0)
 #endif
 
 __device__ __forceinline__ int pf_count(const PdeFuseArgs& a) {
     const int64_t c = (int64_t)(*a.kcount) - a.first;
     return c <= 0 ? 0 : (c > a.cap ? (int)a.cap : (int)c);
 }
+// opaque_u (fuse.h) as a VOLATILE asm: the row-block bases of a tile are formed where they are used - left to loop-invariant code motion, the
+// tile-independent halves of ~60 of them are hoisted out of the persistent loop, overflow the SGPR file and come back as v_readlane / scratch reloads
+__device__ __forceinline__ gcfp pf_base(const float* p) { gcfp q = (gcfp)p; asm volatile("" : "+s"(q)); return q; }
+__device__ __forceinline__ gfp pf_base(float* p) { gfp q = (gfp)p; asm volatile("" : "+s"(q)); return q; }
 __device__ __forceinline__ int pf_inc(int s, int by) { s += by; return s >= PF_NT ? s - PF_NT : s; }
 
 // ---------------------------------------------------------------- adjoint waves
@@ -87,15 +101,16 @@ __device__ __forceinline__ float4* pf_rows(const PfA& A, int img) { return A.S +
 // of the value column's gradient in registers
 template <int L>
 __device__ __forceinline__ void pf_value_phase(const PfA& A, const float* T, const f32x4v (&wq)[16], int yimg,
-                                               float (&d1)[16], float (&d2)[16], float (&gzv)[16]) {
+                                               float (&d1)[16], float (&d2)[16], float (&gzv)[16], PfT& TT) {
     float zr[16];
     {
-        gcfp zp = opaque_u(T + (size_t)(PDE_Z + L * 64 + 16 * A.w) * REGF);
+        gcfp zp = pf_base(T + (size_t)(PDE_Z + L * 64 + 16 * A.w) * REGF);
 #pragma unroll
         for (int r = 0; r < 16; ++r) zr[r] = STASH_LD(zp[r * REGF + A.lane]);
     }
     f32x16 acc;
     pf_dgrad(A, PF_V, wq, acc);
+    PT_MFMA_DONE(acc); PT_ADD(TT, 1);
     float4* Yw = pf_rows(A, yimg);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                         // four registers at a time: the float4 leaves as soon as it is complete
@@ -111,6 +126,7 @@ __device__ __forceinline__ void pf_value_phase(const PfA& A, const float* T, con
         }
         Yw[k * 2 * FUSE_HR] = make_float4(a4[0], a4[1], a4[2], a4[3]);
     }
+    PT_ADD(TT, 2);
 }
 
 // tangent column J (1..4) at layer L (3..0): reads image rimg; writes gzd to image wimg (L > 0) or to the stash (L = 0: the A operand of
@@ -118,15 +134,16 @@ __device__ __forceinline__ void pf_value_phase(const PfA& A, const float* T, con
 // next layer's weights start their trip from L2 behind the last MFMA that reads the current ones
 template <int L, bool LAST>
 __device__ __forceinline__ void pf_tangent_phase(const PfA& A, const PdeFuseArgs& a, float* T, f32x4v (&wq)[16], int J, int rimg, int wimg, int yimg,
-                                                 const float (&d1)[16], const float (&d2)[16], float (&gzv)[16]) {
+                                                 const float (&d1)[16], const float (&d2)[16], float (&gzv)[16], PfT& TT) {
     float zd[16];
     {
-        gcfp zp = opaque_u(T + (size_t)(PDE_ZD + 320 * (J - 1) + L * 64 + 16 * A.w) * REGF);
+        gcfp zp = pf_base(T + (size_t)(PDE_ZD + 320 * (J - 1) + L * 64 + 16 * A.w) * REGF);
 #pragma unroll
         for (int r = 0; r < 16; ++r) zd[r] = STASH_LD(zp[r * REGF + A.lane]);
     }
     f32x16 acc;
     pf_dgrad(A, rimg, wq, acc);
+    PT_MFMA_DONE(acc); PT_ADD(TT, 3);
     if (LAST && L >= 1) {
         asm volatile("" :: "v"(acc[0]));
         split_load16(a.t4[L] + (size_t)A.w * 16 * 64, A.lane, wq);
@@ -134,8 +151,8 @@ __device__ __forceinline__ void pf_tangent_phase(const PfA& A, const PdeFuseArgs
     float4* Yw = pf_rows(A, yimg);
     float4* Xw = pf_rows(A, wimg);
     float4* Vw = pf_rows(A, PF_V);
-    gfp gp = opaque_u(T + (size_t)(PDE_GA + 336 * J + 16 * A.w) * REGF);
-    gfp gv = opaque_u(T + (size_t)(PDE_GA + 16 * A.w) * REGF);
+    gfp gp = pf_base(T + (size_t)(PDE_GA + 336 * J + 16 * A.w) * REGF);
+    gfp gv = pf_base(T + (size_t)(PDE_GA + 16 * A.w) * REGF);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float g4[4], a4[4];
@@ -160,24 +177,25 @@ __device__ __forceinline__ void pf_tangent_phase(const PfA& A, const PdeFuseArgs
             }
         }
     }
+    PT_ADD(TT, 4);
 }
 
 template <int L>
 __device__ __forceinline__ void pf_layer(const PfA& A, const PdeFuseArgs& a, float* T, f32x4v (&wq)[16], int& rs,
-                                         float (&d1)[16], float (&d2)[16], float (&gzv)[16]) {
+                                         float (&d1)[16], float (&d2)[16], float (&gzv)[16], PfT& TT) {
     // phases tau = 1 + 5 (3 - L) + k; the layer inputs alternate between the two Y images by the parity of tau
     constexpr int tau0 = 1 + 5 * (3 - L);
-    pf_value_phase<L>(A, T, wq, PF_Y0 + (tau0 & 1), d1, d2, gzv);
-    FUSE_BAR();
+    pf_value_phase<L>(A, T, wq, PF_Y0 + (tau0 & 1), d1, d2, gzv, TT);
+    FUSE_BAR(); PT_ADD(TT, 9);
 #pragma unroll 1
     for (int k = 1; k <= 3; ++k) {
-        pf_tangent_phase<L, false>(A, a, T, wq, k, rs, pf_inc(rs, 4), PF_Y0 + ((tau0 + k) & 1), d1, d2, gzv);
+        pf_tangent_phase<L, false>(A, a, T, wq, k, rs, pf_inc(rs, 4), PF_Y0 + ((tau0 + k) & 1), d1, d2, gzv, TT);
         rs = pf_inc(rs, 1);
-        FUSE_BAR();
+        FUSE_BAR(); PT_ADD(TT, 11);
     }
-    pf_tangent_phase<L, true>(A, a, T, wq, 4, rs, pf_inc(rs, 4), PF_Y0 + ((tau0 + 4) & 1), d1, d2, gzv);
+    pf_tangent_phase<L, true>(A, a, T, wq, 4, rs, pf_inc(rs, 4), PF_Y0 + ((tau0 + 4) & 1), d1, d2, gzv, TT);
     rs = pf_inc(rs, 1);
-    FUSE_BAR();
+    FUSE_BAR(); PT_ADD(TT, 12);
 }
 
 __device__ __forceinline__ void pf_role_adjoint(const PdeFuseArgs& a, float4* S, int w, int lane, int ntiles) {
@@ -189,33 +207,47 @@ __device__ __forceinline__ void pf_role_adjoint(const PdeFuseArgs& a, float4* S,
     int rs = 0;                                           // tangent image the next tangent phase reads
     f32x4v wq[16];
     float d1[16], d2[16], gzv[16];
+    PfT TT;
+#ifdef PF_TIMING
+    for (int k = 0; k < 32; ++k) TT.pt[k] = 0;
+    TT.t0 = PT_NOW();
+#endif
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += G) {
         float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
         const int i = tile * TILE + j;
         const bool ok = i < (int)a.cap;
+        // per-tile opaque copies of the launch-invariant bases: everything derived from them (20 seed rows, 17 fragment quarters) is formed
+        // where it is used instead of being hoisted out of the persistent loop into SGPRs the kernel does not have
+        PdeFuseArgs al = a;
+        {
+            gcfp sp_ = pf_base(a.seeds); al.seeds = (const float*)sp_;
+#pragma unroll
+            for (int l = 1; l <= 5; ++l) { gcfp tp_ = pf_base(reinterpret_cast<const float*>(a.t4[l])); al.t4[l] = reinterpret_cast<const float4*>((const float*)tp_); }
+        }
+        size_t csl = cs; asm volatile("" : "+s"(csl));
         // ---- phase 0: the five columns at layer 4 (6 -> 128: four MFMAs per column), all from registers
         {
             f32x4v w5;
             {
-                gcf4p b5 = (gcf4p)(a.t4[5] + (size_t)w * 64);
+                gcf4p b5 = (gcf4p)(al.t4[5] + (size_t)w * 64);
                 asm("" : "+s"(b5));
                 w5 = b5[lane];
             }
             // adjoint seeds of the 6 outputs per column, in D-layout registers 0..3: lanes of half h hold outputs 4h .. 4h+3 (k_pde_seeds)
-            // (loaded unconditionally off one wave-uniform base with 32-bit lane offsets - a predicated load becomes a branch per value with a
-            // spilled 64-bit address each -, the rows a half does not own and the points beyond the capacity are zeroed afterwards)
+            // (loaded unconditionally: row sbase + 4h + k off a wave-uniform base per (column, k) with ONE lane offset - a predicated load
+            // becomes a branch per value, a lane-dependent row a hoisted and spilled offset per value -; the two rows past a column's six that
+            // the upper half reads belong to the next column (36 rows are allocated), they and the points beyond the capacity are zeroed afterwards)
             float sd[5][4];
             {
-                gcfp sp = opaque_u(a.seeds);
-                const int capi = (int)a.cap, ii = ok ? i : 0;
+                const int lo = (ok ? i : 0) + (h ? 4 * (int)csl : 0);
 #pragma unroll
                 for (int c = 0; c < 5; ++c) {
                     const int sbase = c == 0 ? 0 : 6 * c;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int row = sbase + (h ? (k < 2 ? 4 + k : 5) : k);
-                        sd[c][k] = sp[row * capi + ii];
+                        gcfp sp = pf_base(al.seeds + (size_t)(sbase + k) * csl);
+                        sd[c][k] = sp[lo];
                     }
                 }
 #pragma unroll
@@ -223,17 +255,26 @@ __device__ __forceinline__ void pf_role_adjoint(const PdeFuseArgs& a, float4* S,
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sd[c][k] = (ok && (k < 2 || h == 0)) ? sd[c][k] : 0.f;
             }
-            float zr[16];
+            // every stash row of the phase is requested up front (96 registers in flight; the derivative / gradient registers are not live
+            // yet and the weight fragment is requested behind the phase): ONE round trip to HBM instead of five dependent ones
+            float zr[16], zd[4][16];
             {
-                gcfp zp = opaque_u(T + (size_t)(PDE_Z + 4 * 64 + 16 * w) * REGF);
+                gcfp zp = pf_base(T + (size_t)(PDE_Z + 4 * 64 + 16 * w) * REGF);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zr[r] = STASH_LD(zp[r * REGF + lane]);
+#pragma unroll
+                for (int k = 0; k < PF_P0_FIRST; ++k) {
+                    gcfp zq = pf_base(T + (size_t)(PDE_ZD + 320 * k + 4 * 64 + 16 * w) * REGF);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zd[k][r] = STASH_LD(zq[r * REGF + lane]);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
             // rows gw of each column's adjoint image (A operand of the output layer's weight gradient): wave c & 3 stores column c
 #pragma unroll
             for (int c = 0; c < 5; ++c)
                 if (w == (c & 3)) {
-                    float* gw_rows = T + (size_t)(PDE_GA + 336 * c + 320) * REGF;
+                    gfp gw_rows = pf_base(T + (size_t)(PDE_GA + 336 * c + 320) * REGF);
 #pragma unroll
                     for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? sd[c][s] : 0.f;
                 }
@@ -252,49 +293,66 @@ __device__ __forceinline__ void pf_role_adjoint(const PdeFuseArgs& a, float4* S,
                     gzv[r] = d1[r] * acc[r];
                 }
             }
-#pragma unroll 1
-            for (int k = 1; k <= 4; ++k) {
-                float zd[16];
-                {
-                    gcfp zp = opaque_u(T + (size_t)(PDE_ZD + 320 * (k - 1) + 4 * 64 + 16 * w) * REGF);
+            // (the rows of the last tangent columns follow once z_4 has been consumed: all 96 at once do not fit the register budget)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) zd[r] = STASH_LD(zp[r * REGF + lane]);
-                }
+            for (int k = PF_P0_FIRST; k < 4; ++k) {
+                gcfp zq = pf_base(T + (size_t)(PDE_ZD + 320 * k + 4 * 64 + 16 * w) * REGF);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zd[k][r] = STASH_LD(zq[r * REGF + lane]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 1; k <= 4; ++k) {
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                {
-                    float s4[4];
+                // one column at a time: an MFMA is a pure register operation that the optimiser forms wherever it likes - all four products
+                // first, 64 registers - unless its operands come out of a statement it cannot move
+                asm volatile("" : "+v"(sd[k][0]), "+v"(sd[k][1]), "+v"(sd[k][2]), "+v"(sd[k][3]) :: "memory");
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) s4[q] = k == 1 ? sd[1][q] : (k == 2 ? sd[2][q] : (k == 3 ? sd[3][q] : sd[4][q]));
+                for (int q = 0; q < 4; ++q) acc = MFMA32(a4[q], sd[k][q], acc);
+                float4* Xw = pf_rows(A, pf_inc(rs, k - 1));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = MFMA32(a4[q], s4[q], acc);
+                for (int q = 0; q < 4; ++q) {
+                    float g4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int r = 4 * q + c;
+                        const float ga = acc[r];
+                        g4[c] = d1[r] * ga;
+                        gzv[r] = gzv[r] + d2[r] * zd[k - 1][r] * ga;
+                    }
+                    Xw[q * 2 * FUSE_HR] = make_float4(g4[0], g4[1], g4[2], g4[3]);
                 }
-                float gz[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float ga = acc[r];
-                    gz[r] = d1[r] * ga;
-                    gzv[r] = gzv[r] + d2[r] * zd[r] * ga;
-                }
-                pf_put(A, pf_inc(rs, k - 1), gz);
+                __builtin_amdgcn_sched_barrier(0);
             }
             pf_put(A, PF_V, gzv);
-            split_load16(a.t4[4] + (size_t)w * 16 * 64, lane, wq);
-            FUSE_BAR();
+            __builtin_amdgcn_sched_barrier(0);              // (the fragment's 64 registers are free only now)
+            split_load16(al.t4[4] + (size_t)w * 16 * 64, lane, wq);
+            PT_ADD(TT, 0);
+            FUSE_BAR(); PT_ADD(TT, 8);
         }
-        pf_layer<3>(A, a, T, wq, rs, d1, d2, gzv);
-        pf_layer<2>(A, a, T, wq, rs, d1, d2, gzv);
-        pf_layer<1>(A, a, T, wq, rs, d1, d2, gzv);
-        pf_layer<0>(A, a, T, wq, rs, d1, d2, gzv);
+        pf_layer<3>(A, al, T, wq, rs, d1, d2, gzv, TT);
+        pf_layer<2>(A, al, T, wq, rs, d1, d2, gzv, TT);
+        pf_layer<1>(A, al, T, wq, rs, d1, d2, gzv, TT);
+        pf_layer<0>(A, al, T, wq, rs, d1, d2, gzv, TT);
+#ifdef PF_TIMING
+        TT.pt[31] += 1;
+#endif
     }
+#ifdef PF_TIMING
+    if (a.timing && blockIdx.x == 0 && w == 0 && lane == 0)
+        for (int k = 0; k < 16; ++k) a.timing[k] = TT.pt[k];
+    if (a.timing && blockIdx.x == 0 && w == 0 && lane == 0) a.timing[31] = TT.pt[31];
+#endif
 }
 
 // ---------------------------------------------------------------- contraction waves
 // (the barrier names the accumulators as in/out operands: see FUSE_BAR_G in vel_fuse.hip)
-#define PF_BAR_G() do { __builtin_amdgcn_sched_barrier(0);                                                            \
+#define PF_BAR_G() do { __builtin_amdgcn_sched_barrier(0); PT_ADD(TT, 16);                                              \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(G0a), "+v"(G0b), "+v"(G1a), "+v"(G1b), "+v"(G2a), "+v"(G2b), "+v"(G3a), "+v"(G3b) :: "memory"); \
-        __builtin_amdgcn_sched_barrier(0); } while (0)
+        PT_ADD(TT, 17); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PF_XBF (FUSE_XB * 4)               // floats per image
 // G[L][t] += sum over the tile's 32 points of g[32 ob + row][s] * a[32 (ib0 + t) + col][s]; BIAS: the value column's gradient also sums into the bias
 #define PF_CONTRACT(L, XIMG, YIMG, BIAS)                                                                             \
@@ -328,6 +386,11 @@ __device__ __forceinline__ void pf_role_contract(const PdeFuseArgs& a, const flo
     const int G = gridDim.x;
     int rs = 0;                                           // tangent image of the next tangent pair
     bool pending = false;                                 // the fourth tangent pair of the previous tile's layer 0 (image rs, Y image 0)
+    PfT TT;
+#ifdef PF_TIMING
+    for (int k = 0; k < 32; ++k) TT.pt[k] = 0;
+    TT.t0 = PT_NOW();
+#endif
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += G) {
         if (pending) { PF_CONTRACT(0, rs, PF_Y0 + 0, 0); rs = pf_inc(rs, 1); }
@@ -343,6 +406,9 @@ __device__ __forceinline__ void pf_role_contract(const PdeFuseArgs& a, const flo
         pending = true;
     }
     if (pending) PF_CONTRACT(0, rs, PF_Y0 + 0, 0);
+#ifdef PF_TIMING
+    if (a.timing && blockIdx.x == 0 && v == 0 && lane == 0) { a.timing[16] = TT.pt[16]; a.timing[17] = TT.pt[17]; }
+#endif
     // one slab per layer and workgroup, in k_wgrad_ring8's format (rows / columns in p-space, bias sums behind the 128 x 128 block)
 #define PF_FLUSH(L)                                                                                                  \
     do {                                                                                                             \
@@ -389,7 +455,23 @@ int launch_pde_fuse_bwd(const PdeFuseArgs& a, int64_t cap_points, int max_slabs,
     }
     int G = ncu < max_slabs ? ncu : max_slabs;
     if ((int64_t)G > tiles) G = (int)tiles;
+#ifdef PF_TIMING
+    static unsigned long long* tbuf = nullptr; static int shots = 0;
+    if (!tbuf) { HIPCK(hipMalloc(&tbuf, 32 * 8)); }
+    PdeFuseArgs b = a; b.timing = tbuf;
+    HIPCK(hipMemsetAsync(tbuf, 0, 32 * 8, st));
+    hipLaunchKernelGGL(k_pde_fuse_bwd, dim3((unsigned)G), dim3(PF_THREADS), PF_LDS_BYTES, st, b);
+    if (++shots % 8 == 0 && shots <= 64) {
+        unsigned long long hh[32];
+        HIPCK(hipStreamSynchronize(st));
+        HIPCK(hipMemcpy(hh, tbuf, sizeof(hh), hipMemcpyDeviceToHost));
+        const double n = hh[31] ? (double)hh[31] : 1.0;
+        fprintf(stderr, "[pde fuse timing] tiles %llu | per tile: P0 %.0f (+wait %.0f) | value dgrad %.0f epi %.0f wait %.0f | tangent dgrad %.0f epi %.0f wait %.0f / %.0f | contraction work %.0f wait %.0f\n",
+                hh[31], hh[0] / n, hh[8] / n, hh[1] / n, hh[2] / n, hh[9] / n, hh[3] / n, hh[4] / n, hh[11] / n, hh[12] / n, hh[16] / n, hh[17] / n);
+    }
+#else
     hipLaunchKernelGGL(k_pde_fuse_bwd, dim3((unsigned)G), dim3(PF_THREADS), PF_LDS_BYTES, st, a);
+#endif
     LAUNCHCK();
     *nslab_out = G;
     return 0;

@@ -242,9 +242,9 @@ def test_engine_rk2_kernels_still_match_goldens():
 
 
 @pytest.mark.parametrize("env", [dict(NVFI_WGRAD="engine"), dict(NVFI_WGRAD_CHAIN="0"), dict(NVFI_BWD_FORK="0"), dict(NVFI_SCATTER="lds"),
-                                 dict(NVFI_APP_FEAT="0"), dict(NVFI_SPLIT_VOUT="0", NVFI_SPLIT_NT="2"), dict(NVFI_SPLIT_UNI_VOUT="1"), dict(NVFI_RK2_FUSE="0")],
+                                 dict(NVFI_APP_FEAT="0"), dict(NVFI_SPLIT_VOUT="0", NVFI_SPLIT_NT="2"), dict(NVFI_SPLIT_UNI_VOUT="1"), dict(NVFI_RK2_FUSE="0"), dict(NVFI_PDE_FUSE="0")],
                          ids=["wgrad_engine", "wgrad_no_chain", "no_bwd_fork", "scatter_lds", "app_gather_in_kernel", "prefilter_output_layer_on_mfma",
-                              "render_warp_output_layer_on_valu", "rk2_adjoint_and_wgrad_unfused"])
+                              "render_warp_output_layer_on_valu", "rk2_adjoint_and_wgrad_unfused", "pde_adjoint_and_wgrad_unfused"])
 def test_round3_switches_keep_the_goldens(env):
     """the alternatives of the round-3 defaults - the register-operand weight-gradient kernel k_wgrad instead of k_wgrad_ring8, un-chained value /
     tangent jobs in the ring kernel, the keyframe backward on one stream instead of the forked density half, the LDS read-add-write tile

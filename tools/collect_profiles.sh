@@ -22,6 +22,7 @@ python $REPO/bench.py --no-extras --workload cfg2 --no-cpu-baseline > $OUT/${TAG
 NVFI_WGRAD=engine python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_wgrad_engine.json 2>/dev/null
 # round 4: the round-3 pair of kernels (k_rk2_split_bwd + k_wgrad_ring8 over the full adjoint stash) instead of vel_fuse.hip, same box; the other BASELINE configs
 NVFI_RK2_FUSE=0 python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_rk2_unfused.json 2>/dev/null
+NVFI_PDE_FUSE=0 python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_pde_unfused.json 2>/dev/null
 NVFI_VEL_FP16_TRAIN=1 python $REPO/bench.py --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_fp16train.json 2>/dev/null
 python $REPO/bench.py --workload chessboard > $OUT/${TAG}_bench_line_chessboard.json 2>/dev/null
 python $REPO/bench.py --workload segm > $OUT/${TAG}_bench_line_segm.json 2>/dev/null
