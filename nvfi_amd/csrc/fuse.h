@@ -65,5 +65,10 @@ struct PdeFuseArgs {
     int64_t layer_stride;      // floats
     int slab_floats;           // 128 * 128 + 128
     unsigned long long* timing; // -DPF_TIMING builds only
+    // second half: the acceleration net's adjoint + its four hidden-layer weight gradients (do_accel)
+    int do_accel;
+    const float4* ta4[6];      // x4 transposed fragments of a_weight_net
+    float* slabs_a;            // same geometry as slabs
+    int* queue;                // device word, zero at launch: next acceleration-net tile
 };
 int launch_pde_fuse_bwd(const PdeFuseArgs& a, int64_t cap_points, int max_slabs, int* nslab_out, hipStream_t st);

@@ -152,4 +152,5 @@ __device__ __forceinline__ void velnet_value_backward(const VelFrags& W, float* 
 }
 
 
-int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st, int fused_nslab = 0, const float* fused_slabs = nullptr);
+int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st, int fused_nslab = 0, const float* fused_slabs = nullptr,
+                     const float* fused_slabs_a = nullptr);

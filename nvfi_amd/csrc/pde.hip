@@ -542,6 +542,7 @@ __global__ void k_pde_pass_count(const int* kcount, int64_t first, int64_t cap, 
         const int64_t c = (int64_t)(*kcount) - first;
         const int n = c <= 0 ? 0 : (c > cap ? (int)cap : (int)c);
         *dcount = (n + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES;
+        dcount[8] = 0;          // k_pde_fuse_bwd's queue of acceleration-net tiles
     }
 }
 // counters[1] = candidates, [3] = prefilter net evaluations (2 per RK2 step, from the step-class histogram), [4] = kept points
@@ -571,7 +572,7 @@ struct PdePlan {
     float* sig;     // density at the warped points (prefilter)
     float4* xw16; uint8_t* near; int* blist; int* bcount; void* img16; void* img16lo;   // fp16 pre-pass (pre16.hip)
     double* sums;
-    float *vel_frag, *a_frag, *vel_x4, *stash, *seeds, *wout, *slabs;
+    float *vel_frag, *a_frag, *vel_x4, *a_x4, *stash, *seeds, *wout, *slabs;
     int64_t chunk, total;
 };
 static void plan_pde(int64_t P, void* ws, PdePlan* L) {
@@ -590,6 +591,7 @@ static void plan_pde(int64_t P, void* ws, PdePlan* L) {
     L->dcount = B.take<int>(16);
     L->vel_frag = B.take<float>(VEL_FRAG_FLOATS); L->a_frag = B.take<float>(VEL_FRAG_FLOATS);
     L->vel_x4 = B.take<float>(VEL_X4_FLOATS);
+    L->a_x4 = B.take<float>(4 * X4_FLOATS(4, 64) + X4_FLOATS(4, 4));      // transposed fragments of a_weight_net (pde_fuse.hip)
     L->chunk = P < PDE_CHUNK ? (P + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES : PDE_CHUNK;
     L->stash = B.take<float>(L->chunk / TILE * (int64_t)PDE_TILE_ROWS * REGF);
     L->seeds = B.take<float>(36 * L->chunk);
@@ -703,6 +705,18 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         add(VW.t[5], 4, 4, &t4[5]);
         if (launch_frag_x4(xj, st)) return 1;
     }
+    const float4* ta4[6] = {nullptr};
+    if (use_jet && pde_fuse && grads) {
+        X4Jobs xj; xj.n = 0;
+        float* p = L.a_x4;
+        for (int l = 1; l <= 5; ++l) {
+            const int NS = l < 5 ? 64 : 4;
+            xj.src[xj.n] = AW.t[l]; xj.dst[xj.n] = p; xj.MT[xj.n] = 4; xj.NS[xj.n] = NS; ++xj.n;
+            ta4[l] = reinterpret_cast<const float4*>(p);
+            p += X4_FLOATS(4, NS);
+        }
+        if (launch_frag_x4(xj, st)) return 1;
+    }
     const unsigned pb = (unsigned)((P + 255) / 256);
     PdePrepArgs pa; pa.f = *f; pa.P = P; pa.points = points; pa.t = t; pa.qorig = L.qorig; pa.xw = L.xw; pa.pt_t = L.pt_t; pa.pt_base = L.pt_base;
     pa.cls = L.cls; pa.rank = L.rank; pa.cls_count = L.cls_count;
@@ -797,19 +811,27 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
                 sb = t_bwd_stream;
                 finished = true;
             }
-            int fused_nslab = 0;
+            int fused_nslab = 0, fused_accel = 0;
             float* fused_slabs = L.slabs + (size_t)14 * PDE_NSLAB * (128 * 128 + 128);      // sets 14..17 (launch_pde_wgrad uses at most 10 beside them)
+            float* fused_slabs_a = L.slabs + (size_t)10 * PDE_NSLAB * (128 * 128 + 128);    // sets 10..13 (at most 6 ring jobs are left then)
+            // (before the adjoint: the fused kernel's queue word is cleared by the same launch)
+            hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, sb, L.kcount, first, cap, L.dcount);
             {
                 ProfScope ps(PK_PDE_BWD, sb);
                 if (use_jet && pde_fuse && grads->vW[1] && grads->vW[2] && grads->vW[3] && grads->vW[4]) {
                     // pde_fuse.hip: the adjoint of weight_net's five columns AND its four hidden-layer weight gradients in one persistent kernel;
                     // the acceleration net's adjoint keeps k_pde_jet_bwd's trailing workgroups (a launch with zero jet tiles)
-                    if (launch_pde_jet_bwd(ja, 0, wgs, sb)) return 1;
                     PdeFuseArgs fa; memset(&fa, 0, sizeof(fa));
-                    for (int l = 0; l < 6; ++l) fa.t4[l] = t4[l];
+                    for (int l = 0; l < 6; ++l) { fa.t4[l] = t4[l]; fa.ta4[l] = ta4[l]; }
                     fa.kcount = L.kcount; fa.first = first; fa.cap = cap; fa.stash = L.stash; fa.seeds = L.seeds;
                     fa.slabs = fused_slabs; fa.layer_stride = (int64_t)PDE_NSLAB * (128 * 128 + 128); fa.slab_floats = 128 * 128 + 128;
+                    // ... and, when all four hidden-layer gradients of a_weight_net are wanted, its adjoint + those gradients as the kernel's second
+                    // half (tiles from a device-side queue); otherwise the acceleration net's adjoint keeps k_pde_jet_bwd's trailing workgroups
+                    fa.do_accel = (grads->aW[1] && grads->aW[2] && grads->aW[3] && grads->aW[4]) ? 1 : 0;
+                    fa.slabs_a = fused_slabs_a; fa.queue = L.dcount + 8;
+                    if (!fa.do_accel && launch_pde_jet_bwd(ja, 0, wgs, sb)) return 1;
                     if (launch_pde_fuse_bwd(fa, cap, PDE_NSLAB, &fused_nslab, sb)) return 1;
+                    fused_accel = fa.do_accel;
                 } else if (use_jet) {
                     if (launch_pde_jet_bwd(ja, (unsigned)(cap / TILE), wgs, sb)) return 1;
                 } else {
@@ -818,8 +840,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
                 }
             }
             LAUNCHCK();
-            hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, sb, L.kcount, first, cap, L.dcount);
-            if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, sb, fused_nslab, fused_slabs)) return 1;
+            if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, sb, fused_nslab, fused_slabs, fused_accel ? fused_slabs_a : nullptr)) return 1;
             if (defer_host) { if (read_host_info()) return 1; }
         }
         LAUNCHCK();
@@ -841,7 +862,9 @@ extern "C" int nvfi_pde_loss(const nvfi_field_desc* f, int64_t P, const float* p
 // weight gradients of both nets from one chunk's stash
 // fused_nslab > 0: the slabs of weight_net's four hidden layers were already written (fused_nslab of them each, value + tangent columns
 // summed) by k_pde_fuse_bwd - only its two edge layers and the acceleration net are contracted here, the reduce covers everything
-int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st, int fused_nslab, const float* fused_slabs) {
+// (fused_slabs_a: likewise for a_weight_net, when the kernel's second half ran)
+int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, const nvfi_grads* G, hipStream_t st, int fused_nslab, const float* fused_slabs,
+                     const float* fused_slabs_a) {
     const size_t ts = (size_t)PDE_TILE_ROWS * REGF;
     const size_t slab = (size_t)PDE_NSLAB * (128 * 128 + 128);
     // k_wgrad reads the sample count from device memory (dcount, set by k_pde_pass_count: no host sync); ntiles is the capacity
@@ -851,10 +874,10 @@ int launch_pde_wgrad(const float* stash, int ntiles, float* slabs, int* dcount, 
             float* gW = net == 0 ? G->vW[l] : G->aW[l];
             float* gb = net == 0 ? G->vb[l] : G->ab[l];
             if (!gW && !gb) continue;
-            if (net == 0 && fused_nslab > 0 && l >= 1 && l <= 4) {
+            if (fused_nslab > 0 && l >= 1 && l <= 4 && (net == 0 || fused_slabs_a)) {
                 ReduceJob& Q = rj.j[rj.n++];
                 memset(&Q, 0, sizeof(Q));
-                Q.slabs = fused_slabs + (size_t)(l - 1) * slab; Q.nslab = fused_nslab; Q.MTA = 4; Q.KTB = 4; Q.gW = gW; Q.gb = gb;
+                Q.slabs = (net == 0 ? fused_slabs : fused_slabs_a) + (size_t)(l - 1) * slab; Q.nslab = fused_nslab; Q.MTA = 4; Q.KTB = 4; Q.gW = gW; Q.gb = gb;
                 Q.out = 128; Q.in = 128; Q.row_kind = RK_NATURAL; Q.slot_kind = SK_HIDDEN; Q.scale = 1.f;
                 continue;
             }

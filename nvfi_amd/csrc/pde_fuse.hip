@@ -20,8 +20,12 @@
 //     read as the dgrad's B operand in phase t+5 and contracted in phase t+6; there are four tangent writes in five phases), one for the
 //     value column's (written with the last tangent column, read in the next two phases), two alternating images of layer inputs: 9 x 16.5 KB;
 //   * at the end every workgroup writes one slab per hidden layer in k_wgrad_ring8's format: k_wgrad_reduce is unchanged.
-// Still through the stash and k_wgrad_ring8: the two edge layers (28 -> 128: gz_0 of the five columns is stored as before; 128 -> 6: the
-// seed rows) and the ReLU acceleration net, whose adjoint stays in k_pde_jet_bwd's trailing workgroups (launched with zero jet tiles).
+//   * SECOND HALF of the launch: the ReLU acceleration net (a_weight_net, value column only).  A workgroup that has run out of weight_net
+//     tiles writes its four slabs, clears the accumulators and takes acceleration-net tiles from a device-side queue: the same roles, five
+//     phases per tile (three rotating gradient images), the four hidden-layer gradients of a_weight_net in the same registers.  A tile costs a
+//     fifth of a weight_net tile, so the queue levels the one-tile imbalance of the first half (1 056 tiles over 256 workgroups are 4.1
+//     rounds: 224 workgroups would idle for the fifth) - and the acceleration net's adjoint no longer needs a launch of its own at half occupancy.
+// Still through the stash and k_wgrad_ring8: the two edge layers of both nets (28 -> 128: gz_0 is stored as before; 128 -> 6: the seed rows).
 //
 // Numerics: every ga / gzd is the number k_pde_jet_bwd forms (same operands, same K order); the value column's gradient adds the four
 // corrections one after the other instead of pairwise, and a weight gradient is summed over points in another order than
@@ -38,7 +42,7 @@
 #define PF_V PF_NT                                    // image of the value column's layer gradient
 #define PF_Y0 (PF_NT + 1)                             // two alternating images of layer inputs
 #define PF_IMAGES (PF_NT + 3)
-#define PF_LDS_BYTES (PF_IMAGES * FUSE_XB * 16)
+#define PF_LDS_BYTES (PF_IMAGES * FUSE_XB * 16 + 64)   // + the two queue words of the acceleration-net half
 #ifndef PF_P0_FIRST
 #define PF_P0_FIRST 4                                 // tangent columns whose layer-4 rows phase 0 requests together with z_4
 #endif
@@ -348,6 +352,134 @@ __device__ __forceinline__ void pf_role_adjoint(const PdeFuseArgs& a, float4* S,
 #endif
 }
 
+// ---- acceleration net (ReLU, value column): one tile = phase 0 (6 -> 128 from the seeds) + one phase per hidden layer
+// gradient images rotate over three of the tangent images (c, c+1, c+2 mod 3; c advances by one per tile), layer inputs alternate as above
+__device__ __forceinline__ int pf_inc3(int s, int by) { s += by; return s >= 3 ? s - 3 : s; }
+
+template <int L>
+__device__ __forceinline__ void pf_accel_phase(const PfA& A, const PdeFuseArgs& al, float* T, f32x4v (&wq)[16], int rimg, int wimg, int yimg) {
+    float zr[16];
+    {
+        gcfp zp = pf_base(T + (size_t)(PDE_ZA + L * 64 + 16 * A.w) * REGF);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zr[r] = STASH_LD(zp[r * REGF + A.lane]);
+    }
+    f32x16 acc;
+    pf_dgrad(A, rimg, wq, acc);
+    if (L >= 1) {
+        asm volatile("" :: "v"(acc[0]));
+        split_load16(al.ta4[L] + (size_t)A.w * 16 * 64, A.lane, wq);
+    }
+    float4* Yw = pf_rows(A, yimg);
+    float4* Xw = pf_rows(A, wimg);
+    gfp gp = pf_base(T + (size_t)(PDE_GAA + 16 * A.w) * REGF);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float g4[4], a4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float z = zr[4 * k + c];
+            g4[c] = (z > 0.f ? 1.f : 0.f) * acc[4 * k + c];         // act_d1<0>(z) * acc, as velnet_value_backward<0> forms it
+            a4[c] = z > 0.f ? z : 0.f;
+        }
+        Yw[k * 2 * FUSE_HR] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+        if (L > 0) Xw[k * 2 * FUSE_HR] = make_float4(g4[0], g4[1], g4[2], g4[3]);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) STASH_ST(gp[(4 * k + c) * REGF + A.lane], g4[c]);
+        }
+    }
+}
+
+// one acceleration-net tile; c = this tile's first gradient image
+__device__ __forceinline__ void pf_accel_tile(const PfA& A, const PdeFuseArgs& a, int tile, int c, f32x4v (&wq)[16]) {
+    const int w = A.w, lane = A.lane, h = lane >> 5, j = lane & 31;
+    float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
+    const int i = tile * TILE + j;
+    const bool ok = i < (int)a.cap;
+    PdeFuseArgs al = a;
+    {
+        gcfp sp_ = pf_base(a.seeds); al.seeds = (const float*)sp_;
+#pragma unroll
+        for (int l = 1; l <= 5; ++l) { gcfp tp_ = pf_base(reinterpret_cast<const float*>(a.ta4[l])); al.ta4[l] = reinterpret_cast<const float4*>((const float*)tp_); }
+    }
+    size_t csl = a.cap; asm volatile("" : "+s"(csl));
+    // ---- phase 0
+    {
+        f32x4v w5;
+        {
+            gcf4p b5 = (gcf4p)(al.ta4[5] + (size_t)w * 64);
+            asm("" : "+s"(b5));
+            w5 = b5[lane];
+        }
+        // seeds of the six outputs (rows 30..35): lanes of half h hold outputs 4h .. 4h+3 in D-layout registers 0..3; the upper half owns only
+        // two - for k = 2, 3 it re-reads the lower half's rows (36, 37 do not exist) and is zeroed
+        float sd[4];
+        {
+            const int ii = ok ? i : 0, lo = ii + (h ? 4 * (int)csl : 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                gcfp sp = pf_base(al.seeds + (size_t)(30 + k) * csl);
+                const float v = sp[k < 2 ? lo : ii];
+                sd[k] = (ok && (k < 2 || h == 0)) ? v : 0.f;
+            }
+        }
+        float zr[16];
+        {
+            gcfp zp = pf_base(T + (size_t)(PDE_ZA + 4 * 64 + 16 * w) * REGF);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zr[r] = STASH_LD(zp[r * REGF + lane]);
+        }
+        if (w == 0) {
+            gfp gw_rows = pf_base(T + (size_t)(PDE_GAA + 320) * REGF);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? sd[s] : 0.f;
+        }
+        const float a4[4] = {w5.x, w5.y, w5.z, w5.w};
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = MFMA32(a4[k], sd[k], acc);
+        float4* Xw = pf_rows(A, c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float g4[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) g4[cc] = (zr[4 * q + cc] > 0.f ? 1.f : 0.f) * acc[4 * q + cc];
+            Xw[q * 2 * FUSE_HR] = make_float4(g4[0], g4[1], g4[2], g4[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        split_load16(al.ta4[4] + (size_t)w * 16 * 64, lane, wq);
+        FUSE_BAR();
+    }
+    pf_accel_phase<3>(A, al, T, wq, c, pf_inc3(c, 1), PF_Y0 + 1); FUSE_BAR();
+    pf_accel_phase<2>(A, al, T, wq, pf_inc3(c, 1), pf_inc3(c, 2), PF_Y0 + 0); FUSE_BAR();
+    pf_accel_phase<1>(A, al, T, wq, pf_inc3(c, 2), c, PF_Y0 + 1); FUSE_BAR();
+    pf_accel_phase<0>(A, al, T, wq, c, c, PF_Y0 + 0); FUSE_BAR();
+}
+
+// the queue of acceleration-net tiles: adjoint wave 0 takes the NEXT tile's index during phase 0 of the current one and parks it in LDS
+// (word n & 1 for the n-th tile of this workgroup); every wave reads it behind the tile's last barrier
+#define PF_QWORD(lds_f, n) ((volatile int*)((lds_f) + PF_IMAGES * FUSE_XB * 4))[(n) & 1]
+
+__device__ __forceinline__ void pf_role_adjoint_accel(const PdeFuseArgs& a, float* lds, int w, int lane, int ntiles) {
+    PfA A; A.S = reinterpret_cast<float4*>(lds); A.w = w; A.lane = lane;
+    A.pos = (lane >> 5) * FUSE_HR + (lane & 31);
+    f32x4v wq[16];
+    if (w == 0 && lane == 0) PF_QWORD(lds, 0) = atomicAdd(a.queue, 1);
+    FUSE_BAR();                                           // the transition barrier: the first index is visible, the contraction waves have flushed weight_net's slabs
+    int c = 0;
+#pragma unroll 1
+    for (int n = 0;; ++n) {
+        const int tile = __builtin_amdgcn_readfirstlane(PF_QWORD(lds, n));
+        if (tile >= ntiles) break;
+        if (w == 0 && lane == 0) PF_QWORD(lds, n + 1) = atomicAdd(a.queue, 1);
+        pf_accel_tile(A, a, tile, c, wq);
+        c = pf_inc3(c, 1);
+    }
+}
+
 // ---------------------------------------------------------------- contraction waves
 // (the barrier names the accumulators as in/out operands: see FUSE_BAR_G in vel_fuse.hip)
 #define PF_BAR_G() do { __builtin_amdgcn_sched_barrier(0); PT_ADD(TT, 16);                                              \
@@ -374,57 +506,86 @@ __device__ __forceinline__ void pf_role_adjoint(const PdeFuseArgs& a, float4* S,
         PF_CONTRACT(L, rs, PF_Y0 + (((TAU0) + 3) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();                            \
     } while (0)
 
-__device__ __forceinline__ void pf_role_contract(const PdeFuseArgs& a, const float* Sf, int v, int lane, int ntiles) {
-    const int i = lane & 31, kk = lane >> 5;
-    const int ob = v >> 1, ib0 = 2 * (v & 1);
-    // float offset of (row i of a 32-row tile, sample kk) in an image
-    const int o = ((i >> 3) * 2 + (i & 1)) * (FUSE_HR * 4) + ((i >> 1) & 3) + 4 * kk;      // MFMA step st contracts sample 2 st + kk: + 8 st floats
-    f32x16 G0a, G0b, G1a, G1b, G2a, G2b, G3a, G3b;
-    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { G0a[r] = 0.f; G0b[r] = 0.f; G1a[r] = 0.f; G1b[r] = 0.f; G2a[r] = 0.f; G2b[r] = 0.f; G3a[r] = 0.f; G3b[r] = 0.f; }
-    const int G = gridDim.x;
-    int rs = 0;                                           // tangent image of the next tangent pair
-    bool pending = false;                                 // the fourth tangent pair of the previous tile's layer 0 (image rs, Y image 0)
-    PfT TT;
-#ifdef PF_TIMING
-    for (int k = 0; k < 32; ++k) TT.pt[k] = 0;
-    TT.t0 = PT_NOW();
-#endif
-#pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += G) {
-        if (pending) { PF_CONTRACT(0, rs, PF_Y0 + 0, 0); rs = pf_inc(rs, 1); }
-        PF_BAR_G();                                       // phase 0 of the adjoint waves
-        PF_BAR_G();                                       // (3, 0)
-        PF_C_LAYER(3, 1);
-        PF_CONTRACT(3, rs, PF_Y0 + ((1 + 4) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();       // (2, 0)
-        PF_C_LAYER(2, 6);
-        PF_CONTRACT(2, rs, PF_Y0 + ((6 + 4) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();       // (1, 0)
-        PF_C_LAYER(1, 11);
-        PF_CONTRACT(1, rs, PF_Y0 + ((11 + 4) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();      // (0, 0)
-        PF_C_LAYER(0, 16);
-        pending = true;
-    }
-    if (pending) PF_CONTRACT(0, rs, PF_Y0 + 0, 0);
-#ifdef PF_TIMING
-    if (a.timing && blockIdx.x == 0 && v == 0 && lane == 0) { a.timing[16] = TT.pt[16]; a.timing[17] = TT.pt[17]; }
-#endif
-    // one slab per layer and workgroup, in k_wgrad_ring8's format (rows / columns in p-space, bias sums behind the 128 x 128 block)
-#define PF_FLUSH(L)                                                                                                  \
+// one slab per layer and workgroup, in k_wgrad_ring8's format (rows / columns in p-space, bias sums behind the 128 x 128 block)
+// (wave-uniform row-group bases + ONE lane offset: with per-lane 64-bit addresses the flush in the middle of the kernel spills hundreds of registers)
+#define PF_FLUSH(SLABS, L)                                                                                           \
     do {                                                                                                             \
-        float* Sl = a.slabs + (size_t)(L) * a.layer_stride + (size_t)blockIdx.x * a.slab_floats;                     \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                             \
-            const int row = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * kk;                                               \
-            Sl[(size_t)row * 128 + 32 * ib0 + i] = G##L##a[r];                                                       \
-            Sl[(size_t)row * 128 + 32 * (ib0 + 1) + i] = G##L##b[r];                                                 \
+        float* Sl = (SLABS) + (size_t)(L) * a.layer_stride + (size_t)blockIdx.x * a.slab_floats;                     \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+            gfp Sq = pf_base(Sl + (size_t)(32 * ob + 8 * q) * 128 + 32 * ib0);                                       \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
+                Sq[c * 128 + flo] = G##L##a[4 * q + c];                                                              \
+                Sq[c * 128 + 32 + flo] = G##L##b[4 * q + c];                                                         \
+            }                                                                                                        \
         }                                                                                                            \
         if ((v & 1) == 0) {                                                                                          \
             float bsum = bs##L; bsum += __shfl_xor(bsum, 32);                                                        \
             if (kk == 0) Sl[(size_t)128 * 128 + 32 * ob + i] = bsum;                                                 \
         }                                                                                                            \
     } while (0)
-    PF_FLUSH(0); PF_FLUSH(1); PF_FLUSH(2); PF_FLUSH(3);
-#undef PF_FLUSH
+
+// ACCEL = false: weight_net's tiles (static share: tile = workgroup + k * grid); true: the acceleration net's (queue).  Two instances run
+// one after the other, each with its own accumulators from zero to its flush (one body that flushed, cleared and went on spilled all 128)
+template <bool ACCEL>
+__device__ __forceinline__ void pf_role_contract(const PdeFuseArgs& a, const float* Sf, int v, int lane, int ntiles) {
+    const int i = lane & 31, kk = lane >> 5;
+    const int ob = v >> 1, ib0 = 2 * (v & 1);
+    // float offset of (row i of a 32-row tile, sample kk) in an image
+    const int o = ((i >> 3) * 2 + (i & 1)) * (FUSE_HR * 4) + ((i >> 1) & 3) + 4 * kk;      // MFMA step st contracts sample 2 st + kk: + 8 st floats
+    const int flo = 4 * kk * 128 + i;                     // lane offset of a slab row: row (r & 3) + 8 (r >> 2) + 4 kk of the wave's 32, column i
+    f32x16 G0a, G0b, G1a, G1b, G2a, G2b, G3a, G3b;
+    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { G0a[r] = 0.f; G0b[r] = 0.f; G1a[r] = 0.f; G1b[r] = 0.f; G2a[r] = 0.f; G2b[r] = 0.f; G3a[r] = 0.f; G3b[r] = 0.f; }
+    PfT TT;
+#ifdef PF_TIMING
+    for (int k = 0; k < 32; ++k) TT.pt[k] = 0;
+    TT.t0 = PT_NOW();
+#endif
+    bool pending = false;
+    if (!ACCEL) {
+        const int G = gridDim.x;
+        int rs = 0;                                       // tangent image of the next tangent pair
+        // pending: the fourth tangent pair of the previous tile's layer 0 (image rs, Y image 0)
+#pragma unroll 1
+        for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+            if (pending) { PF_CONTRACT(0, rs, PF_Y0 + 0, 0); rs = pf_inc(rs, 1); }
+            PF_BAR_G();                                       // phase 0 of the adjoint waves
+            PF_BAR_G();                                       // (3, 0)
+            PF_C_LAYER(3, 1);
+            PF_CONTRACT(3, rs, PF_Y0 + ((1 + 4) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();       // (2, 0)
+            PF_C_LAYER(2, 6);
+            PF_CONTRACT(2, rs, PF_Y0 + ((6 + 4) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();       // (1, 0)
+            PF_C_LAYER(1, 11);
+            PF_CONTRACT(1, rs, PF_Y0 + ((11 + 4) & 1), 0); rs = pf_inc(rs, 1); PF_BAR_G();      // (0, 0)
+            PF_C_LAYER(0, 16);
+            pending = true;
+        }
+        if (pending) PF_CONTRACT(0, rs, PF_Y0 + 0, 0);
+#ifdef PF_TIMING
+        if (a.timing && blockIdx.x == 0 && v == 0 && lane == 0) { a.timing[16] = TT.pt[16]; a.timing[17] = TT.pt[17]; }
+#endif
+        PF_FLUSH(a.slabs, 0); PF_FLUSH(a.slabs, 1); PF_FLUSH(a.slabs, 2); PF_FLUSH(a.slabs, 3);
+    } else {
+        PF_BAR_G();                                       // the transition barrier (weight_net's slabs are on their way, the first queue index is visible)
+        int c = 0;
+#pragma unroll 1
+        for (int n = 0;; ++n) {
+            const int tile = __builtin_amdgcn_readfirstlane(PF_QWORD(Sf, n));
+            if (tile >= ntiles) break;
+            // pairs (gradient image of layer l + 1, layer input of layer l), all with the bias sums; c = this tile's first gradient image
+            if (pending) PF_CONTRACT(0, pf_inc3(c, 2), PF_Y0 + 0, 1);      // the previous tile's last pair: its image c_prev = c - 1
+            PF_BAR_G();                                   // phase 0
+            PF_BAR_G();                                   // layer 3
+            PF_CONTRACT(3, c, PF_Y0 + 1, 1); PF_BAR_G();                    // layer 2
+            PF_CONTRACT(2, pf_inc3(c, 1), PF_Y0 + 0, 1); PF_BAR_G();        // layer 1
+            PF_CONTRACT(1, pf_inc3(c, 2), PF_Y0 + 1, 1); PF_BAR_G();        // layer 0
+            pending = true;
+            c = pf_inc3(c, 1);
+        }
+        if (pending) PF_CONTRACT(0, pf_inc3(c, 2), PF_Y0 + 0, 1);
+        PF_FLUSH(a.slabs_a, 0); PF_FLUSH(a.slabs_a, 1); PF_FLUSH(a.slabs_a, 2); PF_FLUSH(a.slabs_a, 3);
+    }
 }
 
 __global__ __launch_bounds__(PF_THREADS) void k_pde_fuse_bwd(PdeFuseArgs a) {
@@ -437,8 +598,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_pde_fuse_bwd(PdeFuseArgs a) {
     if (wave < 4) {
         __builtin_amdgcn_s_setprio(3);
         pf_role_adjoint(a, reinterpret_cast<float4*>(lds), wave, lane, ntiles);
+        if (a.do_accel) pf_role_adjoint_accel(a, lds, wave, lane, ntiles);
     } else {
-        pf_role_contract(a, lds, wave - 4, lane, ntiles);
+        pf_role_contract<false>(a, lds, wave - 4, lane, ntiles);
+        if (a.do_accel) pf_role_contract<true>(a, lds, wave - 4, lane, ntiles);
     }
 }
 
