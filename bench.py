@@ -648,6 +648,13 @@ class DropinStep:
 
     def __call__(self):
         nvfi, f = self.m, self.m.nvfi
+        # NVFI_DROPIN_TIMING=1: host timestamps of the iteration's stations (tools/hostprof.py dropin prints their means)
+        tm = self.__dict__.setdefault("_tm", [] if os.environ.get("NVFI_DROPIN_TIMING") == "1" else None)
+        mark = (lambda: row.append(time.perf_counter())) if tm is not None else (lambda: None)
+        row = []
+        if tm is not None:
+            tm.append(row)
+        mark()
         nvfi.train(); self.ren.train()
         loss = 0
         if self.workload == "cfg3":
@@ -658,7 +665,9 @@ class DropinStep:
             rgb_map = self.ren.render(i / 60.0, rays, white_background=True, mode="train")[0]
             rgb_loss = torch.nn.functional.mse_loss(rgb_map[..., :3], target[..., :3])
             loss = rgb_loss
+            mark()
             rgb_loss_t = rgb_loss.item()                                 # train_nvfi.py:161
+            mark()
             self.counters.append(f.last_counters)
             t_key = 3 * int(self.rng.integers(0, 16)) / 60.0
         else:
@@ -674,24 +683,30 @@ class DropinStep:
         loss = loss + f.TV_loss_density(self.tvreg) * self.tvd
         self.tva *= self.lr_factor
         loss = loss + f.TV_loss_app(self.tvreg) * self.tva
+        mark()
         if self.workload == "cfg3":
             self.vw *= self.lr_factor
             loss_vel = nvfi.get_vel_loss(self.n_pts)
+            mark()
             self.pde_counters.append(f.last_pde_counters)
             if loss_vel > 0:                                             # train_nvfi.py:233 (a device sync on a tensor)
                 loss = loss + self.vw * loss_vel
+        mark()
         self.opt.zero_grad(set_to_none=True)
         if not self.live:
             for p, s in self.pairs:
                 p.grad = None
         loss.backward()
+        mark()
         if not self.live:
             for p, s in self.pairs:
                 s.grad = p.grad
         self.opt.step()
         for g in self.opt.param_groups:
             g["lr"] = g["lr"] * self.lr_factor
+        mark()
         self.last_psnr = rgb_loss0.item()                                # train_nvfi.py:252
+        mark()
         return loss
 
 

@@ -768,10 +768,13 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     // adjoint half on the other one: the host's wait then covers the prefilter AND the forward (the caller's own wait for the value, `if loss_vel > 0`,
     // returns at once) and the device does not idle between the prefilter and the jets while the host wakes up (30-140 us per iteration in a trace).
     const bool defer_host = host_info && t_bwd_stream && P <= L.chunk && grads;
+    int hcnt_early[PDE_MAX_CLASS + 16];
+    bool early_copy = false;
     auto read_host_info = [&]() -> int {
         int hcnt[PDE_MAX_CLASS + 16];
-        HIPCK(hipMemcpyAsync(hcnt, L.cls_count, sizeof(hcnt), hipMemcpyDeviceToHost, st));
+        if (!early_copy) HIPCK(hipMemcpyAsync(hcnt, L.cls_count, sizeof(hcnt), hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
+        if (early_copy) memcpy(hcnt, hcnt_early, sizeof(hcnt));
         int64_t evals = 0;
         for (int c = 0; c < PDE_MAX_CLASS; ++c) evals += 2ll * c * hcnt[c];
         host_info[0] = hcnt[PDE_MAX_CLASS]; host_info[1] = evals;
@@ -806,6 +809,10 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
             hipStream_t sb = st;
             if (t_bwd_stream && P <= L.chunk) {      // split call: the value is finished on st first, the adjoint half follows on the other stream
                 hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, L.kcount, out);
+                // the host's copy of the counts is queued IN FRONT of the adjoint half: k_pde_fuse_bwd owns every CU for ~0.4 ms (12 waves x 168
+                // registers, 152 KB of LDS per workgroup) and a copy kernel queued behind its start waits for its first workgroup to retire - the
+                // caller's `if loss_vel > 0` then returned 0.43 ms late (trace of the drop-in loop)
+                if (defer_host) { HIPCK(hipMemcpyAsync(hcnt_early, L.cls_count, sizeof(hcnt_early), hipMemcpyDeviceToHost, st)); early_copy = true; }
                 HIPCK(hipEventRecord(t_split_ev, st));
                 HIPCK(hipStreamWaitEvent(t_bwd_stream, t_split_ev, 0));
                 sb = t_bwd_stream;
@@ -830,7 +837,11 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
                     fa.do_accel = (grads->aW[1] && grads->aW[2] && grads->aW[3] && grads->aW[4]) ? 1 : 0;
                     fa.slabs_a = fused_slabs_a; fa.queue = L.dcount + 8;
                     if (!fa.do_accel && launch_pde_jet_bwd(ja, 0, wgs, sb)) return 1;
-                    if (launch_pde_fuse_bwd(fa, cap, PDE_NSLAB, &fused_nslab, sb)) return 1;
+                    // a split call (the reference's loop: the caller waits for the value - `if loss_vel > 0` - while this half runs on the other
+                    // stream) leaves 8 CUs to the caller's comparison / copy kernels: a persistent workgroup owns its CU, and behind 256 of them
+                    // that wait was 0.35 ms
+                    const int max_wgs = sb != st ? PDE_NSLAB - 8 : PDE_NSLAB;
+                    if (launch_pde_fuse_bwd(fa, cap, max_wgs, &fused_nslab, sb)) return 1;
                     fused_accel = fa.do_accel;
                 } else if (use_jet) {
                     if (launch_pde_jet_bwd(ja, (unsigned)(cap / TILE), wgs, sb)) return 1;

@@ -18,6 +18,13 @@ t0 = time.perf_counter()
 for _ in range(20): step()
 torch.cuda.synchronize()
 print(mode, workload, "ms/step (no profiler)", (time.perf_counter() - t0) * 50)
+if mode == "dropin" and getattr(step, "_tm", None):
+    import numpy as np
+    rows = np.array([r for r in step._tm[-20:] if len(r) == len(step._tm[-1])])
+    names = ["render1 issued", "sync1 (.item)", "render2 + regularisers issued", "get_vel_loss returned (sync2)", "loss arithmetic", "backward() returned",
+             "optimizer.step() returned", "sync3 (.item)"]
+    d = np.diff(rows, axis=1).mean(0) * 1e3
+    print("host stations (ms, mean of 20): " + " | ".join(f"{n} {v:.3f}" for n, v in zip(names, d)) + f" | between iterations {np.diff(rows[:, 0]).mean() * 1e3 - d.sum():.3f}")
 # host issue time alone: how long does the host need to queue a step when it never waits for the device?
 if mode != "dropin":
     t0 = time.perf_counter()
