@@ -616,7 +616,10 @@ int launch_pde_fuse_bwd(const PdeFuseArgs& a, int64_t cap_points, int max_slabs,
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         HIPCK(hipFuncSetAttribute((const void*)k_pde_fuse_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS_BYTES));
     }
-    int G = ncu < max_slabs ? ncu : max_slabs;
+    static int reserve = -1;                              // NVFI_FUSE_RESERVE=n (experiment): see launch_rk2_fuse_bwd
+    if (reserve < 0) { const char* e = getenv("NVFI_FUSE_RESERVE"); reserve = e ? atoi(e) : 0; }
+    int G = ncu - reserve < max_slabs ? ncu - reserve : max_slabs;
+    if (G < 1) G = 1;
     if ((int64_t)G > tiles) G = (int)tiles;
 #ifdef PF_TIMING
     static unsigned long long* tbuf = nullptr; static int shots = 0;

@@ -501,7 +501,11 @@ int launch_rk2_fuse_bwd(const FuseBwdArgs& a, int64_t cap_samples, int max_slabs
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         HIPCK(hipFuncSetAttribute((const void*)k_rk2_fuse_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES));
     }
-    int G = ncu < max_slabs ? ncu : max_slabs;
+    // NVFI_FUSE_RESERVE=n (experiment): leave n CUs to the kernels of the other streams (a persistent workgroup owns its CU: 12 waves x 168 registers)
+    static int reserve = -1;
+    if (reserve < 0) { const char* e = getenv("NVFI_FUSE_RESERVE"); reserve = e ? atoi(e) : 0; }
+    int G = ncu - reserve < max_slabs ? ncu - reserve : max_slabs;
+    if (G < 1) G = 1;
     if ((int64_t)G > tiles) G = (int)tiles;
     ProfScope ps(PK_RK2_BWD, st);
 #ifdef FUSE_TIMING
