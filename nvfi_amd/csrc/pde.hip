@@ -835,7 +835,10 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
                     // ... and, when all four hidden-layer gradients of a_weight_net are wanted, its adjoint + those gradients as the kernel's second
                     // half (tiles from a device-side queue); otherwise the acceleration net's adjoint keeps k_pde_jet_bwd's trailing workgroups
                     fa.do_accel = (grads->aW[1] && grads->aW[2] && grads->aW[3] && grads->aW[4]) ? 1 : 0;
-                    fa.slabs_a = fused_slabs_a; fa.queue = L.dcount + 8;
+                    fa.slabs_a = fused_slabs_a;
+                    static int det = -1;
+                    if (det < 0) { const char* e = getenv("NVFI_DETERMINISTIC"); det = (e && atoi(e) != 0) ? 1 : 0; }
+                    fa.queue = det ? nullptr : L.dcount + 8;
                     if (!fa.do_accel && launch_pde_jet_bwd(ja, 0, wgs, sb)) return 1;
                     // a split call (the reference's loop: the caller waits for the value - `if loss_vel > 0` - while this half runs on the other
                     // stream) leaves 8 CUs to the caller's comparison / copy kernels: a persistent workgroup owns its CU, and behind 256 of them

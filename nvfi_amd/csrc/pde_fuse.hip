@@ -467,14 +467,16 @@ __device__ __forceinline__ void pf_role_adjoint_accel(const PdeFuseArgs& a, floa
     PfA A; A.S = reinterpret_cast<float4*>(lds); A.w = w; A.lane = lane;
     A.pos = (lane >> 5) * FUSE_HR + (lane & 31);
     f32x4v wq[16];
-    if (w == 0 && lane == 0) PF_QWORD(lds, 0) = atomicAdd(a.queue, 1);
+    // (no queue - NVFI_DETERMINISTIC=1 -: the static share of the first half, so that every slab sums the same tiles in the same order in every run)
+    const int G = gridDim.x;
+    if (w == 0 && lane == 0) PF_QWORD(lds, 0) = a.queue ? atomicAdd(a.queue, 1) : (int)blockIdx.x;
     FUSE_BAR();                                           // the transition barrier: the first index is visible, the contraction waves have flushed weight_net's slabs
     int c = 0;
 #pragma unroll 1
     for (int n = 0;; ++n) {
         const int tile = __builtin_amdgcn_readfirstlane(PF_QWORD(lds, n));
         if (tile >= ntiles) break;
-        if (w == 0 && lane == 0) PF_QWORD(lds, n + 1) = atomicAdd(a.queue, 1);
+        if (w == 0 && lane == 0) PF_QWORD(lds, n + 1) = a.queue ? atomicAdd(a.queue, 1) : (int)blockIdx.x + (n + 1) * G;
         pf_accel_tile(A, a, tile, c, wq);
         c = pf_inc3(c, 1);
     }
