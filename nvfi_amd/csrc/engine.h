@@ -247,6 +247,23 @@ __device__ __forceinline__ void layer_tiles(const float* lds_w, const float* lds
 }
 
 // store / load a block of NR stash registers (one 256-B row per register)
+// x4 stash blocks: rows 4k .. 4k+3 of a 16-row group as ONE 16-byte access per lane - element (row R, lane L) at (R >> 2) * 256 + 4 L + (R & 3)
+// instead of R * 64 + L, i.e. a permutation inside the 1 KiB the four row-major rows occupy: a quarter of the VMEM instructions of a stash
+// writer / reader.  Only for rows whose EVERY reader knows the layout (the hidden layers' pre-activations once the fused adjoint kernels are
+// their only consumers: the ring kernel's DMA wants row-major rows).
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stash_st16_x4(float* base16, int lane, const f32x16& v) {
+    f32x4s* p = reinterpret_cast<f32x4s*>(base16) + lane;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x4s q = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+#ifdef NVFI_STASH_TEMPORAL
+        p[k * 64] = q;
+#else
+        __builtin_nontemporal_store(q, p + k * 64);
+#endif
+    }
+}
 template <int NR>
 __device__ __forceinline__ void stash_store(float* base, int lane, const float* v) {
 #pragma unroll

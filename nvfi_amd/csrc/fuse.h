@@ -69,6 +69,7 @@ struct PdeFuseArgs {
     int do_accel;
     const float4* ta4[6];      // x4 transposed fragments of a_weight_net
     float* slabs_a;            // same geometry as slabs
+    int x4;                    // the forward wrote layers 0..3 of z / zd_j as x4 stash blocks (PdeJetArgs::x4)
     int* queue;                // device word, zero at launch: next acceleration-net tile (NULL: static share, tile = workgroup + k * grid)
 };
 int launch_pde_fuse_bwd(const PdeFuseArgs& a, int64_t cap_points, int max_slabs, int* nslab_out, hipStream_t st);

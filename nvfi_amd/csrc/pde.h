@@ -44,6 +44,7 @@ struct PdeJetArgs {
     float* stash; float* seeds; float* wout; double* sums;
     float scale; const float* scale_dev;   // loss scale by value, or (non-NULL) read from device memory (hipGraph replay: a weight that decays every iteration)
     float* jac; int64_t n_jac;
+    int x4;                    // k_pde_jet_fwd: layers 0..3 of z / zd_j in x4 stash blocks (engine.h: stash_st16_x4) - their only reader is then k_pde_fuse_bwd
 };
 
 // kept points of this pass: the launch grids are sized for the worst case (every candidate kept) and workgroups beyond the

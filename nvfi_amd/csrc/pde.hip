@@ -793,6 +793,11 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         ja.wout = L.wout;
         ja.only_col = -1;
         for (int l = 0; l < 6; ++l) { ja.f4[l] = f4[l]; ja.t4[l] = t4[l]; ja.bv[l] = VW.b[l]; }
+        // the fused adjoint is the only reader of the hidden layers' pre-activations: they travel as x4 stash blocks (NVFI_PDE_X4=0: row-major)
+        static int want_x4 = -1;
+        if (want_x4 < 0) { const char* e = getenv("NVFI_PDE_X4"); want_x4 = e ? atoi(e) : 1; }
+        const bool fuse_ok = use_jet && pde_fuse && grads && grads->vW[1] && grads->vW[2] && grads->vW[3] && grads->vW[4];
+        ja.x4 = (fuse_ok && want_x4) ? 1 : 0;
         {
             ProfScope ps(PK_PDE_FWD, st);
             if (use_jet) {
@@ -825,12 +830,12 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
             hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, sb, L.kcount, first, cap, L.dcount);
             {
                 ProfScope ps(PK_PDE_BWD, sb);
-                if (use_jet && pde_fuse && grads->vW[1] && grads->vW[2] && grads->vW[3] && grads->vW[4]) {
+                if (fuse_ok) {
                     // pde_fuse.hip: the adjoint of weight_net's five columns AND its four hidden-layer weight gradients in one persistent kernel;
                     // the acceleration net's adjoint keeps k_pde_jet_bwd's trailing workgroups (a launch with zero jet tiles)
                     PdeFuseArgs fa; memset(&fa, 0, sizeof(fa));
                     for (int l = 0; l < 6; ++l) { fa.t4[l] = t4[l]; fa.ta4[l] = ta4[l]; }
-                    fa.kcount = L.kcount; fa.first = first; fa.cap = cap; fa.stash = L.stash; fa.seeds = L.seeds;
+                    fa.kcount = L.kcount; fa.first = first; fa.cap = cap; fa.stash = L.stash; fa.seeds = L.seeds; fa.x4 = ja.x4;
                     fa.slabs = fused_slabs; fa.layer_stride = (int64_t)PDE_NSLAB * (128 * 128 + 128); fa.slab_floats = 128 * 128 + 128;
                     // ... and, when all four hidden-layer gradients of a_weight_net are wanted, its adjoint + those gradients as the kernel's second
                     // half (tiles from a device-side queue); otherwise the acceleration net's adjoint keeps k_pde_jet_bwd's trailing workgroups

@@ -75,7 +75,25 @@ __device__ __forceinline__ int pf_inc(int s, int by) { s += by; return s >= PF_N
 struct PfA {
     float4* S;           // the nine images
     int w, lane, pos;    // pos: float4 index of this lane inside a row group (h * 33 + sample)
+    bool x4;             // the forward's hidden-layer rows are x4 stash blocks
 };
+
+// sixteen stash rows of this wave: row-major (one dword per row and lane) or - the hidden layers the forward wrote as x4 blocks
+// (engine.h: stash_st16_x4; PdeFuseArgs::x4) - four 16-byte accesses
+__device__ __forceinline__ void pf_rows16(const float* base16, int lane, bool x4, float (&v)[16]) {
+    if (x4) {
+        const __attribute__((address_space(1))) f32x4s* q = (const __attribute__((address_space(1))) f32x4s*)pf_base(base16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4s t = __builtin_nontemporal_load(q + k * 64 + lane);
+            v[4 * k] = t[0]; v[4 * k + 1] = t[1]; v[4 * k + 2] = t[2]; v[4 * k + 3] = t[3];
+        }
+    } else {
+        gcfp zp = pf_base(base16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = STASH_LD(zp[r * REGF + lane]);
+    }
+}
 
 // dgrad of one column: acc = T^T fragment (registers) x layer gradient image (LDS)
 __device__ __forceinline__ void pf_dgrad(const PfA& A, int img, const f32x4v (&wq)[16], f32x16& acc) {
@@ -107,11 +125,7 @@ template <int L>
 __device__ __forceinline__ void pf_value_phase(const PfA& A, const float* T, const f32x4v (&wq)[16], int yimg,
                                                float (&d1)[16], float (&d2)[16], float (&gzv)[16], PfT& TT) {
     float zr[16];
-    {
-        gcfp zp = pf_base(T + (size_t)(PDE_Z + L * 64 + 16 * A.w) * REGF);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zr[r] = STASH_LD(zp[r * REGF + A.lane]);
-    }
+    pf_rows16(T + (size_t)(PDE_Z + L * 64 + 16 * A.w) * REGF, A.lane, A.x4, zr);
     f32x16 acc;
     pf_dgrad(A, PF_V, wq, acc);
     PT_MFMA_DONE(acc); PT_ADD(TT, 1);
@@ -140,11 +154,7 @@ template <int L, bool LAST>
 __device__ __forceinline__ void pf_tangent_phase(const PfA& A, const PdeFuseArgs& a, float* T, f32x4v (&wq)[16], int J, int rimg, int wimg, int yimg,
                                                  const float (&d1)[16], const float (&d2)[16], float (&gzv)[16], PfT& TT) {
     float zd[16];
-    {
-        gcfp zp = pf_base(T + (size_t)(PDE_ZD + 320 * (J - 1) + L * 64 + 16 * A.w) * REGF);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zd[r] = STASH_LD(zp[r * REGF + A.lane]);
-    }
+    pf_rows16(T + (size_t)(PDE_ZD + 320 * (J - 1) + L * 64 + 16 * A.w) * REGF, A.lane, A.x4, zd);
     f32x16 acc;
     pf_dgrad(A, rimg, wq, acc);
     PT_MFMA_DONE(acc); PT_ADD(TT, 3);
@@ -203,7 +213,7 @@ __device__ __forceinline__ void pf_layer(const PfA& A, const PdeFuseArgs& a, flo
 }
 
 __device__ __forceinline__ void pf_role_adjoint(const PdeFuseArgs& a, float4* S, int w, int lane, int ntiles) {
-    PfA A; A.S = S; A.w = w; A.lane = lane;
+    PfA A; A.S = S; A.w = w; A.lane = lane; A.x4 = a.x4 != 0;
     const int h = lane >> 5, j = lane & 31;
     A.pos = h * FUSE_HR + j;
     const int G = gridDim.x;
@@ -464,7 +474,7 @@ __device__ __forceinline__ void pf_accel_tile(const PfA& A, const PdeFuseArgs& a
 #define PF_QWORD(lds_f, n) ((volatile int*)((lds_f) + PF_IMAGES * FUSE_XB * 4))[(n) & 1]
 
 __device__ __forceinline__ void pf_role_adjoint_accel(const PdeFuseArgs& a, float* lds, int w, int lane, int ntiles) {
-    PfA A; A.S = reinterpret_cast<float4*>(lds); A.w = w; A.lane = lane;
+    PfA A; A.S = reinterpret_cast<float4*>(lds); A.w = w; A.lane = lane; A.x4 = false;
     A.pos = (lane >> 5) * FUSE_HR + (lane & 31);
     f32x4v wq[16];
     // (no queue - NVFI_DETERMINISTIC=1 -: the static share of the first half, so that every slab sums the same tiles in the same order in every run)

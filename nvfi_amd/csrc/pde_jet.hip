@@ -188,17 +188,23 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_pde_jet_fwd(PdeJetArgs a) {
     for (int l = 0; l < 5; ++l) {
         // epilogue of layer l on this wave's 16 rows: stash z / zd_j, activation and its derivative (once for the five columns)
         const int row0 = l * 64 + 16 * w;
+        const bool x4 = a.x4 && l < 4;            // (layer 4 stays row-major: the output layer's weight gradient reads it through the ring kernel)
+        if (x4) {
+            stash_st16_x4(T + (size_t)(PDE_Z + row0) * REGF, lane, acc[0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) stash_st16_x4(T + (size_t)(PDE_ZD + 320 * j + row0) * REGF, lane, acc[1 + j]);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float z = acc[0][r];
-            STASH_ST(T[(size_t)(PDE_Z + row0 + r) * REGF + lane], z);
+            if (!x4) STASH_ST(T[(size_t)(PDE_Z + row0 + r) * REGF + lane], z);
             const float s = fast_sigmoid(z);
             const float d1 = s * (1.f + z * (1.f - s));
             acc[0][r] = z * s;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float zd = acc[1 + j][r];
-                STASH_ST(T[(size_t)(PDE_ZD + 320 * j + row0 + r) * REGF + lane], zd);
+                if (!x4) STASH_ST(T[(size_t)(PDE_ZD + 320 * j + row0 + r) * REGF + lane], zd);
                 acc[1 + j][r] = d1 * zd;
             }
         }
