@@ -275,3 +275,39 @@ def test_fused_mse_matches_torch(shape):
     assert torch.allclose(mse_loss(x, y).detach(), torch.nn.functional.mse_loss(x2, y).detach(), rtol=2e-6, atol=0)
     assert torch.allclose(x.grad, x2.grad, rtol=1e-6, atol=1e-9)
     assert mse_loss(x.detach().cpu(), y.cpu()).item() == torch.nn.functional.mse_loss(x.detach().cpu(), y.cpu()).item()      # CPU tensors: torch
+
+
+@pytest.mark.parametrize("P", [33, 1000, 262144 + 4133], ids=["one_tile", "fewer_tiles_than_cus", "two_chunks"])
+def test_pde_gradients_add_up_over_ragged_point_sets(P):
+    """The PDE term is a mean over the kept points, so n_kept * (value, gradient) of a point set equals the sum over any partition of it.  Checked for
+    the shapes the persistent adjoint kernel (pde_fuse.hip) treats specially: a single 32-point tile, fewer tiles than workgroups, and more than one
+    262 144-point chunk (the second pass reuses stash, slabs and the tile queue) - each against its two ragged halves."""
+    model, meta = make_model("A")
+    f = model.nvfi
+    f.requires_grad_(True)
+    g = torch.Generator(device="cuda").manual_seed(P)
+    mn, mx = f.aabb
+    pts = torch.rand(P, 3, device="cuda", generator=g) * (mx - mn) * 0.6 + (mn + 0.2 * (mx - mn))      # around the occupied part of field A
+    tt = torch.rand(P, 1, device="cuda", generator=g)
+    cut = P // 2 - 7
+
+    def term(sl):
+        model.zero_grad(set_to_none=True)
+        lv = model.get_vel_loss(points=pts[sl], t=tt[sl])
+        n = int(f.last_pde_n_kept)
+        if n == 0:
+            return 0, None
+        lv.backward()
+        gr = torch.cat([p.grad.reshape(-1).double() for p in f._pde_params()])
+        return n, (float(lv.detach()) * n, gr * n)
+
+    n_all, full = term(slice(0, P))
+    n_a, a = term(slice(0, cut))
+    n_b, b = term(slice(cut, P))
+    assert n_all == n_a + n_b and n_all > (2 if P < 100 else 50), (n_all, n_a, n_b)
+    parts = [x for x in (a, b) if x is not None]
+    val = sum(x[0] for x in parts)
+    grad = sum(x[1] for x in parts)
+    np.testing.assert_allclose(full[0], val, rtol=2e-5)
+    err = (full[1] - grad).abs().max().item()
+    assert err <= 2e-5 * full[1].abs().max().item(), (err, full[1].abs().max().item())
