@@ -267,7 +267,10 @@ int launch_pack(const PackJobs& jobs, hipStream_t st) {
     return 0;
 }
 int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st) {
-    if (wj.n == 0) return 0;
+    if (wj.n == 0) {          // every slab set was written by a fused adjoint kernel: only the reduce is left
+        if (rj.n) { ProfScope ps(PK_WGRAD, st); hipLaunchKernelGGL(k_wgrad_reduce, dim3(REDUCE_BLOCKS, rj.n), dim3(256), 0, st, rj); LAUNCHCK(); }
+        return 0;
+    }
     // Each job's nslab is the capacity of its slab buffer.
     // NVFI_WGRAD_WAVES caps the number of workers and shares them between the jobs in proportion to their work; unset, every
     // job gets as many slabs as its buffer holds (measured best: many short workers balance the ragged job mix).
