@@ -71,17 +71,6 @@ struct AppArgs {
     int plane_tail;      // 1: coordinate gradients of the plane lookups (+ in-kernel scatter when gg is NULL) are computed here; 0: k_og does it (or nobody needs them)
 };
 
-// app_fuse.hip: adjoint of the render MLP + its two 128-wide weight gradients in one persistent kernel
-#define APP_X4_FLOATS (4 * 1 * 256 + 2 * 4 * 16 * 256 + 2 * 4 * 256)      // x4 copies of T3 (4 x 4), T2, T1 (4 x 64), Tb (2 x 16)
-struct AppFuseArgs {
-    AppArgs a;
-    const float4* t3; const float4* t2; const float4* t1; const float4* tb;
-    float* slabs_1; float* slabs_0;      // slab of workgroup g at + g * slab_floats: layer 1 (128 x 128, gz2 x h1), layer 0 (128 x slots, gz1 x x_in)
-    int slab_floats;
-};
-int pack_app_x4(const RenderFrags& W, float* buf, AppFuseArgs* F, hipStream_t st);
-int launch_app_fuse_bwd(const AppFuseArgs& F, int64_t cap_samples, int max_slabs, int* nslab_out, hipStream_t st);
-
 struct ScatterArgs {
     nvfi_field_desc f;
     const int* count; const int* list;

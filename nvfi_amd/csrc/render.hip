@@ -1109,7 +1109,6 @@ struct RenderPlan {
     TileWork tw2; float* slabs2;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     unsigned* app_relu;
-    float* app_x4;             // x4 copies of the transposed render-MLP fragments (app_fuse.hip)
     float *slabs;
     long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
     int64_t zero_bytes;        // counters .. end of the sort histograms: zeroed by the forward's single fill
@@ -1153,7 +1152,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->render_frag = B.take<float>(RENDER_FRAG_FLOATS);
     P->maskv = (flags & NVFI_WANT_MASK) ? B.take<float>(N * 32) : nullptr;
     P->mask_frag = (flags & NVFI_WANT_MASK) ? B.take<float>(64 * 1024) : nullptr;
-    P->app_relu = nullptr; P->app_x4 = nullptr;
+    P->app_relu = nullptr;
     P->app_f = P->app_b = P->zst = P->x0st = P->rec = P->gst = P->slabs = nullptr;
     P->gxw = P->gxk = nullptr; P->gxpre = nullptr; P->gg = nullptr;
     if (train) {
@@ -1162,7 +1161,6 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
         P->app_f = B.take<float>(P->cap_tiles * (int64_t)(APP_F_ROWS * REGF));
         P->app_b = B.take<float>(P->cap_tiles * (int64_t)(APP_B_ROWS * REGF));
         P->app_relu = B.take<unsigned>(P->cap_tiles * (int64_t)256);
-        P->app_x4 = B.take<float>(APP_X4_FLOATS);
         P->slabs = B.take<float>((int64_t)NSLAB_MAX * SLAB_FLOATS * 6);
         P->shadow = nullptr;
         if (det_mode()) { int64_t off[12]; P->shadow = B.take<long long>(plane_elems(f, off)); }
@@ -1387,20 +1385,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     aa.g_rgb = g_rgb; aa.rgb_pre = P.rgb_pre; aa.weight = weights; aa.gxw = P.gxw; aa.gg = P.gg;
     aa.plane_tail = P.tiles ? 0 : 1;
     const unsigned app_wgs = (unsigned)((N + WG_SAMPLES - 1) / WG_SAMPLES);
-    // NVFI_APP_FUSE (default 1): app_fuse.hip - the render MLP's adjoint AND its two 128-wide weight gradients in one persistent kernel (no gz2 / gz1
-    // stash, no second pass over h1 / x_in); 0, SH shading, no sorted-tile scatter or NVFI_DETERMINISTIC: k_app_bwd + the full k_wgrad_ring8 launch
-    static int app_fuse = -1;
-    if (app_fuse < 0) { const char* e = getenv("NVFI_APP_FUSE"); app_fuse = e ? atoi(e) : 1; }
-    int app_nslab = 0;
-    const bool fuse_app = app_fuse && P.tiles && f->shading == 0 && grads->rW[0] && grads->rW[1] && !det_mode() && P.app_x4;
-    if (fuse_app) {
-        ProfScope ps(PK_APP_BWD, st);
-        AppFuseArgs F; memset(&F, 0, sizeof(F));
-        F.a = aa;
-        if (pack_app_x4(RW, P.app_x4, &F, st)) return 1;
-        F.slabs_1 = P.slabs + 1 * (size_t)NSLAB_MAX * SLAB_FLOATS; F.slabs_0 = P.slabs + 2 * (size_t)NSLAB_MAX * SLAB_FLOATS; F.slab_floats = SLAB_FLOATS;
-        if (launch_app_fuse_bwd(F, N, NSLAB, &app_nslab, st)) return 1;
-    } else { ProfScope ps(PK_APP_BWD, st); hipLaunchKernelGGL(k_app_bwd, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa); }
+    { ProfScope ps(PK_APP_BWD, st); hipLaunchKernelGGL(k_app_bwd, dim3(app_wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, aa); }
     const bool want_aplanes = grads->aps[0] || grads->apt[0];
     if (P.tiles) {
         if (want_aplanes || nsteps > 0) {
@@ -1442,19 +1427,8 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         };
         float* sl = P.slabs;
         if (grads->rW[2] || grads->rb[2]) add(P.app_b + 0, 16, P.app_f + 160 * REGF, 64, sl + 0 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->rW[2], grads->rb[2], 3, 128, SK_HIDDEN);
-        if (app_nslab > 0) {       // the slabs of the two 128-wide layers were written by k_app_fuse_bwd (app_nslab of them each): only the reduce is left
-            auto fused = [&](int k, float* gW, float* gb, int in, int sk) {
-                ReduceJob& Q = rj.j[rj.n++];
-                memset(&Q, 0, sizeof(Q));
-                Q.slabs = sl + k * (size_t)NSLAB_MAX * SLAB_FLOATS; Q.nslab = app_nslab; Q.MTA = 4; Q.KTB = 4; Q.gW = gW; Q.gb = gb; Q.out = 128; Q.in = in;
-                Q.row_kind = RK_NATURAL; Q.slot_kind = sk; Q.scale = 1.f;
-            };
-            fused(1, grads->rW[1], grads->rb[1], 128, SK_HIDDEN);
-            fused(2, grads->rW[0], grads->rb[0], 110, SK_RENDER_IN);
-        } else {
         if (grads->rW[1] || grads->rb[1]) add(P.app_b + 16 * REGF, 64, P.app_f + 96 * REGF, 64, sl + 1 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->rW[1], grads->rb[1], 128, 128, SK_HIDDEN);
         if (grads->rW[0] || grads->rb[0]) add(P.app_b + 80 * REGF, 64, P.app_f + 32 * REGF, 64, sl + 2 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->rW[0], grads->rb[0], 128, 110, SK_RENDER_IN);
-        }
         if (grads->basis) add(P.app_b + 144 * REGF, 16, P.app_f + 0, 32, sl + 3 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->basis, nullptr, f->app_dim, f->Ca, SK_HIDDEN);
         if (launch_wgrad(wj, rj, s_atail)) return 1;
     }
