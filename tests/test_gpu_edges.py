@@ -242,9 +242,9 @@ def test_engine_rk2_kernels_still_match_goldens():
 
 
 @pytest.mark.parametrize("env", [dict(NVFI_WGRAD="engine"), dict(NVFI_WGRAD_CHAIN="0"), dict(NVFI_BWD_FORK="0"), dict(NVFI_SCATTER="lds"),
-                                 dict(NVFI_APP_FEAT="0"), dict(NVFI_SPLIT_VOUT="0", NVFI_SPLIT_NT="2"), dict(NVFI_SPLIT_UNI_VOUT="1"), dict(NVFI_RK2_FUSE="0"), dict(NVFI_PDE_FUSE="0")],
+                                 dict(NVFI_APP_FEAT="0"), dict(NVFI_SPLIT_VOUT="0", NVFI_SPLIT_NT="2"), dict(NVFI_SPLIT_UNI_VOUT="1"), dict(NVFI_RK2_FUSE="0"), dict(NVFI_PDE_FUSE="0"), dict(NVFI_PDE_X4="0")],
                          ids=["wgrad_engine", "wgrad_no_chain", "no_bwd_fork", "scatter_lds", "app_gather_in_kernel", "prefilter_output_layer_on_mfma",
-                              "render_warp_output_layer_on_valu", "rk2_adjoint_and_wgrad_unfused", "pde_adjoint_and_wgrad_unfused"])
+                              "render_warp_output_layer_on_valu", "rk2_adjoint_and_wgrad_unfused", "pde_adjoint_and_wgrad_unfused", "pde_stash_row_major"])
 def test_round3_switches_keep_the_goldens(env):
     """the alternatives of the round-3 defaults - the register-operand weight-gradient kernel k_wgrad instead of k_wgrad_ring8, un-chained value /
     tangent jobs in the ring kernel, the keyframe backward on one stream instead of the forked density half, the LDS read-add-write tile
@@ -311,3 +311,50 @@ def test_pde_gradients_add_up_over_ragged_point_sets(P):
     np.testing.assert_allclose(full[0], val, rtol=2e-5)
     err = (full[1] - grad).abs().max().item()
     assert err <= 2e-5 * full[1].abs().max().item(), (err, full[1].abs().max().item())
+
+
+def test_pde_c_abi_with_partial_gradient_sets():
+    """nvfi_pde_loss_ex through ctypes with gradient slots left NULL: without the acceleration net's slots the fused adjoint kernel runs its
+    first half only (the acceleration net keeps k_pde_jet_bwd's workgroups); without one hidden layer of weight_net the call falls back to the
+    unfused adjoint.  The gradients that ARE asked for equal those of the full call."""
+    import ctypes as C
+    from nvfi_amd import _lib
+    L = _lib.lib()
+    model, meta = make_model("A")
+    f = model.nvfi
+    g = torch.Generator(device="cuda").manual_seed(11)
+    mn, mx = f.aabb
+    P = 8192
+    pts = (torch.rand(P, 3, device="cuda", generator=g) * (mx - mn) * 0.6 + (mn + 0.2 * (mx - mn))).contiguous()
+    tt = torch.rand(P, device="cuda", generator=g).contiguous()
+    desc = f._desc()
+    nb = C.c_int64(0)
+    _lib.check(L.nvfi_pde_workspace_bytes(C.byref(desc), C.c_int64(P), C.byref(nb)))
+
+    def run(drop):
+        ws = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
+        grads = [torch.zeros_like(p) for p in f._pde_params()]
+        G = f._grads_struct_vel(grads)
+        if drop == "accel":
+            for i in range(6):
+                G.aW[i] = None; G.ab[i] = None
+        elif drop == "layer2":
+            G.vW[2] = None; G.vb[2] = None
+        out = torch.zeros(4, device="cuda")
+        cnt = torch.zeros(_lib.NCOUNTERS, dtype=torch.int64, device="cuda")
+        _lib.check(L.nvfi_pde_loss_ex(C.byref(desc), C.c_int64(P), _lib.ptr(pts), _lib.ptr(tt), C.c_float(1.0), _lib.ptr(out), C.byref(G),
+                                      _lib.ptr(ws), C.c_int64(ws.numel()), _lib.ptr(cnt), None, None, C.c_int64(0), None, None))
+        torch.cuda.synchronize()
+        return out.cpu(), grads
+
+    out0, g0 = run(None)
+    assert out0[1] > 100
+    for drop, skip in (("accel", range(12, 24)), ("layer2", (4, 5))):
+        out1, g1 = run(drop)
+        assert torch.equal(out0[:2], out1[:2])
+        for k, (a, b) in enumerate(zip(g0, g1)):
+            if k in skip:
+                assert float(b.abs().max()) == 0.0, (drop, k)
+            else:
+                scale = float(a.abs().max())
+                assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-12, (drop, k, float((a - b).abs().max()), scale)
