@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NVFI_ABI_VERSION 4
+#define NVFI_ABI_VERSION 5
 
 /* Field description: TensorVMKeyframeTimeKplane state that reaches the hot path
  * (reference models/tensorf_keyframe.py:37-134, models/tensorf_base.py:133-227). */
@@ -60,6 +60,8 @@ typedef struct nvfi_field_desc {
     const float* aW[6];      /* vel_net.a_weight_net */
     const float* ab[6];
     const float* amask;      /* alpha volume (D,H,W) or NULL */
+    const float* frags;      /* ABI v5: fragment cache written by nvfi_pack_frags for THESE weights, or NULL (the render / PDE calls then repack
+                              * the weights into their own workspace, as in v1-v4) */
 } nvfi_field_desc;
 
 /* Gradient buffers, same shapes/layouts as the parameters; kernels ACCUMULATE (+=) into them.
@@ -122,6 +124,15 @@ int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const float* rays_o, 
 int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d, float t, int t_on_device, int flags,
                       const float* weights, const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_weights,
                       const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- fragment cache (ABI v5).  The MFMA kernels read the nn.Linear weights of the field - renderModule.mlp + basis_mat
+ *      (models/tensorf_base.py:67-98, tensorf_keyframe.py:310), vel_net.weight_net / a_weight_net (models/velocity_field.py:60-67) - in
+ *      fragment order.  nvfi_pack_frags writes every fragment set the render and PDE calls use into `cache` (nvfi_frag_cache_bytes bytes,
+ *      caller-owned) in ONE launch; a descriptor whose `frags` points at it makes nvfi_render_fwd[_t] / nvfi_render_bwd[_t] /
+ *      nvfi_pde_loss* read it instead of repacking the weights per call (7 launches per training iteration otherwise).  The caller repacks
+ *      after every change of the weights (once per optimiser step) and orders the readers behind the repack. */
+int nvfi_frag_cache_bytes(const nvfi_field_desc* f, int64_t* bytes);
+int nvfi_pack_frags(const nvfi_field_desc* f, void* cache, int64_t cache_bytes, void* stream);
 
 /* ---- PDE regulariser: replaces NVFi.get_vel_loss (models/nvfi.py:42-84) with explicit collocation
  *      points (world space (P,3)) and raw times (P).  out (device float[4]): loss, n_kept, sum div^2,

@@ -192,6 +192,46 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---------------------------------------------------------------- single-pass ordered compaction (decoupled look-back)
+// The ordered compact lists of a render / PDE call (valid samples, gate-inside samples, appearance-masked samples, kept points) used to take
+// two launches each: per-group counts, then k_fill (scan of the counts + ballot-ranked fill).  With a look-back the kernel that produces the
+// flags also places them: a workgroup publishes the count of its groups in a status word, sums the words of the workgroups in front of it and
+// fills its part of the list in the same launch - the list is the one k_fill wrote, entry for entry.
+//   status[b] = state << 62 | value   (state 0: nothing yet, 1: the workgroup's own count, 2: the inclusive prefix up to and including b)
+// value may pack two counts (31 bits each): every partial sum stays below 2^31 per field because the totals do (R * S < 2^31).
+// The status array must be zero at launch.  Workgroups are numbered by blockIdx.x: the dispatcher starts workgroups of a grid in index order,
+// so every word a workgroup waits for belongs to a workgroup that is already resident (the launch-order assumption rocPRIM's look-back scan
+// makes for its static tile order); the spin is an agent-scope atomic load, the words themselves carry all the data that is exchanged.
+#define LB_MASK ((1ull << 62) - 1ull)
+__device__ __forceinline__ unsigned long long lb_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lb_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+// Called by ONE whole wave of workgroup b (every lane, same arguments): publishes `agg`, returns the sum of the values of workgroups 0..b-1.
+__device__ __forceinline__ unsigned long long lb_exclusive(unsigned long long* status, int b, unsigned long long agg) {
+    const int lane = threadIdx.x & 63;
+    if (b == 0) { if (lane == 0) lb_store(status, (2ull << 62) | agg); return 0ull; }
+    if (lane == 0) lb_store(status + b, (1ull << 62) | agg);
+    unsigned long long excl = 0ull;
+    for (int j = b - 1;; j -= 64) {
+        const int idx = j - lane;
+        unsigned long long v;
+        do { v = idx >= 0 ? lb_load(status + idx) : (2ull << 62); } while (__any((v >> 62) == 0ull));
+        const unsigned long long incl = __ballot((v >> 62) == 2ull);     // (a lane in front of workgroup 0 reads as an inclusive prefix of zero)
+        const int first = incl ? __ffsll((long long)incl) - 1 : 64;
+        excl += wave_sum_u64(lane <= first ? (v & LB_MASK) : 0ull);
+        if (incl) break;
+    }
+    if (lane == 0) lb_store(status + b, (2ull << 62) | (excl + agg));
+    return excl;
+}
+
 // fragment sets (device pointers into the workspace)
 struct RenderFrags {
     const float* fb;            // basis fwd: MT1 NS24
@@ -224,3 +264,4 @@ int launch_scan_fill(const int* cnt, int* off, int64_t ngroups, int* total, cons
 int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st);
 int launch_wgrad_ring(WgradJobs& bj, ReduceJobs& br, hipStream_t st);   // wgrad_ring.hip
 int ensure_lds_attrs();
+bool fused_launch();     // NVFI_FUSED_LAUNCH (default 1): round 5's fused small launches (render.hip)

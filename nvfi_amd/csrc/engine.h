@@ -90,9 +90,14 @@ struct PackJob {
     int out, in, MT, NS;
     int row_kind, slot_kind;
     int transposed;      // 0: rows=out features, slots=in features ; 1 (dgrad): rows=in features, slots=out features
+    int x4;              // 1: write the fragment in x4 order (four consecutive K steps of a lane side by side, MT * ceil(NS/4) * 256 floats,
+                         //    zero beyond NS) straight from W - what k_frag_x4 (pde_jet.hip) makes of a packed fragment
 };
 #define MAX_PACK_JOBS 40
 struct PackJobs { PackJob j[MAX_PACK_JOBS]; int n; };
+// every fragment set of a field in one launch (nvfi_pack_frags, frags.hip): render MLP 8, two velocity nets 16 + 16, their x4 copies 17
+#define MAX_PACK_JOBS_ALL 60
+struct PackJobsAll { PackJob j[MAX_PACK_JOBS_ALL]; int n; };
 
 __global__ void k_pack(PackJobs jobs);
 

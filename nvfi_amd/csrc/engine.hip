@@ -4,29 +4,40 @@
 #include <stdlib.h>
 #include <string.h>
 
-__global__ void k_pack(PackJobs jobs) {
-    const PackJob& J = jobs.j[blockIdx.x];
-    const int total = J.MT * J.NS * 64;
-    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += gridDim.y * blockDim.x) {
-        int lane = idx & 63, ms = idx >> 6;
-        int s = ms % J.NS, m = ms / J.NS;
+__device__ __forceinline__ void pack_job(const PackJob& J, int y, int ny) {
+    const int NS4 = (J.NS + 3) >> 2;
+    const int total = J.x4 ? J.MT * NS4 * 256 : J.MT * J.NS * 64;
+    for (int idx = y * blockDim.x + threadIdx.x; idx < total; idx += ny * blockDim.x) {
+        int lane, s, m;
+        if (J.x4) { const int k = idx & 3, ms = idx >> 8; lane = (idx >> 2) & 63; m = ms / NS4; s = 4 * (ms - m * NS4) + k; }
+        else { const int ms = idx >> 6; lane = idx & 63; m = ms / J.NS; s = ms - m * J.NS; }
         int i = lane & 31, h = lane >> 5;
         int rowL = row_logical(J.row_kind, 32 * m + i);
         int colL = slot_logical(J.slot_kind, 2 * s + h);
         float v = 0.f;
-        if (!J.transposed) {
-            if (rowL >= 0 && rowL < J.out && colL >= 0 && colL < J.in) v = J.W[(size_t)rowL * J.in + colL];
-        } else {
-            if (rowL >= 0 && rowL < J.in && colL >= 0 && colL < J.out) v = J.W[(size_t)colL * J.in + rowL];
+        if (s < J.NS) {
+            if (!J.transposed) {
+                if (rowL >= 0 && rowL < J.out && colL >= 0 && colL < J.in) v = J.W[(size_t)rowL * J.in + colL];
+            } else {
+                if (rowL >= 0 && rowL < J.in && colL >= 0 && colL < J.out) v = J.W[(size_t)colL * J.in + rowL];
+            }
         }
         J.frag[idx] = v;
     }
-    if (J.bfrag && blockIdx.y == 0) {
+    if (J.bfrag && y == 0) {
         for (int rho = threadIdx.x; rho < J.MT * 32; rho += blockDim.x) {
             int rl = row_logical(J.row_kind, rho);
             J.bfrag[rho] = (J.b && rl >= 0 && rl < J.out) ? J.b[rl] : 0.f;
         }
     }
+}
+__global__ void k_pack(PackJobs jobs) { pack_job(jobs.j[blockIdx.x], blockIdx.y, gridDim.y); }
+__global__ void k_pack_all(PackJobsAll jobs) { pack_job(jobs.j[blockIdx.x], blockIdx.y, gridDim.y); }
+int launch_pack_all(const PackJobsAll& jobs, hipStream_t st) {
+    if (jobs.n == 0) return 0;
+    hipLaunchKernelGGL(k_pack_all, dim3(jobs.n, 8), dim3(256), 0, st, jobs);
+    LAUNCHCK();
+    return 0;
 }
 
 // G[pA][pB] = sum over tiles of A[pA][j] B[pB][j]  (p-space rows of the stash images).
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(ReduceJobs jobs) {
     }
 }
 
-static_assert(sizeof(WgradJobs) <= 4000 && sizeof(ReduceJobs) <= 4000 && sizeof(PackJobs) <= 4000, "kernel argument blocks must stay under 4 KB");
+static_assert(sizeof(WgradJobs) <= 4000 && sizeof(ReduceJobs) <= 4000 && sizeof(PackJobs) <= 4000 && sizeof(PackJobsAll) <= 4000, "kernel argument blocks must stay under 4 KB");
 
 // ---------------------------------------------------------------- host launchers (kept in this TU: no relocatable device code needed)
 int launch_pack(const PackJobs& jobs, hipStream_t st) {

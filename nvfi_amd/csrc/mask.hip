@@ -378,7 +378,7 @@ static int mask_frags(const nvfi_mask_desc* m, float* frag, MkFrags* W, bool tra
         const int MT = l < 4 ? 4 : 1, NS = l == 0 ? 2 : 64;
         J.W = m->W[l]; J.b = m->b[l]; J.frag = p; p += MT * NS * 64; J.bfrag = p; p += 128;
         J.out = l < 4 ? 128 : m->mask_dim; J.in = l == 0 ? 3 : 128; J.MT = MT; J.NS = NS;
-        J.row_kind = RK_NATURAL; J.slot_kind = l == 0 ? SK_XYZ : SK_HIDDEN; J.transposed = 0;
+        J.row_kind = RK_NATURAL; J.slot_kind = l == 0 ? SK_XYZ : SK_HIDDEN; J.transposed = 0; J.x4 = 0;
         W->f[l] = J.frag; W->b[l] = J.bfrag;
     }
     W->t[0] = nullptr;
@@ -388,7 +388,7 @@ static int mask_frags(const nvfi_mask_desc* m, float* frag, MkFrags* W, bool tra
         const int NS = l < 4 ? 64 : 16;
         J.W = m->W[l]; J.b = nullptr; J.frag = p; p += 4 * NS * 64; J.bfrag = nullptr;
         J.out = l < 4 ? 128 : m->mask_dim; J.in = 128; J.MT = 4; J.NS = NS;
-        J.row_kind = RK_NATURAL; J.slot_kind = SK_HIDDEN; J.transposed = 1;
+        J.row_kind = RK_NATURAL; J.slot_kind = SK_HIDDEN; J.transposed = 1; J.x4 = 0;
         W->t[l] = J.frag;
     }
     if (!transposed) jobs.n = 5;

@@ -34,7 +34,16 @@ struct X4Jobs { const float* src[12]; float* dst[12]; int MT[12]; int NS[12]; in
 // v-net fragments in x4 order: forward f[0] (4 tiles x 14 steps), f[1..4] (4 x 64), f[5] (1 x 64); transposed t[1..4], t[5] (4 x 4)
 #define VEL_X4_FLOATS (X4_FLOATS(4, 14) + 4 * X4_FLOATS(4, 64) + X4_FLOATS(1, 64) + 4 * X4_FLOATS(4, 64) + X4_FLOATS(4, 4))
 
+// bookkeeping done by the last workgroup of k_pde_seeds (round 5; ticket == NULL: the separate k_pde_pass_count / _finish / _counters launches)
+struct PdeTail {
+    int* ticket;               // zero at launch
+    int* dcount;               // k_pde_pass_count: [0] samples of this pass (whole 128-point groups), [8] the fused adjoint's queue word
+    float* out;                // k_pde_finish: loss, n_kept, sum div^2, sum transport^2 (NULL: not the last pass of the call)
+    int64_t* counters; const int* cls_count; int64_t P; int pre16;     // k_pde_counters (NULL: not wanted / not the last pass)
+};
+
 struct PdeJetArgs {
+    PdeTail tail;
     VelFrags Wv, Wa;
     const float4* f4[6]; const float4* t4[6]; const float* bv[6];   // x4 fragments / bias fragments of weight_net (fused jet kernels)
     int jet_tiles;             // fused jet launches: workgroups [0, jet_tiles) are jet tiles, the rest the acceleration net's column

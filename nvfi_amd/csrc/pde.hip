@@ -18,6 +18,7 @@
 #include "pde.h"
 #include "fuse.h"
 #include "scatter.h"
+#include "frags.h"
 
 // ---------------------------------------------------------------- prefilter
 __global__ __launch_bounds__(256) void k_pde_prep(PdePrepArgs a) {
@@ -84,6 +85,36 @@ __global__ __launch_bounds__(256) void k_pde_keep(nvfi_field_desc f, int64_t P, 
     }
     const unsigned long long b = __ballot(keep);
     if ((threadIdx.x & 63) == 0 && i < P) cnt[i >> 6] = __popcll(b);
+}
+
+// k_pde_keep + the k_fill launch behind it (round 5): a wave = 64 consecutive points, a workgroup publishes its kept count and places its
+// entries of the ordered kept list itself (look-back, common.h) - the list k_fill wrote, entry for entry
+__global__ __launch_bounds__(256) void k_pde_keep_fill(nvfi_field_desc f, int64_t P, const float* sig, uint8_t* flags, unsigned long long* lb, int* klist, int* kcount) {
+    __shared__ int ck[4];
+    __shared__ unsigned long long excl_sh;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool keep = false;
+    if (i < P) {
+        const float alpha = 1.f - expf(-sig[i] * 0.01f * 25.f);
+        keep = alpha >= f.alpha_thres;
+        flags[i] = keep ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(keep);
+    if (lane == 0) ck[w] = __popcll(b);
+    __syncthreads();
+    if (w == 0) {
+        const unsigned long long agg = (unsigned long long)((ck[0] + ck[1]) + (ck[2] + ck[3]));
+        const unsigned long long e = lb_exclusive(lb, (int)blockIdx.x, agg);
+        if (lane == 0) {
+            excl_sh = e;
+            if (blockIdx.x == gridDim.x - 1) *kcount = (int)(e + agg);
+        }
+    }
+    __syncthreads();
+    int base = (int)excl_sh;
+    for (int k = 0; k < w; ++k) base += ck[k];
+    if (keep) klist[base + __popcll(b & ((1ull << lane) - 1ull))] = (int)i;
 }
 
 // ---------------------------------------------------------------- forward-mode passes
@@ -399,12 +430,39 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_fwd(PdeJetArgs a)
         for (int k = 0; k < 6; ++k) o[(size_t)k * a.cap] = wd[k];
     }
 }
+// Round 5: the call's tiny bookkeeping kernels ride in k_pde_seeds.  Every workgroup of the launch draws a ticket when it is done (its
+// partial sums are agent-scope atomics that have completed - s_waitcnt vmcnt(0) - before the ticket, as in k_tile_hist); the LAST one does the
+// work of k_pde_pass_count (the sample count of this pass for the weight-gradient kernels, the fused adjoint's queue word), and - in the last
+// pass of the call - of k_pde_finish (the value) and k_pde_counters.  One thread, a few dozen loads.
+__device__ __forceinline__ void pde_tail(const PdeJetArgs& a, int count) {
+    if (threadIdx.x != 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const PdeTail& T = a.tail;
+    if (__hip_atomic_fetch_add(T.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int)gridDim.x - 1) return;
+    __hip_atomic_store(T.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (the next pass of the call draws from zero again)
+    if (T.dcount) {
+        *T.dcount = (count + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES;
+        T.dcount[8] = 0;
+    }
+    if (T.out) {
+        const int64_t nk = *a.kcount;
+        const double sd = __hip_atomic_load(a.sums + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), st = __hip_atomic_load(a.sums + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T.out[0] = nk > 0 ? (float)(5.0 * sd / (double)nk + 0.1 * st / (3.0 * (double)nk)) : 0.f;
+        T.out[1] = (float)nk; T.out[2] = (float)sd; T.out[3] = (float)st;
+    }
+    if (T.counters) {
+        int64_t evals = 0;
+        for (int c = 0; c < PDE_MAX_CLASS; ++c) evals += 2ll * c * T.cls_count[c];
+        int64_t* c8 = T.counters;
+        c8[0] = 0; c8[1] = T.P; c8[2] = 0; c8[3] = evals; c8[4] = *a.kcount; c8[5] = T.pre16 ? a.kcount[1] : 0; c8[6] = c8[7] = 0;
+    }
+}
 // K3: per-point residuals (nvfi.py:74-83), loss partial sums and adjoint seeds
 __global__ __launch_bounds__(256) void k_pde_seeds(PdeJetArgs a) {
     __shared__ float red[8];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int count = pde_pass_count(a);
-    if ((int)(blockIdx.x * 256) >= count) return;
+    if ((int)(blockIdx.x * 256) >= count) { if (a.tail.ticket) pde_tail(a, count); return; }
     const bool active = i < count;
     const size_t cs = a.cap;
     const int capc = (count + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES;   // the jet workgroups cover whole 128-point groups
@@ -489,6 +547,7 @@ __global__ __launch_bounds__(256) void k_pde_seeds(PdeJetArgs a) {
         atomicAdd(a.sums + 0, (double)(red[0] + red[1] + red[2] + red[3]));
         atomicAdd(a.sums + 1, (double)(red[4] + red[5] + red[6] + red[7]));
     }
+    if (a.tail.ticket) pde_tail(a, count);
 }
 // K4: tangent-adjoint column j = blockIdx.y (0..3) or the a_weight_net adjoint (y = 4)
 __global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_bwd(PdeJetArgs a) {
@@ -571,7 +630,7 @@ struct PdePlan {
     uint8_t* flags;
     float* sig;     // density at the warped points (prefilter)
     float4* xw16; uint8_t* near; int* blist; int* bcount; void* img16; void* img16lo;   // fp16 pre-pass (pre16.hip)
-    double* sums;
+    double* sums; unsigned long long* lb; int64_t zero_bytes;
     float *vel_frag, *a_frag, *vel_x4, *a_x4, *stash, *seeds, *wout, *slabs;
     int64_t chunk, total;
 };
@@ -580,11 +639,18 @@ static void plan_pde(int64_t P, void* ws, PdePlan* L) {
     const int64_t nw = (P + 63) / 64;
     L->qorig = B.take<float4>(P); L->xw = B.take<float4>(P);
     L->pt_t = B.take<float>(P); L->pt_base = B.take<float>(P); L->pt_t_perm = B.take<float>(P); L->pt_base_perm = B.take<float>(P);
-    L->cls = B.take<int>(P); L->rank = B.take<int>(P); L->cls_count = B.take<int>(PDE_MAX_CLASS + 16); L->perm = B.take<int>(P);
+    L->cls = B.take<int>(P); L->rank = B.take<int>(P);
+    // one fill clears: the class histogram + counts (PDE_MAX_CLASS + 16 ints: [+0] kept, [+1] band, [+2] ticket of k_pde_seeds' tail), the four
+    // double loss sums and the look-back words of k_pde_keep_fill (one per workgroup of 256 points)
+    L->cls_count = B.take<int>(PDE_MAX_CLASS + 16); L->sums = reinterpret_cast<double*>(L->cls_count + PDE_MAX_CLASS + 16);
+    B.off += 4 * (int64_t)sizeof(double);
+    L->lb = reinterpret_cast<unsigned long long*>(L->cls_count + PDE_MAX_CLASS + 16 + 8);
+    B.off += ((P + 255) / 256) * (int64_t)sizeof(unsigned long long);
+    L->zero_bytes = (PDE_MAX_CLASS + 16) * (int64_t)sizeof(int) + 4 * (int64_t)sizeof(double) + ((P + 255) / 256) * (int64_t)sizeof(unsigned long long);
+    L->perm = B.take<int>(P);
     L->cnt = B.take<int>(nw); L->off = B.take<int>(nw + 1); L->klist = B.take<int>(P); L->kcount = L->cls_count + PDE_MAX_CLASS;
     L->flags = B.take<uint8_t>(nw * 64);
     L->sig = B.take<float>(nw * 64);
-    L->sums = B.take<double>(4);
     L->xw16 = B.take<float4>(P); L->near = B.take<uint8_t>(nw * 64); L->blist = B.take<int>(P); L->bcount = L->cls_count + PDE_MAX_CLASS + 1;
     L->img16 = B.take<float4>(PRE16_IMAGE_BYTES / 16);
     L->img16lo = B.take<float4>(PRE16_IMAGE_BYTES / 16);
@@ -661,13 +727,15 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     if (ensure_pde_attrs() || ensure_lds_attrs()) return 1;
     PdePlan L; plan_pde(P, workspace, &L);
     if (L.total > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld bytes, got %lld", (long long)L.total, (long long)workspace_bytes);
-    HIPCK(hipMemsetAsync(L.cls_count, 0, (PDE_MAX_CLASS + 16) * sizeof(int), st));     // 320 bytes: 16-byte multiple, one fill kernel
-    HIPCK(hipMemsetAsync(L.sums, 0, 4 * sizeof(double), st));
+    HIPCK(hipMemsetAsync(L.cls_count, 0, (size_t)L.zero_bytes, st));     // histogram / counts, loss sums, look-back words: one fill
+    const bool fl = fused_launch();
     PackJobs jobs; jobs.n = 0;
     VelFrags VW, AW;
-    if (pack_vel_frags(f->vW, f->vb, L.vel_frag, &VW, &jobs)) return 3;
-    if (pack_vel_frags(f->aW, f->ab, L.a_frag, &AW, &jobs)) return 3;
-    if (launch_pack(jobs, st)) return 1;
+    FragCache FC; const bool cached = f->frags != nullptr;       // round 5: the field's fragment cache (nvfi_pack_frags) instead of a repack per call
+    if (cached) frag_cache_layout(f->frags, &FC);
+    if (pack_vel_frags(f->vW, f->vb, cached ? FC.vel : L.vel_frag, &VW, &jobs)) return 3;
+    if (pack_vel_frags(f->aW, f->ab, cached ? FC.anet : L.a_frag, &AW, &jobs)) return 3;
+    if (!cached && launch_pack(jobs, st)) return 1;
     // fused jet kernels (pde_jet.hip; NVFI_PDE_JET=0 keeps the column kernels for every column): x4 copies of the v-net fragments
     static int use_jet = -1;
     if (use_jet < 0) { const char* e = getenv("NVFI_PDE_JET"); use_jet = e ? atoi(e) : 1; }
@@ -690,7 +758,8 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         if ((e = getenv("NVFI_PDE_GATE_EPS"))) eps16 = (float)atof(e);
     }
     const float4* f4[6] = {nullptr}; const float4* t4[6] = {nullptr};
-    if (use_jet || pre16) {
+    if (cached) { x4f_pointers(FC.vel_x4f, f4); x4b_pointers(FC.vel_x4b, t4); }
+    else if (use_jet || pre16) {
         X4Jobs xj; xj.n = 0;
         float* p = L.vel_x4;
         auto add = [&](const float* src, int MT, int NS, const float4** slot) {
@@ -706,7 +775,8 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         if (launch_frag_x4(xj, st)) return 1;
     }
     const float4* ta4[6] = {nullptr};
-    if (use_jet && pde_fuse && grads) {
+    if (cached) a_x4b_pointers(FC.a_x4b, ta4);
+    else if (use_jet && pde_fuse && grads) {
         X4Jobs xj; xj.n = 0;
         float* p = L.a_x4;
         for (int l = 1; l <= 5; ++l) {
@@ -759,8 +829,11 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         da.count = L.bcount; da.list = L.blist; da.xw = L.xw;
         if (launch_density_q(da, P, st)) return 1;
     }
-    hipLaunchKernelGGL(k_pde_keep, dim3(pb), dim3(256), 0, st, *f, P, L.sig, L.flags, L.cnt);
-    launch_scan_fill(L.cnt, L.off, nw, L.kcount, L.flags, L.klist, st);
+    if (fl) hipLaunchKernelGGL(k_pde_keep_fill, dim3(pb), dim3(256), 0, st, *f, P, L.sig, L.flags, L.lb, L.klist, L.kcount);
+    else {
+        hipLaunchKernelGGL(k_pde_keep, dim3(pb), dim3(256), 0, st, *f, P, L.sig, L.flags, L.cnt);
+        launch_scan_fill(L.cnt, L.off, nw, L.kcount, L.flags, L.klist, st);
+    }
     LAUNCHCK();
     // The kept count stays on the device (L.kcount): the jet passes are launched with worst-case grids and size themselves from it.
     // Only a caller that asks for host_info (diagnostics; the Python mirror's `return 0.` decision, nvfi.py:66) pays a synchronisation.
@@ -808,12 +881,20 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
                 hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
                 hipLaunchKernelGGL(k_pde_tangent_fwd, PDE_GRID(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
             }
+            if (fl) {
+                // the last workgroup of k_pde_seeds does the bookkeeping launches' work (pde_tail); out / counters in the last pass of the call only
+                const bool last_pass = first + L.chunk >= P;
+                ja.tail.ticket = L.cls_count + PDE_MAX_CLASS + 2; ja.tail.dcount = grads ? L.dcount : nullptr;
+                ja.tail.out = last_pass ? out : nullptr;
+                ja.tail.counters = last_pass ? counters : nullptr; ja.tail.cls_count = L.cls_count; ja.tail.P = P; ja.tail.pre16 = (pre16 == 1 || pre16 == 3) ? 1 : 0;
+                if (last_pass) finished = true;
+            }
             hipLaunchKernelGGL(k_pde_seeds, dim3((unsigned)(cap / 256 + 1)), dim3(256), 0, st, ja);
         }
         if (grads) {
             hipStream_t sb = st;
             if (t_bwd_stream && P <= L.chunk) {      // split call: the value is finished on st first, the adjoint half follows on the other stream
-                hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, L.kcount, out);
+                if (!fl) hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, L.kcount, out);
                 // the host's copy of the counts is queued IN FRONT of the adjoint half: k_pde_fuse_bwd owns every CU for ~0.4 ms (12 waves x 168
                 // registers, 152 KB of LDS per workgroup) and a copy kernel queued behind its start waits for its first workgroup to retire - the
                 // caller's `if loss_vel > 0` then returned 0.43 ms late (trace of the drop-in loop)
@@ -827,7 +908,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
             float* fused_slabs = L.slabs + (size_t)14 * PDE_NSLAB * (128 * 128 + 128);      // sets 14..17 (launch_pde_wgrad uses at most 10 beside them)
             float* fused_slabs_a = L.slabs + (size_t)10 * PDE_NSLAB * (128 * 128 + 128);    // sets 10..13 (at most 6 ring jobs are left then)
             // (before the adjoint: the fused kernel's queue word is cleared by the same launch)
-            hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, sb, L.kcount, first, cap, L.dcount);
+            if (!fl) hipLaunchKernelGGL(k_pde_pass_count, dim3(1), dim3(64), 0, sb, L.kcount, first, cap, L.dcount);
             {
                 ProfScope ps(PK_PDE_BWD, sb);
                 if (fuse_ok) {
@@ -866,7 +947,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     }
     if (!finished) hipLaunchKernelGGL(k_pde_finish, dim3(1), dim3(64), 0, st, L.sums, L.kcount, out);
     LAUNCHCK();
-    if (counters) {
+    if (counters && !fl) {
         hipLaunchKernelGGL(k_pde_counters, dim3(1), dim3(64), 0, st, L.cls_count, L.kcount, P, pre16 == 1 || pre16 == 3, counters);
         LAUNCHCK();
     }

@@ -12,6 +12,8 @@ struct SampleArgs {
     const int* inside;
     float4* xw; float* xpre; uint8_t* valid; int* cnt;
     uint8_t* rflag; int* cnt_r;   // valid AND inside the velocity gate: the samples the RK2 warp has to touch (NULL: not wanted)
+    // k_sample_fill (sampling + both ordered compact lists in one launch): look-back status words (zero at launch), the lists, their totals
+    unsigned long long* lb; int* vlist; int* rlist; int* total_v; int* total_r;
 };
 
 struct DensityArgs {
@@ -33,6 +35,8 @@ struct WeightArgs {
     const float* xpre; const float4* xw;
     float distance_scale, weight_thres, far_;
     float* weight; uint8_t* mflag; float* acc; float* depth; int* cnt_m;
+    // k_weights_fill (weights + the ordered list of appearance-masked samples in one launch)
+    unsigned long long* lb; int* off_m_out; int* mlist; int* total_m;
     // backward
     const int* off_m; const float4* rgbs; const float4* rgb_pre;
     const float* g_rgb; const float* g_depth; const float* g_acc; const float* g_weight;
@@ -46,6 +50,8 @@ struct FinalArgs {
     const float* weight; const float4* rgbs; const float* acc;
     int white_bg;
     float4* rgb_pre; float* rgb;
+    // the call's counters (k_counters' job) written by workgroup 0 of the same launch; NULL: not wanted
+    const int* c; int nsteps; int64_t* counters_out; const float* sched;
 };
 
 struct AppArgs {

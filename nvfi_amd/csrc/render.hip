@@ -14,6 +14,7 @@
 #include "fuse.h"
 #include "scatter.h"
 #include "pde.h"
+#include "frags.h"
 #include <stdlib.h>
 #include <mutex>
 
@@ -139,6 +140,87 @@ __global__ __launch_bounds__(256) void k_fill(int64_t R, int S, const uint8_t* _
     }
 }
 
+// ---------------------------------------------------------------- round 5: the same lists without the second (and third) launch
+// NVFI_FUSED_LAUNCH (default 1): the producers of the flags place the list entries themselves (look-back, common.h); 0 keeps the
+// count + k_fill launches of rounds 1-4.  Same flags, same order: the lists are identical entry for entry.
+bool fused_launch() { static int u = -1; if (u < 0) { const char* e = getenv("NVFI_FUSED_LAUNCH"); u = e ? atoi(e) : 1; } return u != 0; }
+
+// k_sample + the two k_fill launches behind it
+__global__ __launch_bounds__(256) void k_sample_fill(SampleArgs a) {
+    __shared__ int cv[4], cr[4];
+    __shared__ unsigned long long excl_sh;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + w;
+    const bool ron = r < a.R;
+    const nvfi_field_desc& f = a.f;
+    const int S = f.n_samples;
+    int cnt = 0, cntr = 0;
+    if (ron) {
+        float o[3] = {a.o[3 * r], a.o[3 * r + 1], a.o[3 * r + 2]};
+        float d[3] = {a.d[3 * r], a.d[3 * r + 1], a.d[3 * r + 2]};
+        const float tmin = ray_tmin(f, *a.inside != 0, o, d);
+        const float u = (a.train && a.u) ? a.u[r] : 0.f;
+        for (int j0 = 0; j0 < S; j0 += 64) {
+            const int j = j0 + lane;
+            bool ok = false, mv = false;
+            if (j < S) {
+                float rng = (float)j + u;
+                float step = f.step_size * rng;
+                float z = tmin + step;
+                float p[3], xn[3];
+                ok = true;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    p[c] = o[c] + d[c] * z;
+                    if (f.aabb[c] > p[c] || p[c] > f.aabb[3 + c]) ok = false;
+                    xn[c] = norm_coord(f, c, p[c]);
+                }
+                if (ok && f.has_amask && !a.train) ok = alpha_lookup(f, xn[0], xn[1], xn[2]) > 0.f;
+                const int64_t n = r * S + j;
+                a.xw[n] = make_float4(xn[0], xn[1], xn[2], z);
+                a.xpre[n] = XPRE_INVALID;
+                a.valid[n] = ok ? 1 : 0;
+                mv = ok && !gated_out(f, xn[0], xn[1], xn[2]);
+                if (a.rflag) a.rflag[n] = mv ? 1 : 0;
+            }
+            cnt += __popcll(__ballot(ok));
+            cntr += __popcll(__ballot(mv));
+        }
+    }
+    if (lane == 0) { cv[w] = cnt; cr[w] = cntr; }
+    __syncthreads();
+    if (w == 0) {
+        const unsigned long long agg = ((unsigned long long)((cv[0] + cv[1]) + (cv[2] + cv[3])) << 31) | (unsigned long long)((cr[0] + cr[1]) + (cr[2] + cr[3]));
+        const unsigned long long e = lb_exclusive(a.lb, (int)blockIdx.x, agg);
+        if (lane == 0) {
+            excl_sh = e;
+            if (blockIdx.x == gridDim.x - 1) {
+                const unsigned long long tot = e + agg;
+                *a.total_v = (int)(tot >> 31);
+                if (a.rflag) *a.total_r = (int)(tot & 0x7fffffffull);
+            }
+        }
+    }
+    __syncthreads();
+    if (!ron) return;
+    int base_v = (int)(excl_sh >> 31), base_r = (int)(excl_sh & 0x7fffffffull);
+    for (int k = 0; k < w; ++k) { base_v += cv[k]; base_r += cr[k]; }
+    // (the flags were written by this very lane above)
+    for (int j0 = 0; j0 < S; j0 += 64) {
+        const int j = j0 + lane;
+        const bool ok = j < S && a.valid[r * S + j];
+        const unsigned long long b = __ballot(ok);
+        if (ok) a.vlist[base_v + __popcll(b & ((1ull << lane) - 1ull))] = (int)(r * S + j);
+        base_v += __popcll(b);
+        if (a.rflag) {
+            const bool mv = j < S && a.rflag[r * S + j];
+            const unsigned long long bm = __ballot(mv);
+            if (mv) a.rlist[base_r + __popcll(bm & ((1ull << lane) - 1ull))] = (int)(r * S + j);
+            base_r += __popcll(bm);
+        }
+    }
+}
+
 // scan + ordered fill for n_groups groups of 64 flags (used by the PDE prefilter)
 int launch_scan_fill(const int* cnt, int* off, int64_t ngroups, int* total, const uint8_t* flags, int* list, hipStream_t st) {
     if (ngroups <= 0) { HIPCK(hipMemsetAsync(total, 0, sizeof(int), st)); return 0; }
@@ -235,6 +317,82 @@ __global__ __launch_bounds__(256) void k_weights_fwd(WeightArgs a) {
     }
 }
 
+// the call's counters for the caller (device-side totals -> int64[8]); by k_counters, or by workgroup 0 of k_final_fwd (round 5)
+__device__ __forceinline__ void counters_body(const int* c, int nsteps, int64_t* out, const float* sched) {
+    out[0] = c[0];
+    out[1] = nsteps > 0 ? c[3] : 0;
+    out[2] = c[1];
+    out[3] = (int64_t)(nsteps > 0 ? c[3] : 0) * 2 * nsteps;
+    out[4] = out[5] = out[6] = 0;
+    out[7] = sched ? __float_as_int(sched[3]) : 0;      // 1: the device-side time did not fit the planned RK2 step count (the planned time was rendered)
+}
+
+// k_weights_fwd + the k_fill launch behind it: the ordered list of appearance-masked samples (weight > rayMarch_weight_thres) and the per-ray
+// offsets into it (k_final_fwd / k_weights_bwd read off_m) from the same launch
+__global__ __launch_bounds__(256) void k_weights_fill(WeightArgs a) {
+    __shared__ int cm[4];
+    __shared__ unsigned long long excl_sh;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + w;
+    const bool ron = r < a.R;
+    const int S = a.S;
+    int cnt = 0;
+    if (ron) {
+        float carry = 1.f, accs = 0.f, dep = 0.f;
+        for (int j0 = 0; j0 < S; j0 += 64) {
+            const int j = j0 + lane;
+            const bool in = j < S;
+            const int64_t n = r * S + j;
+            float sig = 0.f, dist = 0.f, z = 0.f;
+            if (in) {
+                sig = softplus_f(a.xpre[n]);
+                z = a.xw[n].w;
+                if (j + 1 < S) dist = (a.xw[n + 1].w - z) * a.distance_scale;
+            }
+            const float al = 1.f - expf(-sig * dist);
+            const float fct = 1.f - al + 1e-10f;
+            float p = fct;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(p, o); if (lane >= o) p *= t; }
+            float ex = __shfl_up(p, 1);
+            if (lane == 0) ex = 1.f;
+            const float T = carry * ex;
+            const float wgt = al * T;
+            carry = carry * __shfl(p, 63);
+            const bool m = in && wgt > a.weight_thres;
+            if (in) { a.weight[n] = wgt; a.mflag[n] = m ? 1 : 0; accs += wgt; dep += wgt * z; }
+            cnt += __popcll(__ballot(m));
+        }
+        accs = wave_sum(accs); dep = wave_sum(dep);
+        if (lane == 0) {
+            a.acc[r] = accs;
+            a.depth[r] = dep + (1.f - accs) * a.far_;
+        }
+    }
+    if (lane == 0) cm[w] = cnt;
+    __syncthreads();
+    if (w == 0) {
+        const unsigned long long agg = (unsigned long long)((cm[0] + cm[1]) + (cm[2] + cm[3]));
+        const unsigned long long e = lb_exclusive(a.lb, (int)blockIdx.x, agg);
+        if (lane == 0) {
+            excl_sh = e;
+            if (blockIdx.x == gridDim.x - 1) { const int tot = (int)(e + agg); a.off_m_out[a.R] = tot; *a.total_m = tot; }
+        }
+    }
+    __syncthreads();
+    if (!ron) return;
+    int base = (int)excl_sh;
+    for (int k = 0; k < w; ++k) base += cm[k];
+    if (lane == 0) a.off_m_out[r] = base;
+    for (int j0 = 0; j0 < S; j0 += 64) {
+        const int j = j0 + lane;
+        const bool ok = j < S && a.mflag[r * S + j];
+        const unsigned long long b = __ballot(ok);
+        if (ok) a.mlist[base + __popcll(b & ((1ull << lane) - 1ull))] = (int)(r * S + j);
+        base += __popcll(b);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_final_fwd(FinalArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -254,6 +412,7 @@ __global__ __launch_bounds__(256) void k_final_fwd(FinalArgs a) {
         a.rgb[3 * r + 1] = fminf(fmaxf(c1, 0.f), 1.f);
         a.rgb[3 * r + 2] = fminf(fmaxf(c2, 0.f), 1.f);
     }
+    if (a.counters_out && blockIdx.x == 0 && threadIdx.x == 0) counters_body(a.c, a.nsteps, a.counters_out, a.sched);
 }
 
 // backward of composites + raw2alpha: produces d/d(xpre) per sample
@@ -1011,7 +1170,7 @@ int pack_render_frags(const nvfi_field_desc* f, float* buf, RenderFrags* out, Pa
         if (jobs->n >= MAX_PACK_JOBS) return 1;
         PackJob& J = jobs->j[jobs->n++];
         J.W = W; J.b = b; J.frag = frag; J.bfrag = bfrag; J.out = o; J.in = in; J.MT = MT; J.NS = NS;
-        J.row_kind = rk; J.slot_kind = sk; J.transposed = tr;
+        J.row_kind = rk; J.slot_kind = sk; J.transposed = tr; J.x4 = 0;
         return 0;
     };
     int rc = 0;
@@ -1063,8 +1222,7 @@ static int rk_schedule(const nvfi_field_desc* f, float t, int flags, float* base
 struct SchedArgs {
     nvfi_field_desc f; const float* t_dev; int flags; int nsteps_plan; float tn_plan; float dt_plan[4]; float tc_plan[4]; float* sched;
 };
-__global__ void k_sched(SchedArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void sched_body(const SchedArgs& a) {
     const nvfi_field_desc& f = a.f;
     float* S = a.sched;
     const float t = *a.t_dev;
@@ -1095,6 +1253,37 @@ __global__ void k_sched(SchedArgs a) {
     yf = fminf(fmaxf(yf, -4.f), (float)f.K + 2.f);
     S[0] = tn; S[1] = __int_as_float((int)yf); S[2] = __int_as_float(n); S[3] = __int_as_float(bad ? 1 : 0);
 }
+__global__ void k_sched(SchedArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    sched_body(a);
+}
+
+// The head of a render call in ONE workgroup: clears the call's counters / sort histograms / look-back words (the forward's memset), derives the
+// device-side schedule when the frame time lives in device memory (k_sched), and tests the ray origins against the box (k_any_inside,
+// tensorf_base.py:294).  Used for R <= PROLOGUE_MAX_RAYS; larger calls keep the three launches.
+#define PROLOGUE_MAX_RAYS 8192
+struct PrologueArgs { SchedArgs sc; int do_sched; int64_t R; const float* o; int* zero_from; int64_t zero_ints; int* inside; };
+__global__ __launch_bounds__(256) void k_prologue(PrologueArgs a) {
+    __shared__ int hit_any;
+    if (threadIdx.x == 0) hit_any = 0;
+    int4* z4 = reinterpret_cast<int4*>(a.zero_from);         // (256-byte aligned, a multiple of 256 bytes)
+    for (int64_t k = threadIdx.x; k < a.zero_ints / 4; k += 256) z4[k] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    const nvfi_field_desc& f = a.sc.f;
+    bool hit = false;
+    for (int64_t i = threadIdx.x; i < a.R * 3; i += 256) {
+        const int c = (int)(i % 3);
+        const float v = a.o[i];
+        if (f.aabb[c] <= v && v <= f.aabb[3 + c]) hit = true;
+    }
+    if (__any(hit) && (threadIdx.x & 63) == 0) hit_any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *a.inside = hit_any;       // (inside the zeroed range: written after the clear, by the same workgroup)
+        if (a.do_sched) sched_body(a.sc);
+    }
+}
+
 
 struct RenderPlan {
     int64_t N, cap_tiles;
@@ -1111,7 +1300,8 @@ struct RenderPlan {
     unsigned* app_relu;
     float *slabs;
     long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
-    int64_t zero_bytes;        // counters .. end of the sort histograms: zeroed by the forward's single fill
+    int64_t zero_bytes;        // counters .. end of the sort histograms / look-back words: zeroed by the forward's single fill (or k_prologue)
+    unsigned long long *lb_s, *lb_w;   // look-back status words of k_sample_fill / k_weights_fill
     TileWork tw; bool tiles;   // sorted-tile plane scatter (scatter.hip); tiles = false: grid too large, atomic scatter instead
     int64_t total;
 };
@@ -1135,6 +1325,9 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->tiles = train && tile_geom(f, &P->tw.g) == 0 && use_tiles() && !det_mode();
     P->tw.hist = P->tw2.hist = nullptr;
     if (P->tiles) { P->tw2.g = P->tw.g; P->tw.hist = B.take<int>(P->tw.g.nbins + 64); P->tw2.hist = B.take<int>(P->tw.g.nbins + 64); }
+    // ... and so do the look-back words of the two fused compactions (k_sample_fill, k_weights_fill): one per workgroup of 4 rays
+    const int64_t ray_wgs = (R + 3) / 4;
+    P->lb_s = B.take<unsigned long long>(ray_wgs); P->lb_w = B.take<unsigned long long>(ray_wgs);
     P->zero_bytes = align_up(B.off, 256) - off_counters;
     P->sched = B.take<float>(SCHED_FLOATS);
     P->cnt_v = B.take<int>(R); P->off_v = B.take<int>(R + 1);
@@ -1233,31 +1426,54 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
     const int S = f->n_samples;
     const int64_t N = P.N;
     const float tn = f->use_vel ? norm_time(*f, base) : norm_time(*f, t);
-    HIPCK(hipMemsetAsync(P.counters, 0, (size_t)P.zero_bytes, st));
+    const bool fl = fused_launch();
+    const bool pro = fl && R <= PROLOGUE_MAX_RAYS;      // one-workgroup prologue: clear + schedule + origin test
     const float* sched = nullptr;
-    if (t_dev) {
-        if (nsteps > 4) return nvfi_fail(2, "a device-side time supports plans of up to 4 RK2 steps (t=%g needs %d)", t, nsteps);
-        SchedArgs sc; memset(&sc, 0, sizeof(sc));
-        sc.f = *f; sc.t_dev = t_dev; sc.flags = flags; sc.nsteps_plan = nsteps; sc.tn_plan = tn; sc.sched = P.sched;
-        for (int s = 0; s < nsteps; ++s) { sc.dt_plan[s] = dts[s]; sc.tc_plan[s] = tcs[s]; }
-        hipLaunchKernelGGL(k_sched, dim3(1), dim3(64), 0, st, sc);
-        sched = P.sched;
+    if (t_dev && nsteps > 4) return nvfi_fail(2, "a device-side time supports plans of up to 4 RK2 steps (t=%g needs %d)", t, nsteps);
+    if (pro) {
+        PrologueArgs pa; memset(&pa, 0, sizeof(pa));
+        pa.sc.f = *f; pa.R = R; pa.o = rays_o; pa.zero_from = P.counters; pa.zero_ints = P.zero_bytes / 4; pa.inside = P.counters + 2;
+        if (t_dev) {
+            pa.do_sched = 1;
+            pa.sc.t_dev = t_dev; pa.sc.flags = flags; pa.sc.nsteps_plan = nsteps; pa.sc.tn_plan = tn; pa.sc.sched = P.sched;
+            for (int s = 0; s < nsteps; ++s) { pa.sc.dt_plan[s] = dts[s]; pa.sc.tc_plan[s] = tcs[s]; }
+            sched = P.sched;
+        }
+        hipLaunchKernelGGL(k_prologue, dim3(1), dim3(256), 0, st, pa);
+    } else {
+        HIPCK(hipMemsetAsync(P.counters, 0, (size_t)P.zero_bytes, st));
+        if (t_dev) {
+            SchedArgs sc; memset(&sc, 0, sizeof(sc));
+            sc.f = *f; sc.t_dev = t_dev; sc.flags = flags; sc.nsteps_plan = nsteps; sc.tn_plan = tn; sc.sched = P.sched;
+            for (int s = 0; s < nsteps; ++s) { sc.dt_plan[s] = dts[s]; sc.tc_plan[s] = tcs[s]; }
+            hipLaunchKernelGGL(k_sched, dim3(1), dim3(64), 0, st, sc);
+            sched = P.sched;
+        }
     }
     // fragments (weights change every optimiser step: repack per call, ~0.3 MB)
+    // (round 5: or not at all - a descriptor that carries the field's fragment cache, nvfi_pack_frags, points the kernels at it)
     PackJobs jobs; jobs.n = 0;
     VelFrags VW; RenderFrags RW;
-    if (f->use_vel && nsteps > 0) { if (pack_vel_frags(f->vW, f->vb, P.vel_frag, &VW, &jobs)) return 3; }
-    if (pack_render_frags(f, P.render_frag, &RW, &jobs)) return 3;
-    if (launch_pack(jobs, st)) return 1;
+    FragCache FC; const bool cached = f->frags != nullptr;
+    if (cached) frag_cache_layout(f->frags, &FC);
+    if (f->use_vel && nsteps > 0) { if (pack_vel_frags(f->vW, f->vb, cached ? FC.vel : P.vel_frag, &VW, &jobs)) return 3; }
+    if (pack_render_frags(f, cached ? FC.render : P.render_frag, &RW, &jobs)) return 3;
+    if (!cached && launch_pack(jobs, st)) return 1;
     const unsigned ray_blocks = (unsigned)((R + 3) / 4);
     // sampling
-    hipLaunchKernelGGL(k_any_inside, dim3(64), dim3(256), 0, st, *f, R, rays_o, P.counters + 2);
-    SampleArgs sa; sa.f = *f; sa.R = R; sa.o = rays_o; sa.d = rays_d; sa.u = jitter; sa.train = train; sa.inside = P.counters + 2;
+    if (!pro) hipLaunchKernelGGL(k_any_inside, dim3(64), dim3(256), 0, st, *f, R, rays_o, P.counters + 2);
+    SampleArgs sa; memset(&sa, 0, sizeof(sa));
+    sa.f = *f; sa.R = R; sa.o = rays_o; sa.d = rays_d; sa.u = jitter; sa.train = train; sa.inside = P.counters + 2;
     sa.xw = P.xw; sa.xpre = P.xpre; sa.valid = P.valid; sa.cnt = P.cnt_v; sa.rflag = P.rflag; sa.cnt_r = P.cnt_r;
-    hipLaunchKernelGGL(k_sample, dim3(ray_blocks), dim3(256), 0, st, sa);
-    hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.valid, P.cnt_v, P.off_v, P.vlist, P.counters + 0);
-    if (nsteps > 0) {   // second compact list: the valid samples inside the velocity gate (counters[3])
-        hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.rflag, P.cnt_r, P.off_r, P.rlist, P.counters + 3);
+    if (fl) {
+        sa.lb = P.lb_s; sa.vlist = P.vlist; sa.rlist = P.rlist; sa.total_v = P.counters + 0; sa.total_r = P.counters + 3;
+        hipLaunchKernelGGL(k_sample_fill, dim3(ray_blocks), dim3(256), 0, st, sa);
+    } else {
+        hipLaunchKernelGGL(k_sample, dim3(ray_blocks), dim3(256), 0, st, sa);
+        hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.valid, P.cnt_v, P.off_v, P.vlist, P.counters + 0);
+        if (nsteps > 0) {   // second compact list: the valid samples inside the velocity gate (counters[3])
+            hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.rflag, P.cnt_r, P.off_r, P.rlist, P.counters + 3);
+        }
     }
     LAUNCHCK();
     // velocity warp back to the keyframe
@@ -1280,7 +1496,8 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
             if (launch_rk2_inf16(f, h, true, st, train)) return 1;
         } else if (split) {
             SplitUniArgs ua; ua.r = ra;
-            if (pack_vel_x4_fwd(VW, P.vel_x4, ua.f4, st)) return 1;
+            if (cached) x4f_pointers(FC.vel_x4f, ua.f4);
+            else if (pack_vel_x4_fwd(VW, P.vel_x4, ua.f4, st)) return 1;
             for (int l = 0; l < 6; ++l) ua.bv[l] = VW.b[l];
             if (launch_rk2_split_uni(ua, N, train, st)) return 1;
         } else if (launch_rk2_fwd(ra, N, true, train, st)) return 1;
@@ -1293,8 +1510,13 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
     WeightArgs wa; memset(&wa, 0, sizeof(wa));
     wa.R = R; wa.S = S; wa.xpre = P.xpre; wa.xw = P.xw; wa.distance_scale = f->distance_scale; wa.weight_thres = f->weight_thres;
     wa.far_ = f->far_; wa.weight = weights; wa.mflag = P.mflag; wa.acc = acc; wa.depth = depth; wa.cnt_m = P.cnt_m;
-    hipLaunchKernelGGL(k_weights_fwd, dim3(ray_blocks), dim3(256), 0, st, wa);
-    hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.mflag, P.cnt_m, P.off_m, P.mlist, P.counters + 1);
+    if (fl) {
+        wa.lb = P.lb_w; wa.off_m_out = P.off_m; wa.mlist = P.mlist; wa.total_m = P.counters + 1;
+        hipLaunchKernelGGL(k_weights_fill, dim3(ray_blocks), dim3(256), 0, st, wa);
+    } else {
+        hipLaunchKernelGGL(k_weights_fwd, dim3(ray_blocks), dim3(256), 0, st, wa);
+        hipLaunchKernelGGL(k_fill, dim3(ray_blocks), dim3(256), 0, st, R, S, P.mflag, P.cnt_m, P.off_m, P.mlist, P.counters + 1);
+    }
     LAUNCHCK();
     // appearance
     AppArgs aa; memset(&aa, 0, sizeof(aa));
@@ -1315,9 +1537,10 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
     // composite
     FinalArgs fa; fa.R = R; fa.off_m = P.off_m; fa.mlist = P.mlist; fa.weight = weights; fa.rgbs = P.rgbs; fa.acc = acc;
     fa.white_bg = (flags & NVFI_WHITE_BG) ? 1 : 0; fa.rgb_pre = P.rgb_pre; fa.rgb = rgb;
+    fa.c = P.counters; fa.nsteps = nsteps; fa.counters_out = fl ? counters : nullptr; fa.sched = sched;
     hipLaunchKernelGGL(k_final_fwd, dim3(ray_blocks), dim3(256), 0, st, fa);
     LAUNCHCK();
-    if (counters) {
+    if (counters && !fl) {
         hipLaunchKernelGGL(k_counters, dim3(1), dim3(64), 0, st, P.counters, nsteps, counters, sched);
         LAUNCHCK();
     }
@@ -1356,9 +1579,24 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     const bool fork = forkable && nsteps == 0, fork2 = forkable && nsteps > 0;
     hipStream_t sd = st;                                     // stream of k_weights_bwd / k_og<24> (keyframe fork: the side stream)
     hipStream_t s_atail = st, s_dtail = st;                  // streams of the appearance tail (scatter, render-MLP weight gradients) and of the density scatter
-    if (fork) { HIPCK(hipEventRecord(g_fork.fork, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork, 0)); sd = g_fork.s; s_dtail = g_fork.s; }
+    if (fork) { sd = g_fork.s; s_dtail = g_fork.s; }
     if (fork2) { s_atail = g_fork.s; s_dtail = g_fork.s; }
-    const TileWork& twd = (fork || fork2) ? P.tw2 : P.tw;
+    // round 5: both counting sorts of the backward (masked list -> P.tw, valid list -> P.tw2) in ONE pair of launches, up front - the lists and the
+    // positions are the forward's; the density branch then always sorts into tw2 and keeps sharing the og buffer unless it runs on the side stream
+    const bool fl = fused_launch();
+    const bool want_asort = P.tiles && want_aplanes0, want_dsort = P.tiles && want_dplanes0;
+    const bool presort = fl && (want_asort || want_dsort);
+    TileWork twd_v = (fork || fork2 || presort) ? P.tw2 : P.tw;
+    if (presort && !(fork || fork2)) twd_v.og = P.tw.og;
+    const TileWork& twd = twd_v;
+    if (presort) {
+        const TileWork* wp[2]; const int* cp[2]; const int* lp[2]; int nj = 0;
+        if (want_asort) { wp[nj] = &P.tw; cp[nj] = P.counters + 1; lp[nj] = P.mlist; ++nj; }
+        if (want_dsort) { wp[nj] = &twd; cp[nj] = P.counters + 0; lp[nj] = P.vlist; ++nj; }
+        ProfScope ps(PK_DENSITY_SCATTER, st);
+        if (launch_tile_sort(wp, cp, lp, nj, P.xw, N, st)) return 1;
+    }
+    if (fork) { HIPCK(hipEventRecord(g_fork.fork, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork, 0)); }     // (behind the sorts)
     // deterministic mode: the scatters add fixed-point integers into int64 shadow planes; k_det_finish folds them into the gradients
     nvfi_grads gdet = *grads;
     int64_t det_off[12]; int64_t det_n = 0;
@@ -1374,9 +1612,11 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     }
     // fragments were packed by the forward into the same workspace
     VelFrags VW; RenderFrags RW; PackJobs dummy; dummy.n = 0;
-    if (f->use_vel && nsteps > 0) pack_vel_frags(f->vW, f->vb, P.vel_frag, &VW, &dummy);
+    FragCache FC; const bool cached = f->frags != nullptr;      // (... or live in the field's fragment cache: the same weights, the caller's contract)
+    if (cached) frag_cache_layout(f->frags, &FC);
+    if (f->use_vel && nsteps > 0) pack_vel_frags(f->vW, f->vb, cached ? FC.vel : P.vel_frag, &VW, &dummy);
     dummy.n = 0;
-    pack_render_frags(f, P.render_frag, &RW, &dummy);
+    pack_render_frags(f, cached ? FC.render : P.render_frag, &RW, &dummy);
     bool forked = false;
     // appearance branch
     AppArgs aa; memset(&aa, 0, sizeof(aa));
@@ -1398,7 +1638,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
             if (launch_og(f, oa, 48, nsteps > 0, N, st)) return 1;
             if (fork2) { HIPCK(hipEventRecord(g_fork.fork, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork, 0)); }
             if (want_aplanes) {
-                if (launch_tile_scatter(f, P.tw, P.counters + 1, P.mlist, P.xw, tn, *grads, 48, N, s_atail, sched)) return 1;
+                if (launch_tile_scatter(f, P.tw, P.counters + 1, P.mlist, P.xw, tn, *grads, 48, N, s_atail, sched, presort)) return 1;
             }
         }
     } else if (want_aplanes) {
@@ -1456,7 +1696,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         if (fork2) { HIPCK(hipEventRecord(g_fork.fork2, st)); HIPCK(hipStreamWaitEvent(g_fork.s, g_fork.fork2, 0)); }
         if (want_dplanes) {
             ProfScope ps(PK_DENSITY_SCATTER, s_dtail);
-            if (launch_tile_scatter(f, twd, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, s_dtail, sched)) return 1;
+            if (launch_tile_scatter(f, twd, P.counters + 0, P.vlist, P.xw, tn, *grads, 24, N, s_dtail, sched, presort)) return 1;
         }
         if (fork) { HIPCK(hipEventRecord(g_fork.join, g_fork.s)); HIPCK(hipStreamWaitEvent(st, g_fork.join, 0)); }
     } else if (nsteps > 0) { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
@@ -1497,11 +1737,13 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         if (split && fuse) {
             FuseBwdArgs fa; memset(&fa, 0, sizeof(fa));
             fa.r = ra; fa.slabs = vslabs; fa.layer_stride = (int64_t)NSLAB * SLAB_FLOATS; fa.slab_floats = SLAB_FLOATS;
-            if (pack_vel_x4_bwd(VW, P.vel_x4b, fa.t4, st)) return 1;
+            if (cached) x4b_pointers(FC.vel_x4b, fa.t4);
+            else if (pack_vel_x4_bwd(VW, P.vel_x4b, fa.t4, st)) return 1;
             if (launch_rk2_fuse_bwd(fa, N, NSLAB, &fused_nslab, st)) return 1;
         } else if (split) {   // vel_split.hip: same adjoint stash bit for bit
             SplitBwdArgs ba; ba.r = ra;
-            if (pack_vel_x4_bwd(VW, P.vel_x4b, ba.t4, st)) return 1;
+            if (cached) x4b_pointers(FC.vel_x4b, ba.t4);
+            else if (pack_vel_x4_bwd(VW, P.vel_x4b, ba.t4, st)) return 1;
             if (launch_rk2_split_bwd(ba, N, st)) return 1;
         } else if (launch_rk2_bwd(ra, N, st)) return 1;
         if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 3, (int)P.cap_tiles, 2 * nsteps, BM_SILU, vslabs, NSLAB,
@@ -1544,14 +1786,7 @@ int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, cons
 }
 
 __global__ void k_counters(const int* c, int nsteps, int64_t* out, const float* sched) {
-    if (threadIdx.x == 0) {
-        out[0] = c[0];
-        out[1] = nsteps > 0 ? c[3] : 0;
-        out[2] = c[1];
-        out[3] = (int64_t)(nsteps > 0 ? c[3] : 0) * 2 * nsteps;
-        out[4] = out[5] = out[6] = 0;
-        out[7] = sched ? __float_as_int(sched[3]) : 0;      // 1: the device-side time did not fit the planned RK2 step count (the planned time was rendered)
-    }
+    if (threadIdx.x == 0) counters_body(c, nsteps, out, sched);
 }
 
 // ================================================================ building blocks
@@ -1737,7 +1972,7 @@ extern "C" int nvfi_render_mask(const nvfi_field_desc* f, const nvfi_mask_desc* 
         const int MT = l < 4 ? 4 : 1, NS = l == 0 ? 2 : 64;
         J.W = m->W[l]; J.b = m->b[l]; J.frag = p; p += MT * NS * 64; J.bfrag = p; p += 128;
         J.out = l < 4 ? 128 : m->mask_dim; J.in = l == 0 ? 3 : 128; J.MT = MT; J.NS = NS;
-        J.row_kind = RK_NATURAL; J.slot_kind = l == 0 ? SK_XYZ : SK_HIDDEN; J.transposed = 0;
+        J.row_kind = RK_NATURAL; J.slot_kind = l == 0 ? SK_XYZ : SK_HIDDEN; J.transposed = 0; J.x4 = 0;
         a.W.f[l] = J.frag; a.W.b[l] = J.bfrag;
     }
     if (launch_pack(jobs, st)) return 1;

@@ -42,6 +42,8 @@ struct TileSortArgs {
     int* hist; int* cursor; int4* items; int* nitems; float4* sorted; int* start; int* istart;
 };
 
+struct TileSortArgs2 { TileSortArgs j[2]; };
+
 struct TileScatterArgs {
     nvfi_field_desc f;
     TileGeom geo;
@@ -56,6 +58,7 @@ void plan_tile_scatter(Bump& B, const nvfi_field_desc* f, int64_t N, TileWork* w
 int ensure_scatter_attrs();
 int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int64_t N, hipStream_t st);
 int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* count, const int* list, const float4* xw, float tn,
-                        const nvfi_grads& g, int C, int64_t N, hipStream_t st, const float* sched = nullptr);
+                        const nvfi_grads& g, int C, int64_t N, hipStream_t st, const float* sched = nullptr, bool sorted = false);
+int launch_tile_sort(const TileWork* const* w, const int* const* count, const int* const* list, int njobs, const float4* xw, int64_t N, hipStream_t st);
 int launch_app_feat(const OgArgs& oa, int64_t N, hipStream_t st);   // oa.og: feat[i][48], the appearance feature of masked sample i (Ca == 48)
 int launch_density_q(const DensityArgs& da, int64_t N, hipStream_t st);   // Cd == 24 only

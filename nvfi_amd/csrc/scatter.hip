@@ -254,8 +254,11 @@ __device__ __forceinline__ void bins_of(const TileGeom& g, const float4& q, int*
     b[2] = g.boff[2] + tile_of(q.y, q.z, g.G[1], g.G[2], g.ntx[2], g.nty[2], g.T, g.colmajor != 0);
 }
 
+// (round 5: blockIdx.y selects one of up to two sort jobs - the valid-sample list and the appearance-masked list of a render's backward are both
+//  known after the forward, so their counting sorts share the two launches)
 __device__ void tile_scan_block(const TileSortArgs& a);
-__global__ __launch_bounds__(512) void k_tile_hist(TileSortArgs a) {
+__global__ __launch_bounds__(512) void k_tile_hist(TileSortArgs2 a2) {
+    const TileSortArgs& a = a2.j[blockIdx.y];
     extern __shared__ int sh[];
     int* h = sh;
     const int nb = a.g.nbins;
@@ -337,7 +340,8 @@ __device__ void tile_scan_block(const TileSortArgs& a) {
     if (tid == 0) { a.start[nb] = t0; a.istart[nb] = t1; *a.nitems = t1; a.hist[nb] = 0; }
 }
 
-__global__ __launch_bounds__(512) void k_tile_fill(TileSortArgs a) {
+__global__ __launch_bounds__(512) void k_tile_fill(TileSortArgs2 a2) {
+    const TileSortArgs& a = a2.j[blockIdx.y];
     extern __shared__ int sh[];
     const int nb = a.g.nbins;
     int* cnt = sh; int* bas = sh + nb;
@@ -774,15 +778,30 @@ int launch_og(const nvfi_field_desc* f, const OgArgs& oa, int C, bool coord, int
     return 0;
 }
 
-int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* count, const int* list, const float4* xw, float tn,
-                        const nvfi_grads& g, int C, int64_t N, hipStream_t st, const float* sched) {
-    TileSortArgs sa; memset(&sa, 0, sizeof(sa));
-    sa.g = w.g; sa.count = count; sa.list = list; sa.xw = xw; sa.hist = w.hist; sa.cursor = w.cursor; sa.items = w.items; sa.nitems = w.nitems; sa.sorted = w.sorted; sa.start = w.start; sa.istart = w.istart;
-    const int nb = w.g.nbins;
+// counting sort of one or two compact lists by plane tile (w[j], count[j], list[j]; same geometry, same positions xw): two launches
+int launch_tile_sort(const TileWork* const* w, const int* const* count, const int* const* list, int njobs, const float4* xw, int64_t N, hipStream_t st) {
+    TileSortArgs2 s2; memset(&s2, 0, sizeof(s2));
+    for (int j = 0; j < njobs; ++j) {
+        TileSortArgs& sa = s2.j[j];
+        const TileWork& t = *w[j];
+        sa.g = t.g; sa.count = count[j]; sa.list = list[j]; sa.xw = xw; sa.hist = t.hist; sa.cursor = t.cursor; sa.items = t.items; sa.nitems = t.nitems; sa.sorted = t.sorted; sa.start = t.start; sa.istart = t.istart;
+    }
+    const int nb = w[0]->g.nbins;
     unsigned hb = (unsigned)((N + 511) / 512); if (hb > 512) hb = 512;
     const size_t hist_lds = sizeof(int) * 2 * (size_t)(nb + (nb >> 4) + 1);      // the histogram, then the scan's two transposed rows
-    hipLaunchKernelGGL(k_tile_hist, dim3(hb), dim3(512), hist_lds, st, sa);
-    hipLaunchKernelGGL(k_tile_fill, dim3((unsigned)((N + 511) / 512)), dim3(512), sizeof(int) * 2 * nb, st, sa);
+    hipLaunchKernelGGL(k_tile_hist, dim3(hb, njobs), dim3(512), hist_lds, st, s2);
+    hipLaunchKernelGGL(k_tile_fill, dim3((unsigned)((N + 511) / 512), njobs), dim3(512), sizeof(int) * 2 * nb, st, s2);
+    LAUNCHCK();
+    return 0;
+}
+
+// sorted: the list was already sorted into w by launch_tile_sort (round 5: both lists of a backward in one pair of launches)
+int launch_tile_scatter(const nvfi_field_desc* f, const TileWork& w, const int* count, const int* list, const float4* xw, float tn,
+                        const nvfi_grads& g, int C, int64_t N, hipStream_t st, const float* sched, bool sorted) {
+    if (!sorted) {
+        const TileWork* wp[1] = {&w}; const int* cp[1] = {count}; const int* lp[1] = {list};
+        if (launch_tile_sort(wp, cp, lp, 1, xw, N, st)) return 1;
+    }
     TileScatterArgs ta; memset(&ta, 0, sizeof(ta));
     ta.f = *f; ta.geo = w.g; ta.items = w.items; ta.nitems = w.nitems; ta.sorted = w.sorted; ta.list = list; ta.xw = xw; ta.og = w.og; ta.tn = tn;
     ta.g = g; ta.sched = sched;

@@ -232,7 +232,7 @@ int pack_vel_frags(const float* const* W, const float* const* b, float* buf, Vel
         if (jobs->n >= MAX_PACK_JOBS) return 1;
         PackJob& J = jobs->j[jobs->n++];
         J.W = Wl; J.b = bl; J.frag = frag; J.bfrag = bfrag; J.out = o; J.in = in; J.MT = MT; J.NS = NS;
-        J.row_kind = rk; J.slot_kind = sk; J.transposed = tr;
+        J.row_kind = rk; J.slot_kind = sk; J.transposed = tr; J.x4 = 0;
         return 0;
     };
     float* f0 = p; p += VEL_F0;

@@ -574,9 +574,33 @@ class TensorVMKeyframeTimeKplane(nn.Module):
                 child.__dict__["_owner"] = weakref.ref(new)
         return new
 
+    def _host_state(self):
+        """every host-side attribute nvfi_field_desc's scalar fields are derived from (attributes a caller may assign at any time)"""
+        am = self.alphaMask
+        vel = self.__dict__["_modules"].get("vel") if self.use_vel else None
+        return (self.nSamples, self._step_host, id(self._aabb_host), id(self._grid_host), self.num_keyframes, self.use_vel, self.shadingMode,
+                self.vel_fp16, self.__dict__.get("vel_fp16_train", False), self.density_shift, self.distance_scale, self.rayMarch_weight_thres,
+                self.alphaMask_thres, self.tmax, self.near_far[0], self.near_far[1], self.app_dim,
+                0 if am is None else am.alpha_volume.data_ptr(), id(vel), getattr(vel, "eps", None) if vel is not None else None)
+
     def _desc(self, params=None):
-        """nvfi_field_desc for the current parameters (or for the tensors saved by autograd)."""
+        """nvfi_field_desc for the current parameters (or for the tensors saved by autograd).  Building the ctypes struct costs ~25 us of
+        host time and a training iteration makes eight of them, so the struct is cached and re-validated by the parameters' device
+        pointers and the host attributes it is derived from; the caller gets a private copy (the backward edits vel_fp16).  `frags`
+        (ABI v5) points at the field's fragment cache when that is current for these weights (_frags)."""
         ps = self._render_params() if params is None else list(params)
+        pp = self._pde_params() if self.use_vel else []
+        key = (tuple(0 if p is None else p.data_ptr() for p in ps), tuple(p.data_ptr() for p in pp[12:]), self._host_state())
+        rt = _rt(self)
+        c = rt.get("_desc_cache")
+        if c is None or c[0] != key:
+            c = (key, self._desc_build(ps, pp))
+            rt["_desc_cache"] = c
+        d = _lib.FieldDesc.from_buffer_copy(c[1])
+        d.frags = self._frags(d, ps, pp)
+        return d
+
+    def _desc_build(self, ps, pp):
         d = _lib.FieldDesc()
         d.G[:] = self._grid_host
         d.K = int(self.num_keyframes)
@@ -606,7 +630,6 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             if len(ps) >= 31:
                 for i in range(6):
                     d.vW[i] = _lib.ptr(ps[19 + 2 * i]); d.vb[i] = _lib.ptr(ps[20 + 2 * i])
-            pp = self._pde_params()
             for i in range(6):
                 d.aW[i] = _lib.ptr(pp[12 + 2 * i]); d.ab[i] = _lib.ptr(pp[13 + 2 * i])
         if self.alphaMask is not None:
@@ -614,7 +637,61 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             v = self.alphaMask.alpha_volume
             d.am_dims[:] = [v.shape[-1], v.shape[-2], v.shape[-3]]
             d.amask = _lib.ptr(v)
+        d.frags = None
         return d
+
+    # ------------------------------------------------------------------ fragment cache (ABI v5: nvfi_pack_frags)
+    def _frags(self, d, ps, pp):
+        """Device pointer of the field's fragment cache, current for the weights `d` describes - or None (the call then repacks into its
+        own workspace).  The cache is keyed on (data_ptr, _version) of every nn.Linear tensor it is built from plus the generation counter
+        of nvfi_amd.optim.Adam (whose HIP launch does not pass through torch's version counter): the first call after an optimiser step
+        repacks - ONE launch on the current stream instead of 7 across the iteration's calls - and later calls on other streams wait for
+        that launch once.  An in-place edit through `.data` bumps neither: call invalidate_frags().  NVFI_FRAG_CACHE=0 switches it off."""
+        rt = _rt(self)
+        on = rt.get("_frag_on")
+        if on is None:
+            on = rt["_frag_on"] = os.environ.get("NVFI_FRAG_CACHE", "1") != "0"
+        if not on or not ps[0].is_cuda:
+            return None
+        from .. import optim as _optim
+        lin = [p for p in ps[12:] if p is not None] + list(pp[12:])
+        key = (tuple(p.data_ptr() for p in lin), tuple(p._version for p in lin), _optim.GENERATION, rt.get("_frag_epoch", 0))
+        fc = rt.get("_frag_cache")
+        cur = torch.cuda.current_stream()
+        if fc is None or fc["key"] != key or fc["buf"].device != ps[0].device:
+            if torch.cuda.is_current_stream_capturing() and not rt.get("_frag_capture_ok"):
+                return None         # (a captured iteration repacks explicitly at its head: repack_frags(); anything else packs per call)
+            L = _lib.lib()
+            buf = fc["buf"] if fc is not None and fc["buf"].device == ps[0].device else None
+            if buf is None:
+                nb = C.c_int64(0)
+                _lib.check(L.nvfi_frag_cache_bytes(C.byref(d), C.byref(nb)))
+                buf = torch.empty(nb.value, dtype=torch.uint8, device=ps[0].device)
+            d.frags = None
+            _lib.check(L.nvfi_pack_frags(C.byref(d), _lib.ptr(buf), C.c_int64(buf.numel()), C.c_void_p(cur.cuda_stream)))
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            fc = rt["_frag_cache"] = dict(key=key, buf=buf, event=ev, stream=cur, waited=set())
+        elif cur != fc["stream"] and cur.cuda_stream not in fc["waited"]:
+            cur.wait_event(fc["event"])
+            fc["waited"].add(cur.cuda_stream)
+        return fc["buf"].data_ptr()
+
+    def invalidate_frags(self):
+        """the weights were edited behind torch's version counters (p.data.copy_(), a raw kernel): the next call repacks"""
+        rt = _rt(self)
+        rt["_frag_epoch"] = rt.get("_frag_epoch", 0) + 1
+
+    def repack_frags(self):
+        """Repack the fragment cache NOW on the current stream (one launch) whatever its key says, and leave it current: a driver that forks
+        the iteration's chains over several streams - or captures the iteration as a hipGraph - calls this at the head of the iteration."""
+        self.invalidate_frags()
+        rt = _rt(self)
+        rt["_frag_capture_ok"] = True
+        try:
+            self._desc()
+        finally:
+            rt["_frag_capture_ok"] = False
 
     def _grads_struct(self, grads):
         G = _lib.Grads()

@@ -11,6 +11,11 @@ import torch
 from . import _lib
 
 
+# bumped by every step(): nvfi_adam_step writes the parameters through raw pointers, so torch's per-tensor version counters do not move;
+# caches keyed on the weights (the fields' fragment caches, models/tensorf_keyframe.py:_frags) include this counter
+GENERATION = 0
+
+
 class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or eps < 0 or lr < 0:
@@ -83,6 +88,8 @@ class Adam(torch.optim.Optimizer):
                     p.grad = g
                 batches.setdefault((float(b1), float(b2), float(group["eps"]), st["step"]), []).append((p, g, st, lr))
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        global GENERATION
+        GENERATION += 1
         cache = self.__dict__.setdefault("_tables", {})
         for key, items in batches.items():
             b1, b2, eps, step = key

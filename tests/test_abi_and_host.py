@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/nvfi_hip.h but not exported"
     assert set(_lib.EXPORTS) <= set(names)
-    assert _lib.lib().nvfi_abi_version() == 4
+    assert _lib.lib().nvfi_abi_version() == 5
 
 
 def test_struct_layout_matches_header():
