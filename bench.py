@@ -246,153 +246,167 @@ class Step:
             if os.environ.get("NVFI_PRIO_R2") is not None:
                 self.s_r2 = torch.cuda.Stream(device=device, priority=int(os.environ["NVFI_PRIO_R2"]))
 
-    def rays(self):
-        from nvfi_amd.models import Ray
-        idx = torch.randint(0, self.o.shape[0], (self.n_rays,), device=self.dev, generator=self.gen)
-        target = torch.rand(self.n_rays, 3, device=self.dev, generator=self.gen)
-        return Ray(self.o[idx], self.d[idx], self.scene["near"], self.scene["far"]), target
+    # ---- the iteration's random inputs: ONE launch (nvfi_draw_batch) + ONE upload (the reference's CPU-generator jitter of both renders)
+    def _draw_setup(self):
+        from nvfi_amd import _lib
+        R, P, dev = self.n_rays, self.n_pts, self.dev
+        nb = self.renders = 2 if self.workload == "cfg3" else 1
+        self.d_ro = [torch.empty(R, 3, device=dev) for _ in range(nb)]
+        self.d_rd = [torch.empty(R, 3, device=dev) for _ in range(nb)]
+        self.d_tg = [torch.empty(R, 3, device=dev) for _ in range(nb)]
+        self.d_pts = torch.empty(P, 3, device=dev) if self.workload == "cfg3" else None
+        self.d_t = torch.empty(P, device=dev) if self.workload == "cfg3" else None
+        d = _lib.DrawDesc()
+        d.seed = 233 + self.rank
+        d.n_batches, d.R, d.n_pixels = nb, R, self.o.shape[0]
+        d.bundle_o, d.bundle_d, d.target_img = _lib.ptr(self.o), _lib.ptr(self.d), None      # synthetic targets: uniform in [0, 1)
+        for b in range(nb):
+            d.rays_o[b], d.rays_d[b], d.target[b] = _lib.ptr(self.d_ro[b]), _lib.ptr(self.d_rd[b]), _lib.ptr(self.d_tg[b])
+        if self.d_pts is not None:
+            d.P = P
+            d.aabb[:] = [float(v) for v in self.m.nvfi.aabb.reshape(-1).tolist()]
+            d.points, d.t = _lib.ptr(self.d_pts), _lib.ptr(self.d_t)
+        self.draw_desc = d
+        self.draw_it = 0
+        self.jit_dev = torch.empty(nb * R, device=dev)
+        self.jit_ring = [[torch.empty(nb * R, 1).pin_memory(), None] for _ in range(4)]
+
+    def draw(self, it_dev=None):
+        """pixel batches + targets of the iteration's renders and the PDE collocation points / times: one launch on the current stream
+        (it_dev: the iteration counter in device memory - hipGraph replay)"""
+        from nvfi_amd import _lib
+        d = self.draw_desc
+        d.seed = self.seed_override if getattr(self, "seed_override", None) is not None else 233 + self.rank
+        if it_dev is None:
+            self.draw_it += 1
+            d.iteration, d.iteration_dev = self.draw_it, None
+        else:
+            d.iteration_dev = _lib.ptr(it_dev)
+        _lib.check(_lib.lib().nvfi_draw_batch(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def jitter(self):
+        """the per-ray jitter of the iteration's renders - the reference's CPU-generator draw (tensorf_base.py:302-306), non-keyframe render
+        first - through a ring of pinned buffers: one asynchronous upload per iteration"""
+        slot = self.jit_ring[self.draw_it % len(self.jit_ring)]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        R = self.n_rays
+        for k in range(self.renders):
+            torch.rand(R, 1, out=slot[0][k * R:(k + 1) * R])
+        self.jit_dev.copy_(slot[0].view(-1), non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return [self.jit_dev[k * R:(k + 1) * R] for k in range(self.renders)]
+
+    def frame_times(self):
+        """the host's draws of an iteration: a non-keyframe frame i/60 and a keyframe time (cfg3), or any frame time (radiance-only)"""
+        if self.workload == "cfg3":
+            i = int(self.rng.integers(0, 46))
+            while i % self.kf == 0:                 # frame times i/60; keyframes every 0.05 = 3/60 (bat), 0.25 = 15/60 (chessboard)
+                i = int(self.rng.integers(0, 46))
+            return i / 60.0, self.kf * int(self.rng.integers(0, self.scene["K"])) / 60.0
+        return None, float(self.rng.integers(0, 46)) / 60.0      # radiance-only: continuous time rows
+
+    def _pde_term(self):
+        m, f = self.m, self.m.nvfi
+        self.vw *= self.lr_factor
+        # same term as `loss += vw * get_vel_loss()`, fused: d(vw * loss_vel) is accumulated by the PDE kernels - straight into
+        # .grad on one GPU, through a small staging buffer re-weighted by W*n_r/sum(n_r) (device-side) on several
+        m.vel_loss_weight = self.vw
+        if self.world > 1:
+            self.pde_stage.zero()
+            m.vel_grad_targets = self.pde_stage.views
+        self.last_lv = m.get_vel_loss(self.n_pts, points=self.d_pts, t=self.d_t)
+        self.pde_counters.append(f.last_pde_counters)
+        return f.last_pde_out
+
+    def _render_term(self, t, k, jit, wait=None):
+        """one training render + its mse + the backward of both, gradients accumulated in place (field.render_mse_backward_)"""
+        f = self.m.nvfi
+        loss, _ = f.render_mse_backward_(t, self.d_ro[k], self.d_rd[k], self.d_tg[k], white_bg=self.white_bg, jitter=jit, wait_before_backward=wait)
+        self.counters.append(f.last_counters)
+        return loss
 
     def __call__(self):
+        """Round 5: no torch launch and no autograd graph in the iteration.  Per step: one draw launch, one jitter upload, one fragment repack,
+        the PDE term, the two renders (forward + mse + backward each), the regulariser pass, the Adam launch - on three streams when the
+        driver overlaps the chains, the gradient exchange of several ranks in between."""
         m, f = self.m, self.m.nvfi
         if not m.training:
             m.train()
         if not (self.fused_zero and self.stepped):   # after the first step the Adam launch has already cleared the gradients
             self.bucket.zero()
-        loss = 0
-
-        def pde_term():
-            self.vw *= self.lr_factor
-            # same term as `loss += vw * get_vel_loss()`, fused: d(vw * loss_vel) is accumulated by the PDE kernels - straight into
-            # .grad on one GPU, through a small staging buffer re-weighted by W*n_r/sum(n_r) (device-side) on several
-            m.vel_loss_weight = self.vw
-            if self.world > 1:
-                self.pde_stage.zero()
-                m.vel_grad_targets = self.pde_stage.views
-            self.last_lv = m.get_vel_loss(self.n_pts)
-            self.pde_counters.append(f.last_pde_counters)
-            if self.world > 1:
-                self.pde_stage.commit_device(f.last_pde_out)
-
-        # Several GPUs: the PDE term goes LAST, so that the all-reduce of the plane / render-MLP gradients (38 MB, final after the
-        # renders) runs underneath it.  One GPU: first (order is immaterial: no call on this path waits for the device).
-        overlap = self.world > 1 and self.tail_off is not None and self.comm is None
-        if self.streams is not None:
-            return self._step_streams()
-        if self.workload == "cfg3" and not overlap:
-            pde_term()
-        if self.workload == "cfg3":
-            i = int(self.rng.integers(0, 46))
-            while i % self.kf == 0:                 # frame times i/60; keyframes every 0.05 = 3/60 (bat), 0.25 = 15/60 (chessboard)
-                i = int(self.rng.integers(0, 46))
-            rays, target = self.rays()
-            out = self.ren.render(i / 60.0, rays, white_background=self.white_bg, mode="train")
-            loss = loss + mse_loss(out[0], target)
-            self.counters.append(f.last_counters)
-            t_key = self.kf * int(self.rng.integers(0, self.scene["K"])) / 60.0
-        else:
-            t_key = float(self.rng.integers(0, 46)) / 60.0   # radiance-only: continuous time rows
-        rays, target = self.rays()
-        self.L1w *= self.lr_factor; self.tvd *= self.lr_factor; self.tva *= self.lr_factor
-        early_regs = self.fused_regs and self.world == 1 and self.fused_zero and self.stepped and os.environ.get("NVFI_EARLY_REGS", "1") != "0"
-        if early_regs:
-            # the regulariser pass (value + gradient of L1 / TV: a plain read-modify-write of the plane gradients) does not depend on the renders:
-            # it runs on a side stream beside the forward pass - the gradients are zero at this point (the Adam launch cleared them) - and the
-            # backward, whose scatters add atomically on top, waits for it
-            if getattr(self, "_s_reg", None) is None:
-                self._s_reg = torch.cuda.Stream(device=self.dev)
-            main = torch.cuda.current_stream()
-            self._s_reg.wait_stream(main)
-            with torch.cuda.stream(self._s_reg):
-                self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
-        out = self.ren.render(t_key, rays, white_background=self.white_bg, mode="train")
-        loss = loss + mse_loss(out[0], target)
-        self.counters.append(f.last_counters)
-        if not self.fused_regs:
-            loss = loss + self.L1w * f.density_L1() + self.tvd * f.TV_loss_density(self.tv) + self.tva * f.TV_loss_app(self.tv)
-        if early_regs:
-            torch.cuda.current_stream().wait_stream(self._s_reg)
-        loss.backward()
-        if self.fused_regs and not early_regs:   # same regularisers + their gradients, fused into one pass per plane (nvfi_plane_regs)
-            self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
-        if overlap:
-            h = self.bucket.all_reduce_head_start(self.tail_off)
-            if self.workload == "cfg3":
-                pde_term()
-            self.bucket.all_reduce_finish(h, self.tail_off)
-        else:
-            self.bucket.all_reduce_mean(self.comm)
-        if self.fused_zero:
-            self.opt.step(zero_grad=True); self.stepped = True
-        else:
-            self.opt.step()
-        for g in self.opt.param_groups:
-            g["lr"] = g["lr"] * self.lr_factor
-        return loss
-
-
-    def _step_streams(self):
-        """Same iteration, three streams: PDE term | non-keyframe render (forward + backward) | keyframe render (forward + backward);
-        the regularisers and the optimiser step follow on the main stream once the three have joined (several ranks: the gradient all-reduce
-        of the renders' share starts as soon as the two renders are done, underneath the PDE chain)."""
-        m, f = self.m, self.m.nvfi
+        if getattr(self, "draw_desc", None) is None:
+            self._draw_setup()
         main = torch.cuda.current_stream()
-        s_pde, s_r1 = self.streams
-        start = torch.cuda.Event(); start.record(main)
-        i = int(self.rng.integers(0, 46))
-        while i % self.kf == 0:
-            i = int(self.rng.integers(0, 46))
-        t_key = self.kf * int(self.rng.integers(0, self.scene["K"])) / 60.0
         multi = self.world > 1
-        with torch.cuda.stream(s_pde):
-            s_pde.wait_event(start)
-            self.vw *= self.lr_factor
-            m.vel_loss_weight = self.vw
-            if multi:      # several ranks: the PDE gradients go through the staging buffer (re-weighted by W*n_r/sum(n_r) at the commit)
-                self.pde_stage.zero()
-                m.vel_grad_targets = self.pde_stage.views
-            self.last_lv = m.get_vel_loss(self.n_pts)
-            self.pde_counters.append(f.last_pde_counters)
-            pde_out = f.last_pde_out
-        with torch.cuda.stream(s_r1):
-            s_r1.wait_event(start)
-            rays, target = self.rays()
-            out = self.ren.render(i / 60.0, rays, white_background=self.white_bg, mode="train")
-            c1 = f.last_counters
-            mse_loss(out[0], target).backward()
-        if self.s_r2 is not None:
-            with torch.cuda.stream(self.s_r2):
-                self.s_r2.wait_event(start)
-                rays, target = self.rays()
-                out = self.ren.render(t_key, rays, white_background=self.white_bg, mode="train")
-                c2 = f.last_counters
-                loss = mse_loss(out[0], target)
-                loss.backward()
-            main.wait_stream(self.s_r2)
-        else:
-            rays, target = self.rays()
-            out = self.ren.render(t_key, rays, white_background=self.white_bg, mode="train")
-            c2 = f.last_counters
-            loss = mse_loss(out[0], target)
-            loss.backward()
-        self.counters += [c1, c2]
+        cfg3 = self.workload == "cfg3"
+        t1, t_key = self.frame_times()
+        self.draw()
+        jit = self.jitter()
+        f.repack_frags()           # the weights changed in the last optimiser step: every fragment set in one launch, before the chains fork
         self.L1w *= self.lr_factor; self.tvd *= self.lr_factor; self.tva *= self.lr_factor
-        if not multi:
-            main.wait_stream(s_pde); main.wait_stream(s_r1)
-            self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
-        else:
-            # the renders are done first: their gradients (planes, basis, render MLP = the head of the flat buffer, 38 MB) start their
-            # all-reduce on RCCL's stream while the PDE chain is still running on its own; the tail (velocity nets) follows its commit
+        streams = self.streams if cfg3 else None
+        pde_out, early_regs = None, False
+        if streams is not None:
+            # PDE term | non-keyframe render | keyframe render on three streams; the regularisers and the optimiser step follow on the main stream
+            # once the three have joined (several ranks: the all-reduce of the renders' share starts underneath the PDE chain)
+            s_pde, s_r1 = streams
+            start = torch.cuda.Event(); start.record(main)
+            with torch.cuda.stream(s_pde):
+                s_pde.wait_event(start)
+                pde_out = self._pde_term()
+            with torch.cuda.stream(s_r1):
+                s_r1.wait_event(start)
+                self._render_term(t1, 0, jit[0])
+            if self.s_r2 is not None:
+                with torch.cuda.stream(self.s_r2):
+                    self.s_r2.wait_event(start)
+                    loss = self._render_term(t_key, 1, jit[1])
+                main.wait_stream(self.s_r2)
+            else:
+                loss = self._render_term(t_key, 1, jit[1])
             main.wait_stream(s_r1)
+            if not multi:
+                main.wait_stream(s_pde)
+        else:
+            # one stream.  Several GPUs: the PDE term goes LAST, so that the all-reduce of the plane / render-MLP gradients (38 MB, final after
+            # the renders) runs underneath it; one GPU: first (order is immaterial: no call on this path waits for the device)
+            overlap1 = multi and self.tail_off is not None and self.comm is None
+            if cfg3 and not overlap1:
+                pde_out = self._pde_term()
+            if cfg3:
+                self._render_term(t1, 0, jit[0])
+            # single chain: the regulariser pass (a plain read-modify-write of the plane gradients; they are zero here - the Adam launch cleared them)
+            # runs on a side stream beside the forward half of the render; the backward half, whose scatters add atomically on top, waits for it
+            early_regs = not cfg3 and not multi and self.fused_zero and self.stepped and os.environ.get("NVFI_EARLY_REGS", "1") != "0"
+            if early_regs:
+                if getattr(self, "_s_reg", None) is None:
+                    self._s_reg = torch.cuda.Stream(device=self.dev)
+                self._s_reg.wait_stream(main)
+                with torch.cuda.stream(self._s_reg):
+                    self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
+            loss = self._render_term(t_key, self.renders - 1, jit[-1], wait=self._s_reg if early_regs else None)
+        if not (streams is None and early_regs):
             self.last_regs = f.regularizers_backward_(self.L1w, self.tvd, self.tva)
+        if multi:
             split = self.tail_off is not None and self.comm is None
             h = self.bucket.all_reduce_head_start(self.tail_off) if split else None
-            main.wait_stream(s_pde)
-            self.pde_stage.commit_device(pde_out)
+            if streams is not None:
+                main.wait_stream(streams[0])
+            elif cfg3 and pde_out is None:
+                pde_out = self._pde_term()
+            if cfg3:
+                self.pde_stage.commit_device(pde_out)
             if split:
                 self.bucket.all_reduce_finish(h, self.tail_off)
             else:
                 self.bucket.all_reduce_mean(self.comm)
-        self.opt.step(zero_grad=True); self.stepped = True
+        if self.fused_zero:
+            self.opt.step(zero_grad=True); self.stepped = True
+        else:
+            self.opt.step()
         for g in self.opt.param_groups:
             g["lr"] = g["lr"] * self.lr_factor
         return loss
@@ -453,49 +467,48 @@ class GraphedStep:
         # the per-ray jitter of the renders: the reference's CPU-generator draw (tensorf_base.py:302-306), non-keyframe render first
         for k in range(self.renders):
             torch.rand(s.n_rays, 1, out=buf[self.off_jit + k * s.n_rays: self.off_jit + (k + 1) * s.n_rays].view(s.n_rays, 1))
+        s.draw_it += 1
+        buf[8:10].view(torch.int64)[0] = s.draw_it         # the iteration counter of nvfi_draw_batch (rec[8:10] as one int64)
         self.rec.copy_(buf, non_blocking=True)
         if slot[1] is None:
             slot[1] = torch.cuda.Event()
         slot[1].record()
 
     def body(self):
-        """the device side of one iteration; every per-iteration scalar is a view of self.rec"""
+        """the device side of one iteration (Step.__call__'s launches); every per-iteration scalar is a view of self.rec"""
         s, rec, DT = self.s, self.rec, self.DeviceTime
         m, f = s.m, s.m.nvfi
         R = s.n_rays
         jit = [rec[self.off_jit + k * R: self.off_jit + (k + 1) * R] for k in range(self.renders)]
         main = torch.cuda.current_stream()
-        if s.workload == "cfg3":
+        if getattr(s, "draw_desc", None) is None:
+            s._draw_setup()
+        s.draw(it_dev=rec[8:10].view(torch.int64))
+        f.repack_frags()
+        cfg3 = s.workload == "cfg3"
+        if cfg3:
             s_pde, s_r1 = s.streams if s.streams is not None else (main, main)
             start = torch.cuda.Event(); start.record(main)
             with torch.cuda.stream(s_pde):
                 s_pde.wait_event(start)
                 m.vel_loss_weight = rec[5:6]
-                s.last_lv = m.get_vel_loss(s.n_pts)
+                s.last_lv = m.get_vel_loss(s.n_pts, points=s.d_pts, t=s.d_t)
             with torch.cuda.stream(s_r1):
                 s_r1.wait_event(start)
-                rays, target = s.rays()
-                f.jitter_override = jit[0]
-                out = s.ren.render(DT(19.0 / 60.0, rec[0:1]), rays, white_background=True, mode="train")      # plan: a non-keyframe time (1 RK2 step)
+                f.render_mse_backward_(DT(19.0 / 60.0, rec[0:1]), s.d_ro[0], s.d_rd[0], s.d_tg[0], white_bg=True, jitter=jit[0])      # plan: a non-keyframe time (1 RK2 step)
                 self.flags.append(f.last_counters)
-                mse_loss(out[0], target).backward()
-        rays, target = s.rays()
-        early_regs = s.workload != "cfg3" and os.environ.get("NVFI_EARLY_REGS", "1") != "0"      # single chain: the regulariser pass beside the forward (Step.__call__)
+        early_regs = not cfg3 and os.environ.get("NVFI_EARLY_REGS", "1") != "0"      # single chain: the regulariser pass beside the forward (Step.__call__)
         if early_regs:
             if getattr(s, "_s_reg", None) is None:
                 s._s_reg = torch.cuda.Stream(device=s.dev)
             s._s_reg.wait_stream(main)
             with torch.cuda.stream(s._s_reg):
                 s.last_regs = f.regularizers_backward_(rec[2:5])
-        f.jitter_override = jit[-1]
-        out = s.ren.render(DT(0.05 if s.workload == "cfg3" else 0.3, rec[1:2]), rays, white_background=True, mode="train")   # plan: a keyframe time / any time without a velocity field
-        f.jitter_override = None
+        # plan: a keyframe time / any time without a velocity field
+        loss, _ = f.render_mse_backward_(DT(0.05 if cfg3 else 0.3, rec[1:2]), s.d_ro[-1], s.d_rd[-1], s.d_tg[-1], white_bg=True, jitter=jit[-1],
+                                         wait_before_backward=s._s_reg if early_regs else None)
         self.flags.append(f.last_counters)
-        loss = mse_loss(out[0], target)
-        if early_regs:
-            main.wait_stream(s._s_reg)
-        loss.backward()
-        if s.workload == "cfg3":
+        if cfg3:
             main.wait_stream(s_pde); main.wait_stream(s_r1)
         if not early_regs:
             s.last_regs = f.regularizers_backward_(rec[2:5])
@@ -516,7 +529,6 @@ class GraphedStep:
         self.host_record()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        g.register_generator_state(s.gen)
         with torch.cuda.graph(g, stream=cap):
             self.body()
         self.graph = g
@@ -702,6 +714,8 @@ class DropinStep:
             for p, s in self.pairs:
                 s.grad = p.grad
         self.opt.step()
+        if not self.live:
+            f.invalidate_frags()     # stationary mode: the optimiser moved a shadow copy - the next iteration repacks the fragment cache as a real step's would
         for g in self.opt.param_groups:
             g["lr"] = g["lr"] * self.lr_factor
         mark()
@@ -785,28 +799,8 @@ def segm_main(args, device):
     print(json.dumps(out))
 
 
-def segm_cpu_baseline(model, step):
-    """the oracle's MaskField forward + parameter gradients (plain C, OpenMP) on a bounded sample of the step's points; the advection is not in
-    the sample (the oracle's integrate_pos is the same net evaluated point by point: it is timed by the cfg3 baseline)"""
-    from oracle import oracle as orc
-    threads = min(64, os.cpu_count() or 1)
-    orc.set_threads(threads)
-    N = 32768
-    rng = np.random.default_rng(3)
-    pts = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
-    g = rng.standard_normal((N, 8)).astype(np.float32)
-    ps = [p.detach().cpu().numpy() for p in step.mf.parameters()]
-    orc.maskfield(ps, pts[:1024], g[:1024])
-    t0 = time.perf_counter(); n = 0
-    while time.perf_counter() - t0 < 8 and n < 3:
-        orc.maskfield(ps, pts, g); n += 1
-    dt = (time.perf_counter() - t0) / n
-    return dict(value=N / dt, unit="points/s", cores=threads, kind="port",
-                sample=f"oracle/nvfi_oracle.c orc_maskfield (OpenMP x{threads}): forward + parameter gradients of {N} points, {n} reps (MaskField part of the step only)")
-
-
-def cpu_baseline(model, workload, seconds_hint=20, scene="bat"):
-    """Oracle (C restatement, OpenMP) on a bounded sample of the same step: 256+256 rays, P=32768 (chessboard at 688 samples per ray: 64+64 rays, P=16384)."""
+def _oracle_field(model, scene):
+    """the oracle's view of the field (FieldSpec) from the product module's state_dict"""
     from oracle import oracle as orc
     f = model.nvfi
     sd = {k[len("nvfi."):]: v.detach().cpu().contiguous().numpy() for k, v in model.state_dict().items() if not k.startswith("nvfi.vel.vel_net.")}
@@ -814,11 +808,58 @@ def cpu_baseline(model, workload, seconds_hint=20, scene="bat"):
                 near=f.near_far[0], far=f.near_far[1], step_ratio=f.step_ratio, max_n_samples=f.max_n_samples,
                 density_shift=f.density_shift, distance_scale=f.distance_scale, alphaMask_thres=f.alphaMask_thres,
                 rayMarch_weight_thres=f.rayMarch_weight_thres, stepSize=f._step_host, nSamples=f.nSamples, use_sur=0, eps=0.03)
-    sc = SCENES[scene]
     if scene == "chessboard":
         meta.update(use_sur=1, sur_bounds=f.vel.bounds.detach().float().cpu().numpy().reshape(2, 3))
         del meta["eps"]
-    fs = orc.FieldSpec(sd, meta)
+    return orc.FieldSpec(sd, meta)
+
+
+def segm_cpu_baseline(model, step):
+    """The WHOLE step of train_segm.py:127-198 on the oracle (plain C, OpenMP), like for like with the GPU line: density of the 64^3 jittered lattice at
+    t = 0 -> occupied points -> integrate_pos to a time in [0.5, tmax] (the RK2 advection is most of the step's FLOPs) -> MaskField forward +
+    parameter gradients.  One warm-up step, then whole steps for ~10 s."""
+    from oracle import oracle as orc
+    from nvfi_amd.utils.segm_utils import sample_volume_points
+    threads = min(64, os.cpu_count() or 1)
+    orc.set_threads(threads)
+    f = model.nvfi
+    fs = _oracle_field(model, "chessboard")
+    ab = f._aabb_host
+    bounds = [[ab[0], ab[3]], [ab[1], ab[4]], [ab[2], ab[5]]]
+    lo, hi = np.array(ab[:3], np.float32), np.array(ab[3:], np.float32)
+    ps = [p.detach().cpu().numpy() for p in step.mf.parameters()]
+    rng = np.random.default_rng(3)
+    res = step.res
+
+    def one():
+        xyz_w = sample_volume_points(bounds, res, perturb=True).reshape(-1, 3).numpy()
+        xyz = ((xyz_w - lo) * (2.0 / (hi - lo)) - 1.0).astype(np.float32)
+        feat = orc.density_feature(fs, np.concatenate([xyz, np.full((xyz.shape[0], 1), -1.0, np.float32)], 1))      # normalised time of t = 0
+        sigma = orc.feature2density(fs, feat[:, 0])
+        alpha = 1.0 - np.exp(-sigma * 0.01)
+        occ = xyz[alpha > f.alphaMask_thres * 10.0]
+        t = float(0.5 + (f.tmax - 0.5) * rng.uniform())
+        n = occ.shape[0]
+        orc.integrate_pos(fs, occ, np.zeros(n, np.float32), np.full(n, t, np.float32))
+        g = rng.standard_normal((n, 8)).astype(np.float32)
+        orc.maskfield(ps, occ, g)
+        return n
+
+    one()
+    t0 = time.perf_counter(); reps = 0; pts = 0
+    while time.perf_counter() - t0 < 10 and reps < 8:
+        pts += one(); reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=pts / reps / dt, unit="points/s", cores=threads, kind="port", s_per_step=dt, points_per_step=pts / reps,
+                sample=f"oracle/nvfi_oracle.c (OpenMP x{threads}), the whole step: orc_density_feature on the {res}^3 lattice + orc_integrate_pos of the occupied points "
+                       f"(same time range as the GPU line) + orc_maskfield forward and parameter gradients; {reps} whole steps")
+
+
+def cpu_baseline(model, workload, seconds_hint=20, scene="bat"):
+    """Oracle (C restatement, OpenMP) on a bounded sample of the same step: 256+256 rays, P=32768 (chessboard at 688 samples per ray: 64+64 rays, P=16384)."""
+    from oracle import oracle as orc
+    sc = SCENES[scene]
+    fs = _oracle_field(model, scene)
     # 64 threads is the oracle's sweet spot on the GPU box's 256-thread host (measured: 644 rays/s at 64, 300 at 256 on this sample)
     threads = min(64, os.cpu_count() or 1)
     orc.set_threads(threads)
@@ -1142,86 +1183,8 @@ def main():
     default_invocation = (rank == 0 and world == 1 and args.mode == "fused" and args.workload == "cfg3" and scene == "bat" and not args.live and not args.no_extras
                           and not os.environ.get("NVFI_BENCH_CHILD") and os.environ.get("NVFI_PDE_PREFILTER", "fp32") == "fp32")
     if default_invocation:
-        import subprocess
-        def extra(extra_args, env=None, steps_factor=1, scene_args=True, profile=False, timeout=300, full=False):
-            # (the radiance-only step is 0.8 ms: K = 20 steps are a 16 ms timed region, shorter than the clock ramp of an idle GPU - 10 K there)
-            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps * steps_factor), "--warmup", str(args.warmup * steps_factor),
-                   "--profile-steps", "5" if (profile or full) else "0", "--no-extras"] + ([] if full else ["--no-cpu-baseline"])
-            if scene_args:
-                cmd += ["--rays", str(args.rays), "--pts", str(args.pts), "--grid", str(args.grid), "--samples", str(args.samples)]
-            cmd += extra_args
-            try:
-                r = subprocess.run(cmd, env=dict(os.environ, NVFI_BENCH_CHILD="1", **(env or {})), stdout=subprocess.PIPE, text=True, timeout=timeout)
-                ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
-                d = json.loads(ln[-1])
-                e = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "launch": d["config"].get("launch", "eager launches").split(" (")[0]}
-                if profile:
-                    e["_line"] = d
-                if full:        # a workload of its own: its roofline and CPU baseline travel with it
-                    r_ = d.get("roofline") or {}
-                    e["roofline"] = {k: r_.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic") if k in r_}
-                    e["cpu_baseline"] = d.get("cpu_baseline")
-                    e["workload"] = d["config"]["workload"]
-                return e
-            except Exception as e:
-                return {"error": repr(e)}
-
-        def strong_shard():
-            """the step one of 8 ranks runs under --scaling strong (256 rays per render, 32768 collocation points), on this one GPU: its time, its
-            per-class times and launch count, and what they project for the 8-GPU step"""
-            e = extra(["--rays", str(max(1, args.rays // 8)), "--pts", str(max(128, args.pts // 8)), "--grid", str(args.grid), "--samples", str(args.samples),
-                       "--graph", "off"], scene_args=False, profile=True)
-            d = e.pop("_line", None)
-            if d is None:
-                return e
-            pc = (d.get("roofline") or {}).get("per_class", {})
-            e["per_class_ms"] = {k: round(v["ms_per_step"], 4) for k, v in pc.items() if v.get("launches_per_step")}
-            e["kernel_class_launches_per_step"] = sum(v.get("launches_per_step", 0) for v in pc.values())
-            e["serial_ms_per_step"] = (d.get("work_per_step") or {}).get("ms_per_step_profiled_serial")
-            # projection for 8 GPUs, strong scaling: the shard step + the gradient exchange of the flat buffer.  Ring all-reduce of S bytes over N
-            # ranks moves 2 (N - 1) / N x S per link direction; ONE ring at the 153 GB/s of one xGMI link is the conservative figure (RCCL can
-            # stripe rings over the 7 links of the fully connected node).  The head of the buffer (planes + render MLP, 38 MB) is exchanged under
-            # the PDE chain, so the exposed part lies between 0 and the whole transfer.
-            nbytes = 4.0 * sum(p.numel() for p in model.parameters())
-            t_ar = 2.0 * 7.0 / 8.0 * nbytes / 153e9 * 1e3
-            t1, t8 = out["ms_per_step"], d["ms_per_step"]
-            e["projection_8gpu_strong"] = {
-                "gradient_bytes": nbytes, "ring_allreduce_ms_one_link": t_ar,
-                "step_ms_if_exchange_hidden": t8, "step_ms_if_exchange_exposed": t8 + t_ar,
-                "speedup_over_1gpu": [t1 / (t8 + t_ar), t1 / t8], "efficiency": [t1 / (t8 + t_ar) / 8.0, t1 / t8 / 8.0],
-                "note": "a PROJECTION from one-GPU measurements (this pool has one GPU per box); north_star's target is >= 6x at 8 GPUs"}
-            return e
-
-        out["extras"] = {
-            "dropin": dict(extra(["--mode", "dropin"]), what="the loop body of the reference's train_nvfi.py:139-249 verbatim on the `models` alias (plain autograd, "
-                           "torch.optim.Adam, reference-signature regularisers, the per-iteration .item() waits): what tools/run_reference_driver.py gets"),
-            "dropin_fused_adam": dict(extra(["--mode", "dropin"], {"NVFI_DROPIN_FUSED_ADAM": "1"}),
-                                      what="the same loop with `fused=True` in the caller's torch.optim.Adam (tools/run_reference_driver.py --fused-adam; opt-in: "
-                                           "the reference's call as written is the line above)"),
-            "cfg2_radiance_only": dict(extra(["--workload", "cfg2", "--graph", "off"], steps_factor=10), what="BASELINE configs[1]: bat.yaml radiance-only, 2048-ray batches, HBM-bound (gathers / scatters); 10 K steps"),
-            "optin_split16band_prefilter": dict(extra(["--graph", "off"], {"NVFI_PDE_PREFILTER": "split16band"}),
-                                                what="opt-in (NOT the headline): the PDE occupancy prefilter with fp32 products emulated on the fp16 matrix pipe (two binary16 "
-                                                     "terms per operand, three MFMAs, fp32 accumulation: ~2^-21 relative per product) + an fp32 re-evaluation band of 0.1 %; "
-                                                     "identical kept set on every test field"),
-            "optin_fp16band_prefilter": dict(extra(["--graph", "off"], {"NVFI_PDE_PREFILTER": "fp16band"}),
-                                             what="opt-in (NOT the headline): fp16-input pre-pass of the PDE occupancy prefilter with an fp32 re-evaluation band; "
-                                                  "identical kept set on every test field, no proof"),
-            "optin_fp16_forward_warp": dict(extra(["--graph", "off"], {"NVFI_VEL_FP16_TRAIN": "1"}),
-                                            what="opt-in (NOT the headline; the reference's counterpart is --disable_fp32, train_nvfi.py:96,144): the velocity warp of training renders "
-                                                 "evaluates VelBasis FORWARD with fp16-input MFMAs (fp32 accumulation, fp32 stashes); adjoint and weight gradients stay fp32 MFMA on "
-                                                 "those stashes; digit-level parity with the oracle in the same arithmetic"),
-            "live": dict(extra(["--live", "--graph", "off"]), what="the optimiser moves the field it renders (train_nvfi.py:243), as in real training: on random targets the blob "
-                         "thickens and the PDE kept set grows 34 k -> 114 k points within these steps, so the step is slower than the stationary headline (same kernels)"),
-            "strong_shard_1of8": dict(strong_shard(), what="the fused step at 1/8 of the global batch (--rays 256 --pts 32768: what each of 8 ranks runs under --scaling strong), one GPU"),
-            "chessboard": dict(extra(["--workload", "chessboard"], scene_args=False, timeout=600, full=True),
-                               what="BASELINE configs[3], one GPU's share: the same loop on the InDoorSeg chessboard box at its final 199x199x200 grid (K = 4, surround-box gate "
-                                    "with step rejection, no white background, 688 samples per ray, P = 131072)"),
-            "segm": dict(extra(["--workload", "segm"], scene_args=False, full=True),
-                         what="BASELINE configs[4], one GPU's share: train_segm.py's MaskField step (64^3 lattice -> occupied points -> integrate_pos -> MaskField fwd + bwd + Adam); points/s"),
-            "segm_fp16_mfma": dict(extra(["--workload", "segm"], {"NVFI_MASK_FP16": "1", "NVFI_VEL_FP16": "1"}, scene_args=False),
-                                   what="the same step with configs[4]'s 'fp16 MFMA MLP': MaskField forward / adjoint on v_mfma_f32_32x32x16_f16 (fp32 accumulation, fp32 stashes and "
-                                        "weight gradients) and integrate_pos on the fp16-input inference kernel; opt-in, stated in dtype"),
-        }
+        from tools.bench_extras import collect      # (round 5: the extras live in tools/bench_extras.py)
+        out["extras"] = collect(args, out, model)
     if graph_line is not None:
         modes = {"hipgraph_replay": {"value": graph_line["value"], "ms_per_step": graph_line["ms_per_step"]},
                  "eager_three_streams": {"value": out["value"], "ms_per_step": out["ms_per_step"]}}

@@ -125,6 +125,14 @@ int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const float* rays_o, 
                       const float* weights, const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_weights,
                       const nvfi_grads* grads, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* nvfi_render_fwd_t with the photometric loss of the training loop attached (ABI v5; train_nvfi.py:159,178: F.mse_loss(rgb_map, target)):
+ * loss[0] = mean((rgb - target)^2) and g_rgb[i] = loss_scale * 2 (rgb[i] - target[i]) / (3 R) - the upstream gradient nvfi_render_bwd[_t]
+ * takes - come out of the composite kernel of the same call (no nvfi_mse launch, no autograd node). */
+int nvfi_render_fwd_mse(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d, const float* jitter,
+                        float t, const float* t_dev, int flags, float* rgb, float* depth, float* acc, float* weights,
+                        void* workspace, int64_t workspace_bytes, int64_t* counters,
+                        const float* target /* (R,3) */, float loss_scale, float* loss /* device float[1] */, float* g_rgb /* (R,3) */, void* stream);
+
 /* ---- fragment cache (ABI v5).  The MFMA kernels read the nn.Linear weights of the field - renderModule.mlp + basis_mat
  *      (models/tensorf_base.py:67-98, tensorf_keyframe.py:310), vel_net.weight_net / a_weight_net (models/velocity_field.py:60-67) - in
  *      fragment order.  nvfi_pack_frags writes every fragment set the render and PDE calls use into `cache` (nvfi_frag_cache_bytes bytes,
@@ -266,6 +274,21 @@ int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const float* xyz_wor
 /* Camera.get_ray_bundle + pixel selection (models/camera.py:112-138,159-172): pose (device float[12], row-major 3x4 c2w),
  * pixel ids (device int64[n], row-major y*W+x) -> rays_o (n,3), rays_d (n,3) */
 int nvfi_gen_rays(const float* pose3x4, int H, int W, float focal, int64_t n, const int64_t* pixel_ids, float* rays_o, float* rays_d, void* stream);
+/* ---- the random inputs of ONE training iteration in one launch (ABI v5): what train_nvfi.py:150-178 draws per render (a pixel batch of the
+ *      posed image: Camera.sample_rays, models/camera.py:159-172) and what NVFi.get_vel_loss draws (models/nvfi.py:44-47: collocation points
+ *      uniform in the box, times uniform in [0,1)), from a counter-based generator (Philox4x32-10 keyed by `seed`; counter = element, segment,
+ *      iteration): same (seed, iteration) -> same batch, whatever the launch configuration.  Per batch b < n_batches: R pixel indices uniform in
+ *      [0, n_pixels) -> rays_o/rays_d[b] gathered from the camera bundle (n_pixels,3), target[b] gathered from target_img (n_pixels,3) or, when
+ *      that is NULL, uniform in [0,1) (synthetic benchmark targets); pixel_ids[b] (int64, optional) receives the indices.  P points + times. */
+typedef struct nvfi_draw_desc {
+    uint64_t seed, iteration;
+    const uint64_t* iteration_dev;   /* optional: the iteration counter in DEVICE memory (hipGraph replay) */
+    int32_t n_batches; int64_t R; int64_t n_pixels;
+    const float* bundle_o; const float* bundle_d; const float* target_img;
+    float* rays_o[2]; float* rays_d[2]; float* target[2]; int64_t* pixel_ids[2];
+    int64_t P; float aabb[6]; float* points; float* t;
+} nvfi_draw_desc;
+int nvfi_draw_batch(const nvfi_draw_desc* d, void* stream);
 /* The hand-rolled primitives the MLP engine uses instead of libm (engine.h: one-exp2/one-rcp sigmoid, Cody-Waite sin/cos), evaluated
  * element-wise so that tests can bound their error against float64: kind 0 sigmoid, 1 sin, 2 cos, 3 SiLU, 4 SiLU', 5 SiLU''. */
 int nvfi_debug_act(int kind, int64_t n, const float* x, float* y, void* stream);

@@ -48,10 +48,18 @@ class Grads(C.Structure):
     ]
 
 
+class DrawDesc(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("iteration", C.c_uint64), ("iteration_dev", fp),
+                ("n_batches", C.c_int32), ("R", C.c_int64), ("n_pixels", C.c_int64),
+                ("bundle_o", fp), ("bundle_d", fp), ("target_img", fp),
+                ("rays_o", fp * 2), ("rays_d", fp * 2), ("target", fp * 2), ("pixel_ids", fp * 2),
+                ("P", C.c_int64), ("aabb", C.c_float * 6), ("points", fp), ("t", fp)]
+
+
 EXPORTS = [
     "nvfi_last_error", "nvfi_abi_version",
     "nvfi_render_workspace_bytes", "nvfi_render_workspace_bytes_t", "nvfi_render_fwd", "nvfi_render_bwd", "nvfi_render_fwd_t", "nvfi_render_bwd_t",
-    "nvfi_pde_loss_dev", "nvfi_adam_step_dev", "nvfi_frag_cache_bytes", "nvfi_pack_frags",
+    "nvfi_pde_loss_dev", "nvfi_adam_step_dev", "nvfi_frag_cache_bytes", "nvfi_pack_frags", "nvfi_render_fwd_mse", "nvfi_draw_batch",
     "nvfi_pde_workspace_bytes", "nvfi_pde_loss", "nvfi_pde_loss_ex", "nvfi_pde_loss_split", "nvfi_plane_regs", "nvfi_plane_regs_dev", "nvfi_adam_step", "nvfi_mse", "nvfi_render_mask", "nvfi_render_export_masked", "nvfi_maskfield_workspace_bytes", "nvfi_maskfield_fwd", "nvfi_maskfield_bwd", "nvfi_sh_render", "nvfi_compute_alpha", "nvfi_gen_rays",
     "nvfi_vel_eval", "nvfi_vel_workspace_bytes", "nvfi_integrate_pos", "nvfi_density_at", "nvfi_app_at", "nvfi_render_mlp", "nvfi_app_workspace_bytes", "nvfi_alpha_workspace_bytes",
     "nvfi_comm_unique_id", "nvfi_comm_init", "nvfi_allreduce_grads", "nvfi_comm_destroy", "nvfi_selftest", "nvfi_debug_act", "nvfi_prof_enable", "nvfi_prof_collect", "nvfi_prof_nclasses",

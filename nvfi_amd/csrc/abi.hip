@@ -165,6 +165,61 @@ extern "C" int nvfi_gen_rays(const float* pose3x4, int H, int W, float focal, in
     return 0;
 }
 
+// ---------------------------------------------------------------- the random inputs of one training iteration in one launch (round 5)
+// What the reference draws per iteration (train_nvfi.py:150-178: a pixel batch per render via Camera.sample_rays; models/nvfi.py:44-47: the
+// collocation points `torch.rand(n,3) * (max - min) + min` and times `torch.rand(n,1)` of get_vel_loss) took ~13 torch launches in the fused
+// driver (randint, two index gathers and a rand per render; two rands, a subtract, a multiply and an add for the points).  Here one kernel
+// fills all of it from a counter-based generator: Philox4x32-10 (Salmon et al., SC'11) keyed by `seed`, counter = (element, segment,
+// iteration) - thread i produces the four words of ray i of a batch (pixel index + three target channels) or of point i (x, y, z, t).
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.f / 16777216.f); }     // [0, 1): 24 random bits, like torch.rand
+__global__ __launch_bounds__(256) void k_draw_batch(nvfi_draw_desc a) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const unsigned long long it = a.iteration_dev ? *a.iteration_dev : a.iteration;
+    const unsigned k0 = (unsigned)a.seed, k1 = (unsigned)(a.seed >> 32);
+    unsigned w[4];
+    if (i < a.R * a.n_batches) {
+        const int b = (int)(i / a.R);
+        const int64_t r = i - (int64_t)b * a.R;
+        philox4x32_10((unsigned)r, (unsigned)b, (unsigned)it, (unsigned)(it >> 32), k0, k1, w);
+        const int64_t pix = (int64_t)(((unsigned long long)w[0] * (unsigned long long)a.n_pixels) >> 32);     // uniform in [0, n_pixels)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.rays_o[b][3 * r + c] = a.bundle_o[3 * pix + c];
+            a.rays_d[b][3 * r + c] = a.bundle_d[3 * pix + c];
+            a.target[b][3 * r + c] = a.target_img ? a.target_img[3 * pix + c] : u01(w[1 + c]);
+        }
+        if (a.pixel_ids[b]) a.pixel_ids[b][r] = pix;
+    }
+    if (i < a.P) {
+        philox4x32_10((unsigned)i, 0x80000000u | (unsigned)(i >> 32), (unsigned)it, (unsigned)(it >> 32), k0, k1, w);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.points[3 * i + c] = u01(w[c]) * (a.aabb[3 + c] - a.aabb[c]) + a.aabb[c];      // models/nvfi.py:45
+        a.t[i] = u01(w[3]);
+    }
+}
+extern "C" int nvfi_draw_batch(const nvfi_draw_desc* d, void* stream) {
+    if (d->n_batches < 0 || d->n_batches > 2) return nvfi_fail(2, "nvfi_draw_batch: n_batches must be 0, 1 or 2");
+    if (d->n_batches > 0 && (d->R <= 0 || d->n_pixels <= 0 || !d->bundle_o || !d->bundle_d)) return nvfi_fail(2, "nvfi_draw_batch: ray batches need R, n_pixels and the camera bundle");
+    for (int b = 0; b < d->n_batches; ++b) if (!d->rays_o[b] || !d->rays_d[b] || !d->target[b]) return nvfi_fail(2, "nvfi_draw_batch: batch %d has a NULL output", b);
+    if (d->P > 0 && (!d->points || !d->t)) return nvfi_fail(2, "nvfi_draw_batch: points / t are NULL");
+    int64_t n = d->R * d->n_batches;
+    if (d->P > n) n = d->P;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_draw_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    LAUNCHCK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- MFMA layout self test
 __global__ __launch_bounds__(WG_THREADS) void k_selftest(const float* frag, const float* W, const float* X, float* out) {
     // one workgroup, wave 0 only does the maths: out[o][j] = sum_k W[o][k] X[k][j], 128x128 by 128x32
@@ -199,7 +254,7 @@ extern "C" int nvfi_selftest(float* max_err_host, void* stream) {
     PackJobs jobs; jobs.n = 1;
     PackJob& P = jobs.j[0];
     P.W = dW; P.b = nullptr; P.frag = dF; P.bfrag = nullptr; P.out = O; P.in = K; P.MT = 4; P.NS = 64;
-    P.row_kind = RK_NATURAL; P.slot_kind = SK_HIDDEN; P.transposed = 0;
+    P.row_kind = RK_NATURAL; P.slot_kind = SK_HIDDEN; P.transposed = 0; P.x4 = 0;
     if (launch_pack(jobs, st)) return 1;
     HIPCK(hipFuncSetAttribute((const void*)k_selftest, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     hipLaunchKernelGGL(k_selftest, dim3(1), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, dF, dW, dX, dO);

@@ -52,6 +52,9 @@ struct FinalArgs {
     float4* rgb_pre; float* rgb;
     // the call's counters (k_counters' job) written by workgroup 0 of the same launch; NULL: not wanted
     const int* c; int nsteps; int64_t* counters_out; const float* sched;
+    // nvfi_render_fwd_mse: F.mse_loss(rgb, target) and its gradient from the same launch (target == NULL: not wanted).  g_rgb_out[i] =
+    // loss_scale * 2 (rgb[i] - target[i]) / (3 R); per-workgroup partial sums, summed in workgroup order by the last one to finish (ticket)
+    const float* target; float* g_rgb_out; float* loss_out; float* partial; int* ticket; float loss_scale;
 };
 
 struct AppArgs {
@@ -93,4 +96,5 @@ __global__ void k_counters(const int* c, int nsteps, int64_t* out, const float* 
 __global__ void k_unpack_rgb(const float4* in, float* out, int64_t N);
 __global__ void k_pack_xyz4(const float* in, float4* out, int64_t N);
 int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, const int* count, int cap_tiles, int nrep,
-                     int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st, int fused_nslab = 0);
+                     int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st, int fused_nslab = 0,
+                     const WgradJobs* pre_w = nullptr, const ReduceJobs* pre_r = nullptr);

@@ -394,25 +394,50 @@ __global__ __launch_bounds__(256) void k_weights_fill(WeightArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_final_fwd(FinalArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= a.R) return;
-    const int b0 = a.off_m[r], b1 = a.off_m[r + 1];
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    for (int i = b0 + lane; i < b1; i += 64) {
-        const float w = a.weight[a.mlist[i]];
-        const float4 c = a.rgbs[i];
-        c0 += w * c.x; c1 += w * c.y; c2 += w * c.z;
-    }
-    c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
-    if (lane == 0) {
-        if (a.white_bg) { float bg = 1.f - a.acc[r]; c0 += bg; c1 += bg; c2 += bg; }
-        a.rgb_pre[r] = make_float4(c0, c1, c2, 0.f);
-        a.rgb[3 * r] = fminf(fmaxf(c0, 0.f), 1.f);
-        a.rgb[3 * r + 1] = fminf(fmaxf(c1, 0.f), 1.f);
-        a.rgb[3 * r + 2] = fminf(fmaxf(c2, 0.f), 1.f);
+    __shared__ float red[4];
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    const bool ron = r < a.R;
+    float se = 0.f;
+    if (ron) {
+        const int b0 = a.off_m[r], b1 = a.off_m[r + 1];
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        for (int i = b0 + lane; i < b1; i += 64) {
+            const float w = a.weight[a.mlist[i]];
+            const float4 c = a.rgbs[i];
+            c0 += w * c.x; c1 += w * c.y; c2 += w * c.z;
+        }
+        c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+        if (lane == 0) {
+            if (a.white_bg) { float bg = 1.f - a.acc[r]; c0 += bg; c1 += bg; c2 += bg; }
+            a.rgb_pre[r] = make_float4(c0, c1, c2, 0.f);
+            const float o0 = fminf(fmaxf(c0, 0.f), 1.f), o1 = fminf(fmaxf(c1, 0.f), 1.f), o2 = fminf(fmaxf(c2, 0.f), 1.f);
+            a.rgb[3 * r] = o0; a.rgb[3 * r + 1] = o1; a.rgb[3 * r + 2] = o2;
+            if (a.target) {
+                const float inv = 1.f / (float)(3 * a.R);
+                const float d0 = o0 - a.target[3 * r], d1 = o1 - a.target[3 * r + 1], d2 = o2 - a.target[3 * r + 2];
+                a.g_rgb_out[3 * r] = a.loss_scale * (2.f * d0 * inv); a.g_rgb_out[3 * r + 1] = a.loss_scale * (2.f * d1 * inv); a.g_rgb_out[3 * r + 2] = a.loss_scale * (2.f * d2 * inv);
+                se = (d0 * d0 + d1 * d1) + d2 * d2;
+            }
+        }
     }
     if (a.counters_out && blockIdx.x == 0 && threadIdx.x == 0) counters_body(a.c, a.nsteps, a.counters_out, a.sched);
+    if (!a.target) return;
+    if (lane == 0) red[wv] = se;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.partial + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && wv == 0) {      // the last workgroup sums the partials in workgroup order: the value does not depend on which one that is
+        float t = 0.f;
+        for (int k = lane; k < (int)gridDim.x; k += 64) t += __hip_atomic_load(a.partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = wave_sum(t);
+        if (lane == 0) { *a.loss_out = t * (1.f / (float)(3 * a.R)); *a.ticket = 0; }
+    }
 }
 
 // backward of composites + raw2alpha: produces d/d(xpre) per sample
@@ -1302,6 +1327,7 @@ struct RenderPlan {
     long long* shadow;         // NVFI_DETERMINISTIC: int64 fixed-point images of the 12 plane gradients
     int64_t zero_bytes;        // counters .. end of the sort histograms / look-back words: zeroed by the forward's single fill (or k_prologue)
     unsigned long long *lb_s, *lb_w;   // look-back status words of k_sample_fill / k_weights_fill
+    float* mse_part;
     TileWork tw; bool tiles;   // sorted-tile plane scatter (scatter.hip); tiles = false: grid too large, atomic scatter instead
     int64_t total;
 };
@@ -1328,6 +1354,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     // ... and so do the look-back words of the two fused compactions (k_sample_fill, k_weights_fill): one per workgroup of 4 rays
     const int64_t ray_wgs = (R + 3) / 4;
     P->lb_s = B.take<unsigned long long>(ray_wgs); P->lb_w = B.take<unsigned long long>(ray_wgs);
+    P->mse_part = B.take<float>(ray_wgs);        // nvfi_render_fwd_mse: per-workgroup partial sums of k_final_fwd (ticket: counters[8])
     P->zero_bytes = align_up(B.off, 256) - off_counters;
     P->sched = B.take<float>(SCHED_FLOATS);
     P->cnt_v = B.take<int>(R); P->off_v = B.take<int>(R + 1);
@@ -1408,9 +1435,26 @@ extern "C" int nvfi_render_fwd(const nvfi_field_desc* f, int64_t R, const float*
     return nvfi_render_fwd_t(f, R, rays_o, rays_d, jitter, t, nullptr, flags, rgb, depth, acc, weights, workspace, workspace_bytes, counters, stream);
 }
 
+static int render_fwd_impl(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d,
+                           const float* jitter, float t, const float* t_dev, int flags, float* rgb, float* depth, float* acc,
+                           float* weights, void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream,
+                           const float* target, float loss_scale, float* loss, float* g_rgb);
 extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d,
                                  const float* jitter, float t, const float* t_dev, int flags, float* rgb, float* depth, float* acc,
                                  float* weights, void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream) {
+    return render_fwd_impl(f, R, rays_o, rays_d, jitter, t, t_dev, flags, rgb, depth, acc, weights, workspace, workspace_bytes, counters, stream, nullptr, 1.f, nullptr, nullptr);
+}
+extern "C" int nvfi_render_fwd_mse(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d,
+                                   const float* jitter, float t, const float* t_dev, int flags, float* rgb, float* depth, float* acc,
+                                   float* weights, void* workspace, int64_t workspace_bytes, int64_t* counters,
+                                   const float* target, float loss_scale, float* loss, float* g_rgb, void* stream) {
+    if (!target || !loss || !g_rgb) return nvfi_fail(2, "nvfi_render_fwd_mse: target, loss and g_rgb must be non-NULL");
+    return render_fwd_impl(f, R, rays_o, rays_d, jitter, t, t_dev, flags, rgb, depth, acc, weights, workspace, workspace_bytes, counters, stream, target, loss_scale, loss, g_rgb);
+}
+static int render_fwd_impl(const nvfi_field_desc* f, int64_t R, const float* rays_o, const float* rays_d,
+                           const float* jitter, float t, const float* t_dev, int flags, float* rgb, float* depth, float* acc,
+                           float* weights, void* workspace, int64_t workspace_bytes, int64_t* counters, void* stream,
+                           const float* target, float loss_scale, float* loss, float* g_rgb) {
     hipStream_t st = (hipStream_t)stream;
     if (check_desc(f)) return 2;
     if (R <= 0) return 0;
@@ -1538,6 +1582,7 @@ extern "C" int nvfi_render_fwd_t(const nvfi_field_desc* f, int64_t R, const floa
     FinalArgs fa; fa.R = R; fa.off_m = P.off_m; fa.mlist = P.mlist; fa.weight = weights; fa.rgbs = P.rgbs; fa.acc = acc;
     fa.white_bg = (flags & NVFI_WHITE_BG) ? 1 : 0; fa.rgb_pre = P.rgb_pre; fa.rgb = rgb;
     fa.c = P.counters; fa.nsteps = nsteps; fa.counters_out = fl ? counters : nullptr; fa.sched = sched;
+    fa.target = target; fa.g_rgb_out = g_rgb; fa.loss_out = loss; fa.partial = P.mse_part; fa.ticket = P.counters + 8; fa.loss_scale = loss_scale;
     hipLaunchKernelGGL(k_final_fwd, dim3(ray_blocks), dim3(256), 0, st, fa);
     LAUNCHCK();
     if (counters && !fl) {
@@ -1651,8 +1696,11 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     }
     LAUNCHCK();
     // render-MLP weight gradients
+    // (round 5: at a non-keyframe time on one stream their ring / reduce jobs ride in the velocity net's two launches at the end of the call)
+    WgradJobs mlp_wj; mlp_wj.n = 0; ReduceJobs mlp_rj; mlp_rj.n = 0;
+    const bool merge_wgrad = fl && nsteps > 0 && !fork2;
     {
-        WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
+        WgradJobs& wj = mlp_wj; ReduceJobs& rj = mlp_rj;
         const size_t fs = APP_F_ROWS * REGF, bs = APP_B_ROWS * REGF;
         auto add = [&](const float* A, int a_regs, const float* B, int b_regs, float* slabs, float* gW, float* gb, int out, int in, int sk) {
             WgradJob& J = wj.j[wj.n++];
@@ -1670,7 +1718,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         if (grads->rW[1] || grads->rb[1]) add(P.app_b + 16 * REGF, 64, P.app_f + 96 * REGF, 64, sl + 1 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->rW[1], grads->rb[1], 128, 128, SK_HIDDEN);
         if (grads->rW[0] || grads->rb[0]) add(P.app_b + 80 * REGF, 64, P.app_f + 32 * REGF, 64, sl + 2 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->rW[0], grads->rb[0], 128, 110, SK_RENDER_IN);
         if (grads->basis) add(P.app_b + 144 * REGF, 16, P.app_f + 0, 32, sl + 3 * (size_t)NSLAB_MAX * SLAB_FLOATS, grads->basis, nullptr, f->app_dim, f->Ca, SK_HIDDEN);
-        if (launch_wgrad(wj, rj, s_atail)) return 1;
+        if (!merge_wgrad && launch_wgrad(wj, rj, s_atail)) return 1;
     }
     // composites + raw2alpha
     WeightArgs wa; memset(&wa, 0, sizeof(wa));
@@ -1732,7 +1780,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         // stash, no second pass over the z stash); 0: k_rk2_split_bwd + k_wgrad_ring8 over the full adjoint stash
         static int fuse = -1;
         if (fuse < 0) { const char* e = getenv("NVFI_RK2_FUSE"); fuse = e ? atoi(e) : 1; }
-        float* vslabs = fork2 ? P.slabs2 : P.slabs;
+        float* vslabs = (fork2 || merge_wgrad) ? P.slabs2 : P.slabs;      // (merged launches: the render MLP's slabs in P.slabs are still live)
         int fused_nslab = 0;
         if (split && fuse) {
             FuseBwdArgs fa; memset(&fa, 0, sizeof(fa));
@@ -1747,7 +1795,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
             if (launch_rk2_split_bwd(ba, N, st)) return 1;
         } else if (launch_rk2_bwd(ra, N, st)) return 1;
         if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 3, (int)P.cap_tiles, 2 * nsteps, BM_SILU, vslabs, NSLAB,
-                             grads->vW, grads->vb, 1.f, st, fused_nslab)) return 1;
+                             grads->vW, grads->vb, 1.f, st, fused_nslab, merge_wgrad ? &mlp_wj : nullptr, merge_wgrad ? &mlp_rj : nullptr)) return 1;
     }
     if (fork2) { HIPCK(hipEventRecord(g_fork.join, g_fork.s)); HIPCK(hipStreamWaitEvent(st, g_fork.join, 0)); }
     if (forked) { HIPCK(hipEventRecord(g_side.join, g_side.s)); HIPCK(hipStreamWaitEvent(st, g_side.join, 0)); }
@@ -1758,8 +1806,11 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
 // fused_nslab > 0: the slabs of the four hidden layers were already written (fused_nslab of them each) by k_rk2_fuse_bwd - only the two
 // edge layers are contracted here, the reduce covers all six
 int launch_vel_wgrad(const float* zst, const float* x0st, const float* gst, const int* count, int cap_tiles, int nrep,
-                     int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st, int fused_nslab) {
+                     int act_mode, float* slabs, int nslab, float* const* gW, float* const* gb, float scale, hipStream_t st, int fused_nslab,
+                     const WgradJobs* pre_w, const ReduceJobs* pre_r) {
     WgradJobs wj; wj.n = 0; ReduceJobs rj; rj.n = 0;
+    if (pre_w) wj = *pre_w;          // jobs of the same call that share the two launches (the render MLP's, render.hip)
+    if (pre_r) rj = *pre_r;
     const size_t zs = VEL_Z_REGS * REGF, gs = VEL_G_REGS * REGF, xs = VEL_X0_REGS * REGF;
     for (int l = 0; l < 6; ++l) {
         if (!gW[l] && !gb[l]) continue;

@@ -1097,6 +1097,69 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         self.last_pde_n_kept = None
         return out
 
+    def _grads_struct_cached(self, ps):
+        """nvfi_grads over the .grad tensors of the 31 render parameters (NULL for a parameter that is frozen or has no .grad): the ctypes
+        struct is rebuilt only when a gradient pointer changed (a GradBucket / the arena keeps them fixed for the whole run)"""
+        gs = [None if (p is None or p.grad is None or not p.requires_grad) else p.grad for p in ps]
+        key = tuple(0 if g is None else g.data_ptr() for g in gs)
+        c = _rt(self).get("_gs_cache")
+        if c is None or c[0] != key:
+            for g, p in zip(gs, ps):
+                if g is not None and g.stride() != p.stride():
+                    raise _lib.NvfiError("a parameter's .grad must share its memory layout (channels_last planes)")
+            c = (key, self._grads_struct(gs))
+            _rt(self)["_gs_cache"] = c
+        return c[1]
+
+    @torch.no_grad()
+    def render_mse_backward_(self, t, ray_o, ray_d, target, white_bg=True, loss_scale=1.0, jitter=None, wait_before_backward=None):
+        """Fused-driver form of one TRAINING render of train_nvfi.py:150-178 + its share of loss.backward() (train_nvfi.py:242):
+        forward, `loss_scale * F.mse_loss(rgb_map, target)` and the backward of both, with the parameter gradients ACCUMULATED into p.grad
+        (which must exist: nvfi_amd.dist.GradBucket, or zeros_like) - no autograd graph, no torch launch: nvfi_render_fwd_mse forms the loss and
+        its gradient inside the composite kernel, nvfi_render_bwd_t takes it from there.  The counterpart of pde_loss_backward_ /
+        regularizers_backward_ for the photometric term.  Returns (loss, rgb): a 0-dim device tensor with the UN-scaled mse and the (R,3) colours.
+        wait_before_backward: a stream the backward half has to wait for (a driver that runs regularizers_backward_ - a plain read-modify-write of
+        the plane gradients - on a side stream beside the forward half)."""
+        L = _lib.lib()
+        if not ray_o.is_cuda or not self.aabb.is_cuda:
+            raise _lib.NvfiError("NVFi HIP kernels need the field and the rays on the GPU (no CPU fallback exists)")
+        if self.mask_field is not None:
+            raise NotImplementedError("render_mse_backward_ does not drive the mask branch")
+        ray_o = ray_o.reshape(-1, 3).contiguous().float()
+        ray_d = ray_d.reshape(-1, 3).contiguous().float()
+        target = target.reshape(-1, 3).contiguous().float()
+        R = ray_o.shape[0]
+        dev = ray_o.device
+        flags = _lib.NVFI_TRAIN | (_lib.NVFI_BWD_FORK if self.fork_backward else 0)
+        if jitter is None:
+            jitter = self._jitter(R, dev)          # the reference's CPU-generator draw (tensorf_base.py:302-306)
+        if white_bg or bool(torch.rand((1,)) < 0.5):    # tensorf_keyframe.py:740
+            flags |= _lib.NVFI_WHITE_BG
+        t_dev = getattr(t, "dev", None)
+        t = float(np.float32(float(t)))
+        ps = self._render_params()
+        desc = self._desc()
+        S = desc.n_samples
+        nbytes = C.c_int64(0)
+        _lib.check(L.nvfi_render_workspace_bytes_t(C.byref(desc), C.c_int64(R), C.c_int(flags), C.c_float(t), C.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        a3, a1 = (3 * R + 63) // 64 * 64, (R + 63) // 64 * 64          # rgb | g_rgb | depth | acc | loss: one allocation, 256-byte aligned pieces
+        out = torch.empty(2 * a3 + 2 * a1 + 64, device=dev)
+        rgb, g_rgb, depth, acc, loss = out[:3 * R].view(R, 3), out[a3:a3 + 3 * R], out[2 * a3:2 * a3 + R], out[2 * a3 + a1:2 * a3 + a1 + R], out[2 * a3 + 2 * a1:]
+        weights = torch.empty(R, S, device=dev)
+        counters = torch.empty(_lib.NCOUNTERS, dtype=torch.int64, device=dev)
+        st = _stream_ptr()
+        _lib.check(L.nvfi_render_fwd_mse(C.byref(desc), C.c_int64(R), _lib.ptr(ray_o), _lib.ptr(ray_d), _lib.ptr(jitter), C.c_float(t), _lib.ptr(t_dev),
+                                         C.c_int(flags), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(weights), _lib.ptr(ws), C.c_int64(ws.numel()),
+                                         _lib.ptr(counters), _lib.ptr(target), C.c_float(float(loss_scale)), _lib.ptr(loss), _lib.ptr(g_rgb), st))
+        self.last_counters = counters
+        if wait_before_backward is not None:
+            torch.cuda.current_stream().wait_stream(wait_before_backward)
+        G = self._grads_struct_cached(ps)
+        _lib.check(L.nvfi_render_bwd_t(C.byref(desc), C.c_int64(R), _lib.ptr(ray_o), _lib.ptr(ray_d), C.c_float(t), C.c_int(int(t_dev is not None)),
+                                       C.c_int(flags), _lib.ptr(weights), _lib.ptr(g_rgb), None, None, None, C.byref(G), _lib.ptr(ws), C.c_int64(ws.numel()), st))
+        return loss[0], rgb
+
     def _jitter(self, R, device):
         """Per-ray jitter drawn on the CPU generator like the reference (tensorf_base.py:302-306), staged through a small
         ring of pinned buffers so the upload is asynchronous."""

@@ -35,12 +35,14 @@ def test_struct_layout_matches_header():
     """ctypes mirror of nvfi_field_desc / nvfi_grads has the size the C compiler gives the header's structs."""
     import subprocess, tempfile, ctypes as C
     from nvfi_amd import _lib
-    src = '#include <stdio.h>\n#include "nvfi_hip.h"\nint main(){printf("%zu %zu\\n", sizeof(nvfi_field_desc), sizeof(nvfi_grads));return 0;}\n'
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "nvfi_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(nvfi_field_desc), sizeof(nvfi_grads), '
+           'sizeof(nvfi_draw_desc), offsetof(nvfi_field_desc, frags), offsetof(nvfi_draw_desc, points));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
-        a, b = map(int, subprocess.check_output([os.path.join(d, "s")]).split())
-    assert C.sizeof(_lib.FieldDesc) == a and C.sizeof(_lib.Grads) == b
+        a, b, c, o1, o2 = map(int, subprocess.check_output([os.path.join(d, "s")]).split())
+    assert C.sizeof(_lib.FieldDesc) == a and C.sizeof(_lib.Grads) == b and C.sizeof(_lib.DrawDesc) == c
+    assert _lib.FieldDesc.frags.offset == o1 and _lib.DrawDesc.points.offset == o2      # ABI v5 additions
 
 
 @pytest.mark.parametrize("kind", ["A", "B"])

@@ -144,6 +144,7 @@ def test_graph_replay_follows_the_eager_iteration(workload):
         step()                                   # optimiser state, workspaces
         torch.manual_seed(11); torch.cuda.manual_seed(11)
         step.gen.manual_seed(5); step.rng = np.random.default_rng(5)
+        step.seed_override, step.draw_it = 5, 0          # nvfi_draw_batch: (seed, iteration) -> the pixel batches and collocation points
         losses = []
         if graphed:
             gs = bench.GraphedStep(step)

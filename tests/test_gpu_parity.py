@@ -30,7 +30,7 @@ def models():
 def test_native_library_loaded():
     from nvfi_amd import _lib
     L = _lib.lib()
-    assert L.nvfi_abi_version() == 4
+    assert L.nvfi_abi_version() == 5
     import ctypes as C
     err = C.c_float(-1)
     _lib.check(L.nvfi_selftest(C.byref(err), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
