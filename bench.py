@@ -53,7 +53,7 @@ APP_FLOP = 64768           # 2*(48*32 + 110*128 + 128^2 + 128*3)
 PEAK_FP32_MFMA = 157.3     # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 PEAK_HBM_GBS = 8000.0      # GB/s, MI355X_MICROARCH.md (HBM3E)
 CLASSES = ["rk2_fwd", "rk2_bwd", "app_fwd", "app_bwd", "wgrad", "pde_fwd", "pde_bwd", "density_fwd", "density_bwd", "pde_prefilter", "density_scatter", "app_scatter", "other"]
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def bat_cfg(S=128, use_vel=True):
@@ -1137,8 +1137,10 @@ def main():
             # inputs/outputs, over the WHOLE step time (the MLP contractions ride along); peak = 8 TB/s HBM3E
             nbytes = (V * 6912.0 + M * 13824.0) / psteps + renders * n_rays * (24.0 + (5.0 + args.samples) * 4.0)
             gbs = nbytes / (dt / args.steps) / 1e9
+            tr2 = _load_json(f"{PROFILE_TAG}_traffic_cfg2.json") or {}
             roof = dict(bound="hbm", kernel="whole step: plane gathers + plane-gradient scatters (k_density_q, k_og, k_tile_scatter, k_app_fwd gather)",
-                        achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=None,
+                        achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=tr2.get("bytes_per_step"),
+                        traffic_source=f"static: HBM bytes of the WHOLE step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload cfg2`, profiles/{PROFILE_TAG}_traffic_cfg2.json",
                         bytes_per_step=nbytes, mfma=roof)
 
     out = {

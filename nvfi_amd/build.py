@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["engine.hip", "wgrad_ring.hip", "vel.hip", "render.hip", "scatter.hip", "mask.hip", "pde.hip", "pde_jet.hip", "pre16.hip", "vel_split.hip", "vel_fuse.hip", "pde_fuse.hip", "regs.hip", "optim.hip", "abi.hip", "comm.hip", "frags.hip"]
+SOURCES = ["engine.hip", "wgrad_ring.hip", "vel.hip", "render.hip", "scatter.hip", "mask.hip", "pde.hip", "pde_jet.hip", "pre16.hip", "vel_split.hip", "vel_fuse.hip", "pde_fuse.hip", "regs.hip", "optim.hip", "abi.hip", "comm.hip", "frags.hip", "vel_x6.hip"]
 # every header under csrc/ (engine16.h, ... - a header that is not listed here would leave stale objects behind) + the public ABI
 HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith(".h")) + [os.path.join("..", "..", "include", "nvfi_hip.h")]
 SO = os.environ.get("NVFI_BUILD_SO", os.path.join(CSRC, "libnvfi_hip.so"))   # experiments build a second library elsewhere

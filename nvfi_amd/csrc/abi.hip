@@ -6,6 +6,7 @@
 #include "pde.h"
 #include "scatter.h"
 #include "vel.h"
+#include "x6.h"
 
 static thread_local char g_err[512] = "";
 int nvfi_fail(int code, const char* fmt, ...) {
@@ -54,6 +55,15 @@ extern "C" int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const flo
     float* fv = B.take<float>(VEL_FRAG_FLOATS);
     float4* xw = B.take<float4>(N);
     if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
+    if ((f->vel_fp16 & 3) == 3) {      // opt-in x6 mode (vel_x6.hip): fp32 products of the hidden layers formed exactly on the 16-bit matrix pipe
+        float* img = B.take<float>(X6_IMAGE_BYTES / 4);
+        if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
+        if (launch_pack_x6(f->vW, img, nullptr, st)) return 1;
+        hipLaunchKernelGGL(k_pack_xt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, x, xw);
+        X6Args xa; memset(&xa, 0, sizeof(xa));
+        xa.f = *f; xa.img = img; xa.n_direct = N; xa.xw = xw; xa.xout3 = xk; xa.pt_t = t; xa.pt_base = base; xa.dt_max = dt_max_of(*f); xa.max_steps = 4096;
+        return launch_rk2_x6(xa, N, st);
+    }
     PackJobs jobs; jobs.n = 0;
     Rk2Args a; memset(&a, 0, sizeof(a));
     if (!(f->vel_fp16 & 3)) {

@@ -19,6 +19,7 @@
 #include "fuse.h"
 #include "scatter.h"
 #include "frags.h"
+#include "x6.h"
 
 // ---------------------------------------------------------------- prefilter
 __global__ __launch_bounds__(256) void k_pde_prep(PdePrepArgs a) {
@@ -630,6 +631,7 @@ struct PdePlan {
     uint8_t* flags;
     float* sig;     // density at the warped points (prefilter)
     float4* xw16; uint8_t* near; int* blist; int* bcount; void* img16; void* img16lo;   // fp16 pre-pass (pre16.hip)
+    void* x6img;                                                                       // x6 prefilter (vel_x6.hip)
     double* sums; unsigned long long* lb; int64_t zero_bytes;
     float *vel_frag, *a_frag, *vel_x4, *a_x4, *stash, *seeds, *wout, *slabs;
     int64_t chunk, total;
@@ -654,6 +656,7 @@ static void plan_pde(int64_t P, void* ws, PdePlan* L) {
     L->xw16 = B.take<float4>(P); L->near = B.take<uint8_t>(nw * 64); L->blist = B.take<int>(P); L->bcount = L->cls_count + PDE_MAX_CLASS + 1;
     L->img16 = B.take<float4>(PRE16_IMAGE_BYTES / 16);
     L->img16lo = B.take<float4>(PRE16_IMAGE_BYTES / 16);
+    L->x6img = B.take<float4>(X6_IMAGE_BYTES / 16);
     L->dcount = B.take<int>(16);
     L->vel_frag = B.take<float>(VEL_FRAG_FLOATS); L->a_frag = B.take<float>(VEL_FRAG_FLOATS);
     L->vel_x4 = B.take<float>(VEL_X4_FLOATS);
@@ -750,9 +753,10 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     static int pre16 = -1; static float band16 = 0.1f, eps16 = 2e-3f;
     if (pre16 < 0) {
         const char* e = getenv("NVFI_PDE_PREFILTER");
-        if (e && strcmp(e, "fp16band") && strcmp(e, "split16band") && strcmp(e, "fp32") && strcmp(e, "split32") && strcmp(e, "engine32"))
-            return nvfi_fail(2, "NVFI_PDE_PREFILTER must be fp32, engine32, fp16band or split16band");
-        pre16 = !e ? 2 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "split16band") ? 3 : (!strcmp(e, "engine32") ? 0 : 2)));      // 2 = split kernel ("split32" = "fp32")
+        if (e && strcmp(e, "fp16band") && strcmp(e, "split16band") && strcmp(e, "fp32") && strcmp(e, "split32") && strcmp(e, "engine32") && strcmp(e, "x6"))
+            return nvfi_fail(2, "NVFI_PDE_PREFILTER must be fp32, engine32, x6, fp16band or split16band");
+        // 2 = split kernel ("split32" = "fp32"); 4 = x6 (vel_x6.hip: fp32 products formed exactly from three binary16 terms per operand)
+        pre16 = !e ? 2 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "split16band") ? 3 : (!strcmp(e, "engine32") ? 0 : (!strcmp(e, "x6") ? 4 : 2))));
         if (pre16 == 3) { band16 = 1e-3f; eps16 = 2e-5f; }
         if ((e = getenv("NVFI_PDE_BAND"))) band16 = (float)atof(e);
         if ((e = getenv("NVFI_PDE_GATE_EPS"))) eps16 = (float)atof(e);
@@ -805,6 +809,14 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     if (pre16 == 2) {
         sa.count = nullptr; sa.n_direct = P; sa.list = L.perm; sa.pt_t = L.pt_t_perm; sa.pt_base = L.pt_base_perm;
         if (launch_rk2_split(sa, P, 1, st)) return 1;
+        da.n_direct = P; da.xw = L.xw;
+        if (launch_density_q(da, P, st)) return 1;
+    } else if (pre16 == 4) {
+        X6Args xa; memset(&xa, 0, sizeof(xa));
+        xa.f = *f; xa.img = L.x6img; xa.n_direct = P; xa.list = L.perm; xa.xw = L.xw; xa.pt_t = L.pt_t_perm; xa.pt_base = L.pt_base_perm;
+        xa.dt_max = ra.dt_max; xa.max_steps = PDE_MAX_CLASS;
+        if (launch_pack_x6(f->vW, L.x6img, nullptr, st)) return 1;
+        { ProfScope ps(PK_PDE_PREFILTER, st); if (launch_rk2_x6(xa, P, st)) return 1; }
         da.n_direct = P; da.xw = L.xw;
         if (launch_density_q(da, P, st)) return 1;
     } else if (!pre16) {

@@ -53,5 +53,29 @@ def main(fetch_csv, write_csv, out_json, note):
     print(json.dumps(res, indent=1))
 
 
+def whole_step(fetch_csv, write_csv, out_json, note, steps, marker):
+    """another workload's counter passes (cfg2 / chessboard / segm): HBM bytes of the WHOLE step = sum over every kernel of the trace of
+    (2 x FETCH_SIZE + WRITE_SIZE) / steps, and the same per kernel.  `steps` = launches of `marker`, a kernel that runs once per step."""
+    tot = {}
+    launches = {}
+    for path, counter, mul in ((fetch_csv, "FETCH_SIZE", 2.0), (write_csv, "WRITE_SIZE", 1.0)):
+        for r in csv.DictReader(open(path)):
+            if r["Counter"] == counter:
+                tot[r["Kernel"]] = tot.get(r["Kernel"], 0.0) + mul * float(r["Total"]) * 1024.0
+                launches[r["Kernel"]] = int(r["Launches"])
+    if steps <= 0:
+        ms = [v for k, v in launches.items() if re.match(marker, k[5:] if k.startswith("void ") else k)]
+        steps = ms[0] if ms else 1
+    per_kernel = {k: v / steps for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
+    json.dump({"source": f"{fetch_csv} + {write_csv} ({note})", "steps": steps,
+               "note": "HBM bytes per STEP = sum over all kernels of (2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE) / steps; KiB->B",
+               "bytes_per_step": sum(per_kernel.values()), "bytes_per_step_per_kernel": per_kernel}, open(out_json, "w"), indent=1)
+    print(json.dumps({"bytes_per_step": sum(per_kernel.values()), "steps": steps}))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
+    if "--whole-step" in sys.argv:
+        a = [x for x in sys.argv[1:] if x != "--whole-step"]
+        whole_step(a[0], a[1], a[2], a[3] if len(a) > 3 else "", int(a[4]) if len(a) > 4 else 0, a[5] if len(a) > 5 else r"k_adam|k_prologue")
+    else:
+        main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
