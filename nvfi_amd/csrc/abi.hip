@@ -58,7 +58,7 @@ extern "C" int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const flo
     if ((f->vel_fp16 & 3) == 3) {      // opt-in x6 mode (vel_x6.hip): fp32 products of the hidden layers formed exactly on the 16-bit matrix pipe
         float* img = B.take<float>(X6_IMAGE_BYTES / 4);
         if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
-        if (launch_pack_x6(f->vW, img, nullptr, st)) return 1;
+        if (launch_pack_x6(f->vW, img, st)) return 1;
         hipLaunchKernelGGL(k_pack_xt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, x, xw);
         X6Args xa; memset(&xa, 0, sizeof(xa));
         xa.f = *f; xa.img = img; xa.n_direct = N; xa.xw = xw; xa.xout3 = xk; xa.pt_t = t; xa.pt_base = base; xa.dt_max = dt_max_of(*f); xa.max_steps = 4096;

@@ -815,7 +815,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         X6Args xa; memset(&xa, 0, sizeof(xa));
         xa.f = *f; xa.img = L.x6img; xa.n_direct = P; xa.list = L.perm; xa.xw = L.xw; xa.pt_t = L.pt_t_perm; xa.pt_base = L.pt_base_perm;
         xa.dt_max = ra.dt_max; xa.max_steps = PDE_MAX_CLASS;
-        if (launch_pack_x6(f->vW, L.x6img, nullptr, st)) return 1;
+        if (launch_pack_x6(f->vW, L.x6img, st)) return 1;
         { ProfScope ps(PK_PDE_PREFILTER, st); if (launch_rk2_x6(xa, P, st)) return 1; }
         da.n_direct = P; da.xw = L.xw;
         if (launch_density_q(da, P, st)) return 1;

@@ -2,26 +2,25 @@
 // of models/velocity_field.py:21-98) with the hidden layers' fp32 products formed on the 16-BIT matrix pipe - exactly.
 //
 // Why: v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate (64 FLOP / clk / SIMD) and nothing issues beside it - not from another wave, not
-// from its own (tools/probes/dual_pipe_probe3.hip) - so the fp32 kernels sit at 0.6-0.75 of a 157 TFLOP/s roof.  v_mfma_f32_32x32x16_f16
+// from its own (tools/probes/dual_pipe_probe3.hip) - so the fp32 kernels sit at 0.6-0.75 of a 157 TFLOP/s roof.  v_mfma_f32_32x32x16_bf16
 // delivers 16x the multiply-adds per cycle and leaves 4-5 issue slots per instruction to the issuing wave's own VALU work.
 //
-// How (the "x6" scheme; the 3-term analogue of cuBLAS' BF16x9 fp32 emulation, with binary16 terms):
-//   every operand is split into THREE binary16 terms at scales 1, 2^-11, 2^-22 -   x = x1 + x2 / 2^11 + x3 / 2^22,
-//   x1 = rn16(x), x2 = rn16((x - x1) 2^11), x3 = rn16(((x - x1) 2^11 - x2) 2^11): the residuals are exact in fp32, three 11-bit terms carry
-//   33 bits - more than the 24 of an fp32 number, so (barring binary16 under/overflow, see below) x1 + x2/2^11 + x3/2^22 == x EXACTLY;
-//   a product w x = sum_ij w_i x_j 2^-11(i+j-2) is formed from the SIX term products of magnitude >= 2^-22 (each the exact product of two
-//   11-bit numbers, added into an fp32 accumulator by the MFMA): w1x1 | w1x2 + w2x1 | w2x2 + w1x3 + w3x1 - three accumulators, one per
-//   scale, combined once per layer as a0 + a1 2^-11 + a2 2^-22.  The dropped products are <= 3 * 2^-33 |w x|.
+// How (the "x6" scheme; the 6-product analogue of cuBLAS' BF16x9 fp32 emulation):
+//   every fp32 operand is split into THREE bfloat16 terms, x = x1 + x2 + x3 with x1 = rn_bf16(x), x2 = rn_bf16(x - x1), x3 = x - x1 - x2:
+//   the residuals are exact in fp32 (|x - x1| <= 2^-9 |x| has at most 16 significant bits, the second residual at most 8), bfloat16 has
+//   the exponent range of fp32, so the three 8-bit terms carry the 24-bit significand EXACTLY - no scaling, no subnormal terms (a binary16
+//   version of this file lost first terms below 6.1e-5 to the subnormal range: 4.7e-6 outliers against float64);
+//   a product w x = sum_ij w_i x_j is formed from the SIX term products of relative magnitude >= 2^-18 - each the exact product of two 8-bit
+//   numbers, added into an fp32 accumulator by the MFMA - w1x1 | w1x2 + w2x1 | w2x2 + w1x3 + w3x1: three accumulators, one per magnitude
+//   class, added once per layer, small ones first.  The dropped products (w2x3, w3x2, w3x3) are <= 2^-26 |w x|: a quarter of the rounding
+//   error of ONE fp32 product.
 //   What is left is the rounding of the fp32 accumulation itself - with the small terms summed apart from the large ones it is SMALLER
 //   than the error of a K = 128 fp32 dot product accumulated in sequence (tests/studies/x6_accuracy_study.py; on the device:
 //   tests/test_gpu_x6.py compares both kernels against float64).  Encoder, biases, SiLU, the 128 -> 6 output layer (vector pipe, fp32
 //   FMAs as in velnet_split_vout), gates and the RK2 recurrence are the fp32 code of vel_split.hip.
-//   Range: binary16 holds |v| < 65504 (weights and SiLU activations of VelBasis are O(1); a term that overflows would poison the
-//   product, so the pack kernel reports the largest |w| and the launcher refuses images above 6e4), and a first term below 6.1e-5 is
-//   subnormal: its absolute error is <= 2^-25, carried by the second term anyway.
 //
 // Layout: feature split as in k_rk2_split - one workgroup of four waves per NT point tiles, wave w owns output rows [32 w, 32 w + 32) of
-// every hidden layer; the weights' three binary16 images ([layer][row tile][K step][lane] x 8 halves = the A operand of one MFMA per 16
+// every hidden layer; the weights' three bfloat16 images ([layer][row tile][K step][lane] x 8 halves = the A operand of one MFMA per 16
 // bytes) stream from L2 two K steps ahead; the layer input travels between the waves through LDS already split: every lane writes the
 // six 16-byte B operands (3 terms x 2 K steps) of its 16 outputs and reads 3 x 8 per tile and layer.
 #include <stdlib.h>
@@ -31,69 +30,62 @@
 #include "engine16.h"
 #include "x6.h"
 
-// ---------------------------------------------------------------- packing: three binary16 images of layers 0..4
+// ---------------------------------------------------------------- packing: three bfloat16 images of layers 0..4
+__device__ __forceinline__ void split3(float x, __bf16& t1, __bf16& t2, __bf16& t3) {
+    t1 = (__bf16)x;
+    const float r1 = x - (float)t1;
+    t2 = (__bf16)r1;
+    t3 = (__bf16)(r1 - (float)t2);
+}
 __global__ __launch_bounds__(256) void k_pack_x6(X6PackArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    float wmax = 0.f;
-    if (idx < X6_H8) {
-        int l, local, NS, in, kind;
-        if (idx < 512) { l = 0; local = idx; NS = 2; in = 28; kind = SK_VEL_IN; }
-        else { l = 1 + (idx - 512) / 2048; local = (idx - 512) % 2048; NS = 8; in = 128; kind = SK_HIDDEN; }
-        const int lane = local & 63, ms = local >> 6, s = ms % NS, m = ms / NS;
-        const int row = 32 * m + (lane & 31), h = lane >> 5;
-        const float* W = a.W[l];
-        h8_t v1, v2, v3;
+    if (idx >= X6_H8) return;
+    int l, local, NS, in, kind;
+    if (idx < 512) { l = 0; local = idx; NS = 2; in = 28; kind = SK_VEL_IN; }
+    else { l = 1 + (idx - 512) / 2048; local = (idx - 512) % 2048; NS = 8; in = 128; kind = SK_HIDDEN; }
+    const int lane = local & 63, ms = local >> 6, s = ms % NS, m = ms / NS;
+    const int row = 32 * m + (lane & 31), h = lane >> 5;
+    const float* W = a.W[l];
+    b8_t v1, v2, v3;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int feat = slot_logical(kind, 2 * (8 * s + j) + h);     // register 8 s + j of lane half h of the producing layer (engine.h)
-            float w = 0.f;
-            if (feat >= 0 && feat < in) w = W[(size_t)row * in + feat];
-            wmax = fmaxf(wmax, fabsf(w));
-            const _Float16 t1 = (_Float16)w;
-            const float r1 = (w - (float)t1) * X6_SCALE;
-            const _Float16 t2 = (_Float16)r1;
-            const float r2 = (r1 - (float)t2) * X6_SCALE;
-            v1[j] = t1; v2[j] = t2; v3[j] = (_Float16)r2;
-        }
-        a.img[idx] = v1; a.img[X6_H8 + idx] = v2; a.img[2 * X6_H8 + idx] = v3;
+    for (int j = 0; j < 8; ++j) {
+        const int feat = slot_logical(kind, 2 * (8 * s + j) + h);     // register 8 s + j of lane half h of the producing layer (engine.h)
+        float w = 0.f;
+        if (feat >= 0 && feat < in) w = W[(size_t)row * in + feat];
+        __bf16 t1, t2, t3;
+        split3(w, t1, t2, t3);
+        v1[j] = t1; v2[j] = t2; v3[j] = t3;
     }
-    // the largest |w| of the image (as int bits: non-negative floats order like integers), for the launcher's range check
-    wmax = fmaxf(wmax, __shfl_xor(wmax, 32));
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-    if ((threadIdx.x & 63) == 0 && a.wmax_bits) atomicMax(a.wmax_bits, __float_as_int(wmax));
+    a.img[idx] = v1; a.img[X6_H8 + idx] = v2; a.img[2 * X6_H8 + idx] = v3;
 }
-int launch_pack_x6(const float* const* W, void* img, int* wmax_bits, hipStream_t st) {
+int launch_pack_x6(const float* const* W, void* img, hipStream_t st) {
     X6PackArgs pk;
     for (int l = 0; l < 5; ++l) pk.W[l] = W[l];
-    pk.img = reinterpret_cast<h8_t*>(img); pk.wmax_bits = wmax_bits;
+    pk.img = reinterpret_cast<b8_t*>(img);
     hipLaunchKernelGGL(k_pack_x6, dim3((X6_H8 + 255) / 256), dim3(256), 0, st, pk);
     LAUNCHCK();
     return 0;
 }
 
 // ---------------------------------------------------------------- three-term split of 8 activations -> the B operands of one K step
-typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split3_8(const float* v, h8_t& b1, h8_t& b2, h8_t& b3) {
+__device__ __forceinline__ void split3_8(const float* v, b8_t& b1, b8_t& b2, b8_t& b3) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const _Float16 t1 = (_Float16)v[j];
-        const float r1 = (v[j] - (float)t1) * X6_SCALE;
-        const _Float16 t2 = (_Float16)r1;
-        const float r2 = (r1 - (float)t2) * X6_SCALE;
-        b1[j] = t1; b2[j] = t2; b3[j] = (_Float16)r2;
+        __bf16 t1, t2, t3;
+        split3(v[j], t1, t2, t3);
+        b1[j] = t1; b2[j] = t2; b3[j] = t3;
     }
 }
 
 // the six term products of one K step for one tile: a0 += A1 B1 ; a1 += A1 B2 + A2 B1 ; a2 += A2 B2 + A1 B3 + A3 B1
-__device__ __forceinline__ void x6_step(const h8_t& A1, const h8_t& A2, const h8_t& A3, const h8_t& B1, const h8_t& B2, const h8_t& B3,
+__device__ __forceinline__ void x6_step(const b8_t& A1, const b8_t& A2, const b8_t& A3, const b8_t& B1, const b8_t& B2, const b8_t& B3,
                                         f32x16& a0, f32x16& a1, f32x16& a2) {
-    a0 = MFMA16(A1, B1, a0);
-    a1 = MFMA16(A1, B2, a1);
-    a2 = MFMA16(A2, B2, a2);
-    a1 = MFMA16(A2, B1, a1);
-    a2 = MFMA16(A1, B3, a2);
-    a2 = MFMA16(A3, B1, a2);
+    a0 = MFMA16B(A1, B1, a0);
+    a1 = MFMA16B(A1, B2, a1);
+    a2 = MFMA16B(A2, B2, a2);
+    a1 = MFMA16B(A2, B1, a1);
+    a2 = MFMA16B(A1, B3, a2);
+    a2 = MFMA16B(A3, B1, a2);
 }
 
 // LDS exchange image of one tile: [term][K step 0..7][lane] h8
@@ -101,15 +93,26 @@ __device__ __forceinline__ void x6_step(const h8_t& A1, const h8_t& A2, const h8
 #define X6_LDS_BYTES(NT) ((NT) * (X6_XCH_H8 * 16 + 4 * 2 * 32 * 16) + 6 * 128 * 4 + 4 * 2 * 16 * 8 * 4)
 
 // one gated-velocity network evaluation of the workgroup's NT tiles (velnet_split_vout of vel_split.hip with x6 hidden layers)
+//
+// OPERAND LIFETIME RULE (measured, tools/tmp notes in DESIGN 4.8): the B operand registers of a v_mfma_f32_32x32x16_* must stay intact until
+// the instruction has COMPLETED, not merely issued.  A wave runs ahead of its queued MFMAs; a register set that a later instruction - an LDS
+// or L2 load returning, or a VALU write the allocator placed there - overwrote after the issue reached the matrix pipe with new contents
+// for the columns read last (points 16..31 of a tile off by ~1e-5, 0.1-1 % of the tiles, more with more waves per SIMD; the fp16 kernels
+// of pre16.hip keep a layer's B operands in registers for the whole layer and never showed it).  Hence:
+//   * a tile's whole layer input (8 K steps x 3 terms = 24 operands, 96 registers) is read from LDS BEFORE the layer's first MFMA and
+//     kept until the layer's accumulators have been read by the epilogue (a VALU read of an accumulator waits for the MFMAs that write it),
+//     pinned by an empty asm behind that read;
+//   * the A operands (weights) rotate through four register sets, refilled from L2 behind the MFMAs of a later step (A is consumed at issue:
+//     overwriting it early was never observed to matter - pre16.hip reloads A from LDS for every MFMA).
 template <int NT>
-__device__ __forceinline__ void velnet_x6(const h8_t* __restrict__ img, h8_t* xch, float4* part, const float4* w5l, int w, int lane, int h,
+__device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xch, float4* part, const float4* w5l, int w, int lane, int h,
                                           const float4* q, const float* lb, float (&out6)[NT][6]) {
-    const h8_t* W1 = img; const h8_t* W2 = img + X6_H8; const h8_t* W3 = img + 2 * X6_H8;
+    const b8_t* W1 = img; const b8_t* W2 = img + X6_H8; const b8_t* W3 = img + 2 * X6_H8;
     f32x16 a0[NT], a1[NT], a2[NT];
-    float v[NT][16];
+    b8_t Bf[NT][8][3];
     // ---- layer 0: every wave encodes the point itself (28 inputs in 16 slots per lane half = 2 K steps)
     {
-        h8_t A1[2], A2[2], A3[2];
+        b8_t A1[2], A2[2], A3[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int o = X6_L0 + (w * 2 + s) * 64 + lane;
@@ -119,53 +122,70 @@ __device__ __forceinline__ void velnet_x6(const h8_t* __restrict__ img, h8_t* xc
         for (int t = 0; t < NT; ++t) {
             float x0[16];
             vel_encode_slots(q[t], h, x0);
-            h8_t B1[2], B2[2], B3[2];
-            split3_8(x0, B1[0], B2[0], B3[0]);
-            split3_8(x0 + 8, B1[1], B2[1], B3[1]);
+            split3_8(x0, Bf[t][0][0], Bf[t][0][1], Bf[t][0][2]);
+            split3_8(x0 + 8, Bf[t][1][0], Bf[t][1][1], Bf[t][1][2]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a0[t][r] = lb[32 * w + (r & 3) + 8 * (r >> 2) + 4 * h]; a1[t][r] = 0.f; a2[t][r] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) x6_step(A1[s], A2[s], A3[s], B1[s], B2[s], B3[s], a0[t], a1[t], a2[t]);
         }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) x6_step(A1[s], A2[s], A3[s], Bf[t][s][0], Bf[t][s][1], Bf[t][s][2], a0[t], a1[t], a2[t]);
     }
 #pragma unroll 1
     for (int l = 0; l < 4; ++l) {
-        // the next layer's first two K steps start their trip from L2 now; they land behind the epilogue and the exchange
-        const h8_t* P1 = W1 + X6_LH(l + 1) + (w * 8) * 64 + lane;
-        const h8_t* P2 = W2 + X6_LH(l + 1) + (w * 8) * 64 + lane;
-        const h8_t* P3 = W3 + X6_LH(l + 1) + (w * 8) * 64 + lane;
-        h8_t A1[3], A2[3], A3[3];
-        A1[0] = P1[0]; A2[0] = P2[0]; A3[0] = P3[0];
-        A1[1] = P1[64]; A2[1] = P2[64]; A3[1] = P3[64];
-        // epilogue of layer l: combine the three scales, SiLU, split, hand the wave's 16 outputs per tile to the workgroup
+        // epilogue of layer l, first half: the sums of the three magnitude classes, small ones first - the read of the accumulators is the
+        // point behind which the layer's MFMAs have completed
+        float v[NT][16];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[t][r] = act_f<1>(__builtin_fmaf(__builtin_fmaf(a2[t][r], X6_INV1, a1[t][r]), X6_INV1, a0[t][r]));
+            for (int r = 0; r < 16; ++r) v[t][r] = (a2[t][r] + a1[t][r]) + a0[t][r];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(Bf[t][s][0]), "v"(Bf[t][s][1]), "v"(Bf[t][s][2]), "v"(v[t][0]), "v"(v[t][15]));
+        __builtin_amdgcn_sched_barrier(0);
+        // the next layer's first three K steps start their trip from L2 now; they land behind the rest of the epilogue and the exchange
+        const b8_t* P1 = W1 + X6_LH(l + 1) + (w * 8) * 64 + lane;
+        const b8_t* P2 = W2 + X6_LH(l + 1) + (w * 8) * 64 + lane;
+        const b8_t* P3 = W3 + X6_LH(l + 1) + (w * 8) * 64 + lane;
+        b8_t A1[4], A2[4], A3[4];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { A1[s] = P1[s * 64]; A2[s] = P2[s * 64]; A3[s] = P3[s * 64]; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[t][r] = act_f<1>(v[t][r]);
         __syncthreads();                                 // the previous layer's readers of the exchange buffer are done
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                h8_t b1, b2, b3;
+                b8_t b1, b2, b3;
                 split3_8(v[t] + 8 * k, b1, b2, b3);
-                h8_t* dst = xch + (size_t)t * X6_XCH_H8 + (2 * w + k) * 64 + lane;
+                b8_t* dst = xch + (size_t)t * X6_XCH_H8 + (2 * w + k) * 64 + lane;
                 dst[0] = b1; dst[8 * 64] = b2; dst[16 * 64] = b3;
             }
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const b8_t* src = xch + (size_t)t * X6_XCH_H8 + s * 64 + lane;
+                Bf[t][s][0] = src[0]; Bf[t][s][1] = src[8 * 64]; Bf[t][s][2] = src[16 * 64];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a0[t][r] = lb[128 * (l + 1) + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h]; a1[t][r] = 0.f; a2[t][r] = 0.f; }
+        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            if (s + 2 < 8) { A1[(s + 2) % 3] = P1[(s + 2) * 64]; A2[(s + 2) % 3] = P2[(s + 2) * 64]; A3[(s + 2) % 3] = P3[(s + 2) * 64]; }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const h8_t* src = xch + (size_t)t * X6_XCH_H8 + s * 64 + lane;
-                const h8_t B1 = src[0], B2 = src[8 * 64], B3 = src[16 * 64];
-                x6_step(A1[s % 3], A2[s % 3], A3[s % 3], B1, B2, B3, a0[t], a1[t], a2[t]);
-            }
+            for (int t = 0; t < NT; ++t) x6_step(A1[s & 3], A2[s & 3], A3[s & 3], Bf[t][s][0], Bf[t][s][1], Bf[t][s][2], a0[t], a1[t], a2[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 3 < 8) { A1[(s + 3) & 3] = P1[(s + 3) * 64]; A2[(s + 3) & 3] = P2[(s + 3) * 64]; A3[(s + 3) & 3] = P3[(s + 3) * 64]; }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- 128 -> 6 output layer on the vector pipe (velnet_split_vout): fp32 FMAs over the 16 activations each lane holds
@@ -175,13 +195,24 @@ __device__ __forceinline__ void velnet_x6(const h8_t* __restrict__ img, h8_t* xc
 #pragma unroll
         for (int o = 0; o < 6; ++o) p[t][o] = 0.f;
     const float4* wl = w5l + (w * 2 + h) * 32;
+    float zl[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zl[t][r] = (a2[t][r] + a1[t][r]) + a0[t][r];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(Bf[t][s][0]), "v"(Bf[t][s][1]), "v"(Bf[t][s][2]), "v"(zl[t][0]), "v"(zl[t][15]));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if ((r & 1) == 0) __builtin_amdgcn_sched_barrier(0);
         const float4 wa = wl[2 * r], wb = wl[2 * r + 1];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float av = act_f<1>(__builtin_fmaf(__builtin_fmaf(a2[t][r], X6_INV1, a1[t][r]), X6_INV1, a0[t][r]));
+            const float av = act_f<1>(zl[t][r]);
             p[t][0] = __builtin_fmaf(av, wa.x, p[t][0]); p[t][1] = __builtin_fmaf(av, wa.y, p[t][1]); p[t][2] = __builtin_fmaf(av, wa.z, p[t][2]);
             p[t][3] = __builtin_fmaf(av, wa.w, p[t][3]); p[t][4] = __builtin_fmaf(av, wb.x, p[t][4]); p[t][5] = __builtin_fmaf(av, wb.y, p[t][5]);
         }
@@ -211,9 +242,9 @@ __device__ __forceinline__ void velnet_x6(const h8_t* __restrict__ img, h8_t* xc
 
 // the recurrence of k_rk2_split<NT, true> (vel_split.hip), per-point times
 template <int NT>
-__global__ __launch_bounds__(WG_THREADS, NT == 1 ? 3 : 2) void k_rk2_x6(X6Args a) {
+__global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6(X6Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    h8_t* xch = reinterpret_cast<h8_t*>(lds);
+    b8_t* xch = reinterpret_cast<b8_t*>(lds);
     float4* part = reinterpret_cast<float4*>(xch + NT * X6_XCH_H8);
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -239,7 +270,7 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 3 : 2) void k_rk2_x6(X6Args a
         w5f[k] = o < 6 ? a.f.vW[5][o * 128 + 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
     }
     const float4* w5l = reinterpret_cast<const float4*>(w5f);
-    const h8_t* img = reinterpret_cast<const h8_t*>(a.img);
+    const b8_t* img = reinterpret_cast<const b8_t*>(a.img);
     __syncthreads();
 #pragma unroll 1
     for (int s = 0; s < a.max_steps; ++s) {

@@ -442,7 +442,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         # back-advection - integrate_pos, the warp of eval-mode renders, getDenseAlpha - on the fp16-input MFMA (nvfi_field_desc.vel_fp16).
         # Training renders, the PDE term and all gradients stay fp32 whatever this says.
         # True / 1: one binary16 term per MFMA operand; 2 / "split": two terms (fp32 products emulated, ~2^-21 relative per product, 2.4x fp32 speed)
-        self.vel_fp16 = {"0": False, "1": True, "2": 2, "split": 2}.get(os.environ.get("NVFI_VEL_FP16", "0"), False)
+        self.vel_fp16 = {"0": False, "1": True, "2": 2, "split": 2, "3": 3, "x6": 3}.get(os.environ.get("NVFI_VEL_FP16", "0"), False)
         # opt-in (round 4; the reference's counterpart: --disable_fp32 autocasts the forward of every nn.Linear, train_nvfi.py:96,144): the velocity
         # warp of TRAINING renders evaluates VelBasis forward with fp16-input MFMAs (fp32 accumulation, fp32 stashes); its adjoint and the
         # weight gradients stay fp32 MFMA on those stashes, the PDE term and the render MLP stay fp32.  Never the default, never the headline.
@@ -606,7 +606,9 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         d.K = int(self.num_keyframes)
         d.Cd, d.Ca, d.app_dim = int(self.density_n_comp[0]), int(self.app_n_comp[0]), int(self.app_dim)
         d.shading = 1 if self.shadingMode == "SH" else 0
-        d.vel_fp16 = (2 if self.vel_fp16 in (2, "split", "split16") else (1 if self.vel_fp16 else 0)) | (4 if getattr(self, "vel_fp16_train", False) else 0)
+        # 3 / "x6": every no-grad back-advection on the x6 kernels (vel_x6.hip: fp32 products formed exactly from three binary16 terms per operand)
+        vf = self.vel_fp16
+        d.vel_fp16 = (3 if (vf == 3 or vf == "x6") else (2 if vf in (2, "split", "split16") else (1 if vf else 0))) | (4 if getattr(self, "vel_fp16_train", False) else 0)
         d.n_samples = int(self.nSamples)
         d.use_vel = int(self.use_vel)
         gsur, lo, hi = self._gate()
