@@ -1,6 +1,7 @@
 // engine.hip - fragment packing, split-K weight-gradient kernel, slab reduce.  See engine.h.
 #include "engine.h"
 #include "common.h"
+#include "x6.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -32,10 +33,17 @@ __device__ __forceinline__ void pack_job(const PackJob& J, int y, int ny) {
     }
 }
 __global__ void k_pack(PackJobs jobs) { pack_job(jobs.j[blockIdx.x], blockIdx.y, gridDim.y); }
-__global__ void k_pack_all(PackJobsAll jobs) { pack_job(jobs.j[blockIdx.x], blockIdx.y, gridDim.y); }
-int launch_pack_all(const PackJobsAll& jobs, hipStream_t st) {
-    if (jobs.n == 0) return 0;
-    hipLaunchKernelGGL(k_pack_all, dim3(jobs.n, 8), dim3(256), 0, st, jobs);
+// ... and, behind the fp32 fragment jobs, the three bfloat16 images of the x6 kernels (x6.h): workgroups [jobs.n, jobs.n + X6_PACK_WGX) x 8
+#define X6_PACK_WGX ((X6_H8 + 8 * 256 - 1) / (8 * 256))
+__global__ void k_pack_all(PackJobsAll jobs, X6PackArgs x6) {
+    if ((int)blockIdx.x < jobs.n) pack_job(jobs.j[blockIdx.x], blockIdx.y, gridDim.y);
+    else x6_pack_body(x6, (((int)blockIdx.x - jobs.n) * 8 + (int)blockIdx.y) * 256 + (int)threadIdx.x);
+}
+int launch_pack_all(const PackJobsAll& jobs, const X6PackArgs* x6, hipStream_t st) {
+    if (jobs.n == 0 && !x6) return 0;
+    X6PackArgs xa; memset(&xa, 0, sizeof(xa));
+    if (x6) xa = *x6;
+    hipLaunchKernelGGL(k_pack_all, dim3(jobs.n + (x6 ? X6_PACK_WGX : 0), 8), dim3(256), 0, st, jobs, xa);
     LAUNCHCK();
     return 0;
 }
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(ReduceJobs jobs) {
     }
 }
 
-static_assert(sizeof(WgradJobs) <= 4000 && sizeof(ReduceJobs) <= 4000 && sizeof(PackJobs) <= 4000 && sizeof(PackJobsAll) <= 4000, "kernel argument blocks must stay under 4 KB");
+static_assert(sizeof(WgradJobs) <= 4000 && sizeof(ReduceJobs) <= 4000 && sizeof(PackJobs) <= 4000 && sizeof(PackJobsAll) + sizeof(X6PackArgs) <= 4000, "kernel argument blocks must stay under 4 KB");
 
 // ---------------------------------------------------------------- host launchers (kept in this TU: no relocatable device code needed)
 int launch_pack(const PackJobs& jobs, hipStream_t st) {

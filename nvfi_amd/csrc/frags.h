@@ -9,9 +9,10 @@
 #pragma once
 #include "common.h"
 #include "pde.h"
+#include "x6.h"
 
 #define A_X4B_FLOATS (4 * X4_FLOATS(4, 64) + X4_FLOATS(4, 4))      // transposed x4 fragments t[1..5] of a_weight_net (pde_fuse.hip)
-struct FragCache { float *render, *vel, *anet, *vel_x4f, *vel_x4b, *a_x4b; int64_t total; };
+struct FragCache { float *render, *vel, *anet, *vel_x4f, *vel_x4b, *a_x4b; void* vel_x6; int64_t total; };
 static inline void frag_cache_layout(const float* base, FragCache* c) {
     Bump B{(char*)base, 0, 0};
     c->render = B.take<float>(RENDER_FRAG_FLOATS);
@@ -20,6 +21,7 @@ static inline void frag_cache_layout(const float* base, FragCache* c) {
     c->vel_x4f = B.take<float>(VEL_X4F_FLOATS);
     c->vel_x4b = B.take<float>(VEL_X4B_FLOATS);
     c->a_x4b = B.take<float>(A_X4B_FLOATS);
+    c->vel_x6 = B.take<float>(X6_IMAGE_BYTES / 4);         // the three bfloat16 images of weight_net's layers 0..4 (vel_x6.hip)
     c->total = align_up(B.off, 256);
 }
 // pointer tables into the x4 regions (the layouts pack_vel_x4_fwd / pack_vel_x4_bwd write)
@@ -41,4 +43,4 @@ static inline void a_x4b_pointers(const float* buf, const float4** ta4) {   // t
     for (int l = 1; l <= 4; ++l) { ta4[l] = reinterpret_cast<const float4*>(p); p += X4_FLOATS(4, 64); }
     ta4[5] = reinterpret_cast<const float4*>(p);
 }
-int launch_pack_all(const PackJobsAll& jobs, hipStream_t st);
+int launch_pack_all(const PackJobsAll& jobs, const X6PackArgs* x6, hipStream_t st);

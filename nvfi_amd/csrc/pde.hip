@@ -746,7 +746,8 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     // (no gz_1..gz_4 stash, no second pass over the z / zd stash); 0: k_pde_jet_bwd + k_wgrad_ring8 over the full adjoint stash
     static int pde_fuse = -1;
     if (pde_fuse < 0) { const char* e = getenv("NVFI_PDE_FUSE"); pde_fuse = e ? atoi(e) : 1; }
-    // prefilter mode: fp32 (default: the feature-split kernel of vel_split.hip) | engine32 (k_rk2_fwd of vel.hip: the same numbers bit for
+    // prefilter mode: x6 (default, round 5: vel_x6.hip - the fp32 products of the hidden layers formed exactly on the 16-bit matrix pipe) | fp32 (the
+    // feature-split fp32 MFMA kernel of vel_split.hip, the default of rounds 2-4) | engine32 (k_rk2_fwd of vel.hip: the same numbers bit for
     // bit, ~4 % slower) | fp16band (pre16.hip: fp16-input pass + fp32 re-evaluation of the unsafe points)
     // split16band (opt-in, pre16.hip): the pre-pass with fp32 products emulated by two binary16 terms per operand (three fp16 MFMAs), and a
     // band 100 x narrower than fp16band's in front of the same fp32 re-evaluation
@@ -756,7 +757,8 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         if (e && strcmp(e, "fp16band") && strcmp(e, "split16band") && strcmp(e, "fp32") && strcmp(e, "split32") && strcmp(e, "engine32") && strcmp(e, "x6"))
             return nvfi_fail(2, "NVFI_PDE_PREFILTER must be fp32, engine32, x6, fp16band or split16band");
         // 2 = split kernel ("split32" = "fp32"); 4 = x6 (vel_x6.hip: fp32 products formed exactly from three binary16 terms per operand)
-        pre16 = !e ? 2 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "split16band") ? 3 : (!strcmp(e, "engine32") ? 0 : (!strcmp(e, "x6") ? 4 : 2))));
+        // round 5: x6 is the default - its error against float64 is not larger than the fp32 MFMA kernel's (tests/test_gpu_x6.py) and it is 1.35x faster
+        pre16 = !e ? 4 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "split16band") ? 3 : (!strcmp(e, "engine32") ? 0 : (!strcmp(e, "x6") ? 4 : 2))));
         if (pre16 == 3) { band16 = 1e-3f; eps16 = 2e-5f; }
         if ((e = getenv("NVFI_PDE_BAND"))) band16 = (float)atof(e);
         if ((e = getenv("NVFI_PDE_GATE_EPS"))) eps16 = (float)atof(e);
@@ -813,9 +815,9 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         if (launch_density_q(da, P, st)) return 1;
     } else if (pre16 == 4) {
         X6Args xa; memset(&xa, 0, sizeof(xa));
-        xa.f = *f; xa.img = L.x6img; xa.n_direct = P; xa.list = L.perm; xa.xw = L.xw; xa.pt_t = L.pt_t_perm; xa.pt_base = L.pt_base_perm;
+        xa.f = *f; xa.img = cached ? FC.vel_x6 : L.x6img; xa.n_direct = P; xa.list = L.perm; xa.xw = L.xw; xa.pt_t = L.pt_t_perm; xa.pt_base = L.pt_base_perm;
         xa.dt_max = ra.dt_max; xa.max_steps = PDE_MAX_CLASS;
-        if (launch_pack_x6(f->vW, L.x6img, st)) return 1;
+        if (!cached && launch_pack_x6(f->vW, L.x6img, st)) return 1;
         { ProfScope ps(PK_PDE_PREFILTER, st); if (launch_rk2_x6(xa, P, st)) return 1; }
         da.n_direct = P; da.xw = L.xw;
         if (launch_density_q(da, P, st)) return 1;

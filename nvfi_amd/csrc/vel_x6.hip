@@ -24,40 +24,15 @@
 // bytes) stream from L2 two K steps ahead; the layer input travels between the waves through LDS already split: every lane writes the
 // six 16-byte B operands (3 terms x 2 K steps) of its 16 outputs and reads 3 x 8 per tile and layer.
 #include <stdlib.h>
+#include <utility>
 #include "common.h"
 #include "vel.h"
 #include "pde.h"
 #include "engine16.h"
 #include "x6.h"
 
-// ---------------------------------------------------------------- packing: three bfloat16 images of layers 0..4
-__device__ __forceinline__ void split3(float x, __bf16& t1, __bf16& t2, __bf16& t3) {
-    t1 = (__bf16)x;
-    const float r1 = x - (float)t1;
-    t2 = (__bf16)r1;
-    t3 = (__bf16)(r1 - (float)t2);
-}
-__global__ __launch_bounds__(256) void k_pack_x6(X6PackArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= X6_H8) return;
-    int l, local, NS, in, kind;
-    if (idx < 512) { l = 0; local = idx; NS = 2; in = 28; kind = SK_VEL_IN; }
-    else { l = 1 + (idx - 512) / 2048; local = (idx - 512) % 2048; NS = 8; in = 128; kind = SK_HIDDEN; }
-    const int lane = local & 63, ms = local >> 6, s = ms % NS, m = ms / NS;
-    const int row = 32 * m + (lane & 31), h = lane >> 5;
-    const float* W = a.W[l];
-    b8_t v1, v2, v3;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int feat = slot_logical(kind, 2 * (8 * s + j) + h);     // register 8 s + j of lane half h of the producing layer (engine.h)
-        float w = 0.f;
-        if (feat >= 0 && feat < in) w = W[(size_t)row * in + feat];
-        __bf16 t1, t2, t3;
-        split3(w, t1, t2, t3);
-        v1[j] = t1; v2[j] = t2; v3[j] = t3;
-    }
-    a.img[idx] = v1; a.img[X6_H8 + idx] = v2; a.img[2 * X6_H8 + idx] = v3;
-}
+// ---------------------------------------------------------------- packing: three bfloat16 images of layers 0..4 (x6_pack_body, x6.h)
+__global__ __launch_bounds__(256) void k_pack_x6(X6PackArgs a) { x6_pack_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
 int launch_pack_x6(const float* const* W, void* img, hipStream_t st) {
     X6PackArgs pk;
     for (int l = 0; l < 5; ++l) pk.W[l] = W[l];
@@ -240,8 +215,215 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
     }
 }
 
+// ---------------------------------------------------------------- the same evaluation, software-pipelined over two tiles in ONE wave per SIMD
+// The 16-bit MFMA leaves 4-5 issue slots per instruction to the issuing wave's own VALU / LDS work and nothing to the other waves of the SIMD
+// (dual_pipe_probe3), so the epilogue of a layer - sum of the three accumulators, SiLU, three-term split, exchange through LDS: ~350 VALU
+// instructions per tile - only disappears behind matrix work that the SAME wave issues.  Here a workgroup (four waves, one per SIMD, the whole
+// 512-register file each) owns two tiles X and Y and alternates: while the 48 MFMAs of one tile's layer are issued, the other tile's epilogue
+// runs between them -   E(X,0) | L0(Y)    E(Y,l) | M(X,l)    E(X,l+1) | M(Y,l)   ...   VOUT(X) | M(Y,3)    VOUT(Y).
+// A tile's exchange buffer is written in one slot and read in the same slot behind ONE barrier; its previous readers finished a slot earlier.
+// Operand lifetime rule as above: Bf[T] is refilled inside E(T), behind the read of T's accumulators.
+__device__ __forceinline__ void x6_step0(const b8_t& A1, const b8_t& A2, const b8_t& A3, const b8_t& B1, const b8_t& B2, const b8_t& B3,
+                                         f32x16& a0, f32x16& a1, f32x16& a2) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // (the SrcC inline constant 0: no register clears)
+    a0 = MFMA16B(A1, B1, zero);
+    a1 = MFMA16B(A1, B2, zero);
+    a2 = MFMA16B(A2, B2, zero);
+    a1 = MFMA16B(A2, B1, a1);
+    a2 = MFMA16B(A1, B3, a2);
+    a2 = MFMA16B(A3, B1, a2);
+}
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+
+struct X6P {
+    const b8_t *W1, *W2, *W3; b8_t* xch; const float* lb; int w, lane, h;
+};
+typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+// three-term split of a PAIR of values: one packed conversion per term (v_cvt_pk_bf16_f32), the residuals exact
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const b2_t t1 = {(__bf16)x, (__bf16)y};
+    const float rx = x - (float)t1[0], ry = y - (float)t1[1];
+    const b2_t t2 = {(__bf16)rx, (__bf16)ry};
+    const b2_t t3 = {(__bf16)(rx - (float)t2[0]), (__bf16)(ry - (float)t2[1])};
+    p1 = __builtin_bit_cast(unsigned, t1); p2 = __builtin_bit_cast(unsigned, t2); p3 = __builtin_bit_cast(unsigned, t3);
+}
+// MFMA number I (0..47) of a tile's layer: K step I / 6, product I % 6 in x6_step's order; the first of every accumulator starts from SrcC = 0
+template <int I>
+__device__ __forceinline__ void x6p_one(const b8_t (&A1)[4], const b8_t (&A2)[4], const b8_t (&A3)[4], const b8_t (&Bf)[8][3], f32x16& a0, f32x16& a1, f32x16& a2) {
+    constexpr int s = I / 6, j = I % 6, k = s & 3;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (j == 0) a0 = MFMA16B(A1[k], Bf[s][0], s == 0 ? zero : a0);
+    else if (j == 1) a1 = MFMA16B(A1[k], Bf[s][1], s == 0 ? zero : a1);
+    else if (j == 2) a2 = MFMA16B(A2[k], Bf[s][1], s == 0 ? zero : a2);
+    else if (j == 3) a1 = MFMA16B(A2[k], Bf[s][0], a1);
+    else if (j == 4) a2 = MFMA16B(A1[k], Bf[s][2], a2);
+    else a2 = MFMA16B(A3[k], Bf[s][0], a2);
+}
+template <int... Is, class F> __device__ __forceinline__ void x6p_for(std::integer_sequence<int, Is...>, F f) { (f(std::integral_constant<int, Is>{}), ...); }
+
+// one slot: the epilogue of tile `te` (its layer `le` output -> its layer le + 1 input) between the MFMAs of the other tile (layer lm + 1),
+// interleaved BY HAND - one MFMA, then a piece of the epilogue that fits the issue slots the MFMA leaves (the scheduler, asked through
+// sched_group_barrier, put the whole epilogue in front of the MFMAs); a sched_barrier after every piece pins the order
+// HAVE_M = false: nothing to interleave (the first slot runs beside layer 0 of Y, issued by the caller)
+template <bool HAVE_M>
+__device__ __forceinline__ void x6p_slot(const X6P& c, int te, int le, int lm, b8_t (&BfE)[8][3], f32x16& e0, f32x16& e1, f32x16& e2,
+                                         const b8_t (&BfM)[8][3], f32x16& m0, f32x16& m1, f32x16& m2) {
+    const int w = c.w, lane = c.lane, h = c.h;
+    const b8_t* P1 = c.W1 + X6_LH(lm + 1) + (w * 8) * 64 + lane;
+    const b8_t* P2 = c.W2 + X6_LH(lm + 1) + (w * 8) * 64 + lane;
+    const b8_t* P3 = c.W3 + X6_LH(lm + 1) + (w * 8) * 64 + lane;
+    b8_t A1[4], A2[4], A3[4];
+    if (HAVE_M) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { A1[s] = P1[s * 64]; A2[s] = P2[s * 64]; A3[s] = P3[s * 64]; }
+    }
+    // the read of tile te's accumulators: behind it its MFMAs have completed and BfE may be refilled
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = ((e2[r] + e1[r]) + e0[r]) + c.lb[128 * le + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(BfE[s][0]), "v"(BfE[s][1]), "v"(BfE[s][2]), "v"(v[0]), "v"(v[15]));
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned pk[3][8];          // the split values: term, pair
+    b8_t* dst = c.xch + (size_t)te * X6_XCH_H8 + (2 * w) * 64 + lane;
+    auto piece = [&](auto Ic) {
+        constexpr int I = decltype(Ic)::value;
+        if constexpr (I < 16) v[I] = act_f<1>(v[I]);                                    // SiLU of one value
+        else if constexpr (I < 24) split3_pair(v[2 * (I - 16)], v[2 * (I - 16) + 1], pk[0][I - 16], pk[1][I - 16], pk[2][I - 16]);
+        else if constexpr (I < 30) {                                                    // one of the six 16-byte LDS writes
+            constexpr int term = (I - 24) % 3, k = (I - 24) / 3;
+            const u4_t q = {pk[term][4 * k], pk[term][4 * k + 1], pk[term][4 * k + 2], pk[term][4 * k + 3]};
+            dst[k * 64 + term * 8 * 64] = __builtin_bit_cast(b8_t, q);
+        }
+    };
+    if (HAVE_M) {
+        x6p_for(std::make_integer_sequence<int, 36>{}, [&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            x6p_one<I>(A1, A2, A3, BfM, m0, m1, m2);
+            if (I % 6 == 5 && I / 6 + 3 < 8) { constexpr int s = I / 6; A1[(s + 3) & 3] = P1[(s + 3) * 64]; A2[(s + 3) & 3] = P2[(s + 3) * 64]; A3[(s + 3) & 3] = P3[(s + 3) * 64]; }
+            piece(Ic);
+        });
+        // the order asked of the scheduler: one MFMA, then the piece of the epilogue that fits behind it
+#pragma unroll
+        for (int i = 0; i < 36; ++i) {
+            SGB(0x008, 1);
+            if (i < 16) { SGB(0x002, 3); SGB(0x400, 2); }
+            else if (i < 24) SGB(0x002, 11);
+            else if (i < 30) { SGB(0x002, 2); SGB(0x200, 1); }
+            if (i % 6 == 5 && i / 6 + 3 < 8) SGB(0x020, 3);
+        }
+    } else {
+        x6p_for(std::make_integer_sequence<int, 30>{}, piece);
+    }
+    __syncthreads();                                     // tile te's layer input is complete in LDS (its previous readers finished a slot ago)
+    const b8_t* src = c.xch + (size_t)te * X6_XCH_H8 + lane;
+    if (HAVE_M) {
+        x6p_for(std::make_integer_sequence<int, 12>{}, [&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            x6p_one<36 + I>(A1, A2, A3, BfM, m0, m1, m2);
+            // two of the 24 B operands of tile te's next layer per MFMA
+            constexpr int o0 = 2 * I, o1 = 2 * I + 1;
+            BfE[o0 / 3][o0 % 3] = src[(o0 / 3) * 64 + (o0 % 3) * 8 * 64];
+            BfE[o1 / 3][o1 % 3] = src[(o1 / 3) * 64 + (o1 % 3) * 8 * 64];
+        });
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { SGB(0x008, 1); SGB(0x100, 2); }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { BfE[s][0] = src[s * 64]; BfE[s][1] = src[s * 64 + 8 * 64]; BfE[s][2] = src[s * 64 + 16 * 64]; }
+    }
+}
+
+__device__ __forceinline__ void x6p_vout(const X6P& c, int t, float4* part, const float4* w5l, const b8_t (&Bf)[8][3], const f32x16& a0, const f32x16& a1, const f32x16& a2) {
+    const int w = c.w, lane = c.lane, h = c.h;
+    float zl[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zl[r] = ((a2[r] + a1[r]) + a0[r]) + c.lb[128 * 4 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(Bf[s][0]), "v"(Bf[s][1]), "v"(Bf[s][2]), "v"(zl[0]), "v"(zl[15]));
+    __builtin_amdgcn_sched_barrier(0);
+    float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float4* wl = w5l + (w * 2 + h) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float4 wa = wl[2 * r], wb = wl[2 * r + 1];
+        const float av = act_f<1>(zl[r]);
+        p[0] = __builtin_fmaf(av, wa.x, p[0]); p[1] = __builtin_fmaf(av, wa.y, p[1]); p[2] = __builtin_fmaf(av, wa.z, p[2]);
+        p[3] = __builtin_fmaf(av, wa.w, p[3]); p[4] = __builtin_fmaf(av, wb.x, p[4]); p[5] = __builtin_fmaf(av, wb.y, p[5]);
+    }
+#pragma unroll
+    for (int o = 0; o < 6; ++o) p[o] += __shfl_xor(p[o], 32);
+    if (h == 0) {
+        part[((t * 4 + w) * 2 + 0) * 32 + lane] = make_float4(p[0], p[1], p[2], p[3]);
+        part[((t * 4 + w) * 2 + 1) * 32 + lane] = make_float4(p[4], p[5], 0.f, 0.f);
+    }
+}
+
+__device__ __forceinline__ void velnet_x6p(const b8_t* __restrict__ img, b8_t* xch, float4* part, const float4* w5l, int w, int lane, int h,
+                                           const float4* q, const float* lb, float (&out6)[2][6]) {
+    X6P c; c.W1 = img; c.W2 = img + X6_H8; c.W3 = img + 2 * X6_H8; c.xch = xch; c.lb = lb; c.w = w; c.lane = lane; c.h = h;
+    f32x16 a0[2], a1[2], a2[2];
+    b8_t Bf[2][8][3];
+    // ---- layer 0 of both tiles (the bias of every layer is added in the epilogue: the accumulators start from the SrcC constant 0)
+    {
+        b8_t A1[2], A2[2], A3[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int o = X6_L0 + (w * 2 + s) * 64 + lane;
+            A1[s] = c.W1[o]; A2[s] = c.W2[o]; A3[s] = c.W3[o];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float x0[16];
+            vel_encode_slots(q[t], h, x0);
+            split3_8(x0, Bf[t][0][0], Bf[t][0][1], Bf[t][0][2]);
+            split3_8(x0 + 8, Bf[t][1][0], Bf[t][1][1], Bf[t][1][2]);
+            x6_step0(A1[0], A2[0], A3[0], Bf[t][0][0], Bf[t][0][1], Bf[t][0][2], a0[t], a1[t], a2[t]);
+            x6_step(A1[1], A2[1], A3[1], Bf[t][1][0], Bf[t][1][1], Bf[t][1][2], a0[t], a1[t], a2[t]);
+        }
+    }
+    // ---- E(X,0) beside L0(Y) (already issued), then the alternation
+    x6p_slot<false>(c, 0, 0, 0, Bf[0], a0[0], a1[0], a2[0], Bf[1], a0[1], a1[1], a2[1]);
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        x6p_slot<true>(c, 1, l, l, Bf[1], a0[1], a1[1], a2[1], Bf[0], a0[0], a1[0], a2[0]);            // E(Y,l) | M(X,l)
+        if (l < 3) x6p_slot<true>(c, 0, l + 1, l, Bf[0], a0[0], a1[0], a2[0], Bf[1], a0[1], a1[1], a2[1]);   // E(X,l+1) | M(Y,l)
+    }
+    // ---- VOUT(X) | M(Y,3), VOUT(Y)
+    {
+        const b8_t* P1 = c.W1 + X6_LH(4) + (w * 8) * 64 + lane;
+        const b8_t* P2 = c.W2 + X6_LH(4) + (w * 8) * 64 + lane;
+        const b8_t* P3 = c.W3 + X6_LH(4) + (w * 8) * 64 + lane;
+        b8_t A1[4], A2[4], A3[4];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { A1[s] = P1[s * 64]; A2[s] = P2[s * 64]; A3[s] = P3[s * 64]; }
+        // (VOUT(X) needs X's accumulators only: it is issued first, the 48 MFMAs of Y behind it fill the pipe while nothing else is left to do)
+        x6p_vout(c, 0, part, w5l, Bf[0], a0[0], a1[0], a2[0]);
+        x6p_for(std::make_integer_sequence<int, 48>{}, [&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            x6p_one<I>(A1, A2, A3, Bf[1], a0[1], a1[1], a2[1]);
+            if (I % 6 == 5 && I / 6 + 3 < 8) { constexpr int s = I / 6; A1[(s + 3) & 3] = P1[(s + 3) * 64]; A2[(s + 3) & 3] = P2[(s + 3) * 64]; A3[(s + 3) & 3] = P3[(s + 3) * 64]; }
+        });
+        x6p_vout(c, 1, part, w5l, Bf[1], a0[1], a1[1], a2[1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int o = 0; o < 6; ++o) out6[t][o] = lb[128 * 5 + o];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float4 A = part[((t * 4 + ww) * 2 + 0) * 32 + (lane & 31)], B = part[((t * 4 + ww) * 2 + 1) * 32 + (lane & 31)];
+            out6[t][0] += A.x; out6[t][1] += A.y; out6[t][2] += A.z; out6[t][3] += A.w; out6[t][4] += B.x; out6[t][5] += B.y;
+        }
+    }
+}
+
 // the recurrence of k_rk2_split<NT, true> (vel_split.hip), per-point times
-template <int NT>
+template <int NT, bool PIPE = false>
 __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6(X6Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     b8_t* xch = reinterpret_cast<b8_t*>(lds);
@@ -288,7 +470,7 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6(X6Args a
         float4 q[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur[t]);
-        velnet_x6<NT>(img, xch, part, w5l, w, lane, h, q, lb, o6);
+        if constexpr (PIPE) velnet_x6p(img, xch, part, w5l, w, lane, h, q, lb, o6); else velnet_x6<NT>(img, xch, part, w5l, w, lane, h, q, lb, o6);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v1[3];
@@ -298,7 +480,7 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6(X6Args a
             px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
             q[t] = make_float4(px[t], py[t], pz[t], tcur[t] - hdt);
         }
-        velnet_x6<NT>(img, xch, part, w5l, w, lane, h, q, lb, o6);
+        if constexpr (PIPE) velnet_x6p(img, xch, part, w5l, w, lane, h, q, lb, o6); else velnet_x6<NT>(img, xch, part, w5l, w, lane, h, q, lb, o6);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v2[3];
@@ -323,11 +505,13 @@ int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st) {
     if (tiles <= 0) return 0;
     static int nt = -1;
     if (nt < 0) {
-        const char* e = getenv("NVFI_X6_NT"); nt = e ? atoi(e) : 2;
+        const char* e = getenv("NVFI_X6_NT"); nt = e ? atoi(e) : 1;      // (1: 0.97 ms, 2: 1.10 ms for the bench prefilter; 3: the pipelined two-tile kernel)
         HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES(1)));
         HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6<2>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES(2)));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES(2)));
     }
-    if (nt == 1) hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), X6_LDS_BYTES(1), st, a);
+    if (nt == 3) hipLaunchKernelGGL((k_rk2_x6<2, true>), dim3((unsigned)((tiles + 1) / 2)), dim3(WG_THREADS), X6_LDS_BYTES(2), st, a);
+    else if (nt == 1) hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), X6_LDS_BYTES(1), st, a);
     else hipLaunchKernelGGL(k_rk2_x6<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(WG_THREADS), X6_LDS_BYTES(2), st, a);
     LAUNCHCK();
     return 0;

@@ -1,0 +1,107 @@
+"""The x6 kernels (nvfi_amd/csrc/vel_x6.hip): the hidden layers of the velocity net with every fp32 product formed EXACTLY from three
+bfloat16 terms per operand on the 16-bit matrix pipe (six MFMAs per K step, three accumulators by magnitude class, fp32 accumulation).
+
+* accuracy: integrate_pos (tensorf_keyframe.py:575-611) through x6 and through the fp32 MFMA kernels against a float64 restatement on the
+  199^3 bench field and on fields A / B: the x6 error is not larger than the fp32 kernels' (both sit on the rounding floor of the fp32
+  RK2 recurrence), no outliers, bit-reproducible from run to run (the operand-lifetime rule of vel_x6.hip: without it 0.1-1 % of the
+  tiles came back with their points 16..31 off by 1e-5);
+* the PDE occupancy prefilter on x6 (NVFI_PDE_PREFILTER=x6): kept set, loss and gradients against the fp32 prefilter on 10^6 points of
+  three fields and the bench field, ragged counts, the reference's PDE goldens, and every keep / drop decision on 10^7 points."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, relerr
+from helpers import make_model
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _fields():
+    import bench
+    yield "bench", bench.build_scene(torch.device("cuda"), 199, 128, True)
+    for kind in ("A", "B"):
+        yield kind, make_model(kind)[0]
+
+
+@pytest.mark.parametrize("nsteps", [1, 4, 10])
+def test_x6_integrate_pos_is_as_accurate_as_the_fp32_kernels(nsteps):
+    from x6_check import integrate64
+    N = 1 << 16
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for name, model in _fields():
+        f = model.nvfi
+        f.eval()
+        ts = f.tmax / (f.num_keyframes - 1)
+        x = torch.rand(N, 3, device="cuda", generator=g) * 1.6 - 0.8
+        tt = torch.full((N, 1), float(np.float32(ts * 0.5 * nsteps * 0.999)), device="cuda")
+        base = torch.zeros(N, 1, device="cuda")
+        ref = integrate64(f, x.cpu().numpy(), tt.cpu().numpy()[:, 0], base.cpu().numpy()[:, 0])
+        err = {}
+        for mode_name, mode in (("fp32", False), ("x6", 3)):
+            f.vel_fp16 = mode
+            with torch.no_grad():
+                outs = [f.integrate_pos(x.clone(), tt.clone(), base).cpu().numpy() for _ in range(3)]
+            assert all(np.array_equal(outs[0], o) for o in outs[1:]), (name, mode_name, "not reproducible")
+            e = np.abs(outs[0].astype(np.float64) - ref).max(1)
+            err[mode_name] = (float(e.max()), float(np.sqrt((e ** 2).mean())), float((e > 20 * np.median(e) + 1e-7).mean()))
+        f.vel_fp16 = False
+        print(f"{name}, {nsteps} RK2 steps: max / rms error against float64: fp32 kernels {err['fp32'][0]:.2e} / {err['fp32'][1]:.2e}, "
+              f"x6 {err['x6'][0]:.2e} / {err['x6'][1]:.2e}")
+        assert err["x6"][0] <= 1.25 * err["fp32"][0] + 1e-9 and err["x6"][1] <= 1.05 * err["fp32"][1] + 1e-10, (name, err)
+        assert err["x6"][2] <= err["fp32"][2], (name, "outliers", err)      # (a point that takes another gate branch than float64 does is an outlier of BOTH kernels)
+
+
+def _run(tmp_path, mode, extra=(), n=262144, **switches):
+    out = str(tmp_path / f"x6_{mode}_{n}_{'_'.join(f'{k}{v}' for k, v in switches.items())}.npz")
+    env = dict(os.environ, NVFI_PDE_PREFILTER=mode, **{k: str(v) for k, v in switches.items()})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pre16_check.py"), out, str(n), *extra], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("n,extra,nt", [(1000000, (), 1), (262144, ("--bench",), 1), (262144, ("--bench",), 2), (37, (), 1), (1000, (), 2)])
+def test_x6_prefilter_keeps_the_fp32_set(tmp_path, n, extra, nt):
+    """both prefilters decide `alpha >= alphaMask_thres` on positions that differ by rounding (another summation order of the same fp32
+    products): a point would have to sit within ~1e-7 of the threshold to flip - at most a handful among 10^6"""
+    a, b = _run(tmp_path, "fp32", extra, n), _run(tmp_path, "x6", extra, n, NVFI_X6_NT=nt)
+    for name in ("A", "B", "cfg1") + (("bench",) if extra else ()):
+        ka, kb = a[f"{name}:kept"], b[f"{name}:kept"]
+        flips = int((ka != kb).sum())
+        print(f"{name}: kept {int(ka.sum())} / {int(kb.sum())} of {ka.size}, flips {flips}; get_vel_loss {float(a[f'{name}:ms']):.3f} ms fp32 -> {float(b[f'{name}:ms']):.3f} ms x6")
+        assert flips <= 2, (name, flips)
+        np.testing.assert_allclose(float(a[f"{name}:loss"]), float(b[f"{name}:loss"]), rtol=1e-4 if flips else 1e-5)
+        if not flips:
+            for k in a.files:
+                if k.startswith(f"{name}:grad:"):
+                    assert relerr(b[k], a[k]) < 2e-5, k
+
+
+def test_x6_prefilter_flip_count_on_ten_million_points(tmp_path):
+    n = 10 * (1 << 20)
+    out = {}
+    for mode in ("fp32", "x6"):
+        path = str(tmp_path / f"flips_{mode}.npz")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pre16_check.py"), path, "--flips", str(n)], env=dict(os.environ, NVFI_PDE_PREFILTER=mode),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[mode] = np.load(path)
+    a, b = np.unpackbits(out["fp32"]["kept"]), np.unpackbits(out["x6"]["kept"])
+    flips = int((a != b).sum())
+    print(f"bench field: {int(out['fp32']['n'])} points, kept {int(a.sum())}; decisions that differ between the fp32 and the x6 prefilter: {flips}")
+    assert int(out["fp32"]["n"]) >= 10 ** 7 and int(a.sum()) > 10 ** 6
+    assert flips <= 8, flips          # (two fp32 summation orders of one quantity: a point within ~1e-7 of the threshold may land on either side)
+
+
+def test_x6_prefilter_under_the_reference_goldens():
+    env = dict(os.environ, NVFI_PDE_PREFILTER="x6")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_fullsize_chessboard.py"), os.path.join(ROOT, "tests", "test_gpu_fullsize.py"), "-k", "pde"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

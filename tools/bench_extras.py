@@ -88,6 +88,9 @@ def collect(args, out, model):
         "eval_frame": dict(X([ "eval_frame"], script=me, timeout=600),
                            what="SURVEY 8d config 2's other half: one full 800x800 TEST-mode frame (640 000 rays, 128 samples per ray; train_nvfi.py:395-459 -> "
                                 "Renderer.render(mode='test')) at a non-keyframe time with the velocity field, and radiance-only; ms per frame, rays/s, roofline"),
+        "fp32_mfma_prefilter": dict(X(["--graph", "off"], {"NVFI_PDE_PREFILTER": "fp32"}),
+                                    what="the default of rounds 2-4: the PDE occupancy prefilter on the fp32 MFMA kernel (vel_split.hip) instead of x6 (vel_x6.hip: the same fp32 "
+                                         "products formed exactly from three bfloat16 terms per operand on the 16-bit matrix pipe)"),
         "optin_split16band_prefilter": dict(X(["--graph", "off"], {"NVFI_PDE_PREFILTER": "split16band"}),
                                             what="opt-in (NOT the headline): the PDE occupancy prefilter with fp32 products emulated on the fp16 matrix pipe (two binary16 "
                                                  "terms per operand, three MFMAs, fp32 accumulation: ~2^-21 relative per product) + an fp32 re-evaluation band of 0.1 %; "

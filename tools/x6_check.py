@@ -52,7 +52,10 @@ def integrate64(f, x0, t, base):
         v1 = vel64(net, x, tc, lo, hi)
         pm = x - 0.5 * dt[:, None] * v1
         v2 = vel64(net, pm, tc - 0.5 * dt, lo, hi)
-        x = np.where(live[:, None], x - dt[:, None] * v2, x)
+        xn = x - dt[:, None] * v2
+        if gsur:        # VelocityAABBSur: a step that would leave the surround box is rejected (tensorf_keyframe.py:603-605)
+            live = live & ~((xn < lo) | (xn > hi)).any(1)
+        x = np.where(live[:, None], xn, x)
         off = off - dt; tc = tc - dt
         off[np.abs(off) < 1e-12] = 0.0
     return x
