@@ -12,6 +12,10 @@ HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith(".h")) + [os.path.joi
 SO = os.environ.get("NVFI_BUILD_SO", os.path.join(CSRC, "libnvfi_hip.so"))   # experiments build a second library elsewhere
 OBJDIR = os.environ.get("NVFI_BUILD_OBJDIR", CSRC)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"] + os.environ.get("NVFI_EXTRA_FLAGS", "").split()
+# per-file flags.  vel_x6.hip: no SLP vectorisation, i.e. no packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in the
+# kernels that run two workgroups per CU beside 16-bit MFMAs - with them one encoder input of one wave came out wrong in lanes 48..63
+# once per few hundred tiles (delta debugging in DESIGN.md 4.8; tests/test_gpu_x6.py repeats 4 M points bit for bit)
+FILE_FLAGS = {"vel_x6.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(a, b):
@@ -33,7 +37,7 @@ def build(force=False, verbose=False):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

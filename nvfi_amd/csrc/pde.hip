@@ -855,7 +855,9 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     // adjoint half on the other one: the host's wait then covers the prefilter AND the forward (the caller's own wait for the value, `if loss_vel > 0`,
     // returns at once) and the device does not idle between the prefilter and the jets while the host wakes up (30-140 us per iteration in a trace).
     const bool defer_host = host_info && t_bwd_stream && P <= L.chunk && grads;
-    int hcnt_early[PDE_MAX_CLASS + 16];
+    // (static storage, per host thread: an error return between the copy being queued and the wait must not leave the copy a dead stack frame
+    // to write into - ADVICE r4)
+    static thread_local int hcnt_early[PDE_MAX_CLASS + 16];
     bool early_copy = false;
     auto read_host_info = [&]() -> int {
         int hcnt[PDE_MAX_CLASS + 16];
@@ -912,7 +914,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
                 // the host's copy of the counts is queued IN FRONT of the adjoint half: k_pde_fuse_bwd owns every CU for ~0.4 ms (12 waves x 168
                 // registers, 152 KB of LDS per workgroup) and a copy kernel queued behind its start waits for its first workgroup to retire - the
                 // caller's `if loss_vel > 0` then returned 0.43 ms late (trace of the drop-in loop)
-                if (defer_host) { HIPCK(hipMemcpyAsync(hcnt_early, L.cls_count, sizeof(hcnt_early), hipMemcpyDeviceToHost, st)); early_copy = true; }
+                if (defer_host) { HIPCK(hipMemcpyAsync(hcnt_early, L.cls_count, sizeof(int) * (PDE_MAX_CLASS + 16), hipMemcpyDeviceToHost, st)); early_copy = true; }
                 HIPCK(hipEventRecord(t_split_ev, st));
                 HIPCK(hipStreamWaitEvent(t_bwd_stream, t_split_ev, 0));
                 sb = t_bwd_stream;

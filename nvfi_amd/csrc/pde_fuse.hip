@@ -621,13 +621,17 @@ int launch_pde_fuse_bwd(const PdeFuseArgs& a, int64_t cap_points, int max_slabs,
     *nslab_out = 0;
     const int64_t tiles = (cap_points + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t prop;
-        ncu = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    static int ncu_dev[64] = {0};                          // per device: the attribute and the CU count belong to the current device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!ncu_dev[dev]) {
+        hipDeviceProp_t prop;
+        int n = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
         HIPCK(hipFuncSetAttribute((const void*)k_pde_fuse_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS_BYTES));
+        ncu_dev[dev] = n;
     }
+    const int ncu = ncu_dev[dev];
     static int reserve = -1;                              // NVFI_FUSE_RESERVE=n (experiment): see launch_rk2_fuse_bwd
     if (reserve < 0) { const char* e = getenv("NVFI_FUSE_RESERVE"); reserve = e ? atoi(e) : 0; }
     int G = ncu - reserve < max_slabs ? ncu - reserve : max_slabs;

@@ -15,6 +15,7 @@
 #include "scatter.h"
 #include "pde.h"
 #include "frags.h"
+#include "x6.h"
 #include <stdlib.h>
 #include <mutex>
 
@@ -1319,7 +1320,7 @@ struct RenderPlan {
     uint8_t *valid, *mflag, *rflag;
     float4 *xw, *rgbs, *rgb_pre, *gxw, *gxk;
     float *xpre, *gxpre;
-    float *vel_frag, *render_frag, *vel_x4, *vel_x4b; void* img16;
+    float *vel_frag, *render_frag, *vel_x4, *vel_x4b; void* img16; void* x6img;
     TileWork tw2; float* slabs2;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     unsigned* app_relu;
@@ -1369,6 +1370,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->vel_x4 = nsteps > 0 ? B.take<float>(VEL_X4F_FLOATS) : nullptr;
     P->img16 = (nsteps > 0 && ((!train && (f->vel_fp16 & 3)) || (train && (f->vel_fp16 & 4)))) ? (void*)B.take<float4>(2 * PRE16_IMAGE_BYTES / 16) : nullptr;   // fp16 images (hi, lo)
     P->vel_x4b = (nsteps > 0 && train) ? B.take<float>(VEL_X4B_FLOATS) : nullptr;
+    P->x6img = nsteps > 0 ? (void*)B.take<float>(X6_IMAGE_BYTES / 4) : nullptr;      // the x6 images when the descriptor carries no fragment cache
     P->render_frag = B.take<float>(RENDER_FRAG_FLOATS);
     P->maskv = (flags & NVFI_WANT_MASK) ? B.take<float>(N * 32) : nullptr;
     P->mask_frag = (flags & NVFI_WANT_MASK) ? B.take<float>(64 * 1024) : nullptr;
@@ -1530,7 +1532,16 @@ static int render_fwd_impl(const nvfi_field_desc* f, int64_t R, const float* ray
         // the feature-split layout of vel_split.hip (NVFI_RK2_SPLIT=0: k_rk2_fwd of vel.hip; same stash, same numbers bit for bit)
         static int split = -1;
         if (split < 0) { const char* e = getenv("NVFI_RK2_SPLIT"); split = e ? atoi(e) : 1; }
-        if (((f->vel_fp16 & 3) && !train) || ((f->vel_fp16 & 4) && train)) {
+        // round 5: the warp on the x6 evaluation (vel_x6.hip: the hidden layers' fp32 products formed exactly from three bfloat16 terms per operand
+        // on the 16-bit matrix pipe; same stash / records for the fp32 adjoint) unless NVFI_RK2_X6=0 or an fp16-input mode is asked for
+        static int x6 = -1;
+        if (x6 < 0) { const char* e = getenv("NVFI_RK2_X6"); x6 = e ? atoi(e) : 1; }
+        const int vf = f->vel_fp16 & 3;
+        if ((x6 && split && !(train && (f->vel_fp16 & 4)) && (train || vf == 0 || vf == 3)) || (!train && vf == 3)) {
+            X6UniArgs xa; xa.r = ra; xa.img = cached ? FC.vel_x6 : P.x6img;
+            if (!cached && launch_pack_x6(f->vW, P.x6img, st)) return 1;
+            if (launch_rk2_x6_uni(xa, N, train, st)) return 1;
+        } else if (((f->vel_fp16 & 3) && !train) || ((f->vel_fp16 & 4) && train)) {
             // opt-in fp16-input modes (pre16.hip): eval-mode renders (bits 0-1), and - bit 2 - the FORWARD of a training render's warp, which
             // writes the same stash as k_rk2_split_uni<STASH> (the adjoint and the weight gradients stay fp32 MFMA)
             Rk16Args h; memset(&h, 0, sizeof(h));

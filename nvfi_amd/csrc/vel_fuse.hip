@@ -73,6 +73,14 @@ struct FuseT { unsigned long long ft[64]; unsigned long long t0; };
 // w5 holds the T5 fragment on entry (requested by the previous evaluation, or by the caller for the first one) and that of the next evaluation
 // on exit (if zn); `hook()` is called once, at the end of phase 5: the caller issues its own prefetches (RK2 record of the next
 // evaluation) there.
+// The parked record / upstream gradient arrive by inline-asm LDS-DMA, outside the compiler's vmcnt bookkeeping; the reader's wait leaves the 16 g_0
+// stash stores of the previous evaluation (issued BEHIND the DMAs) in flight.  That count is tied to those 16 stores: a change to the stash
+// code must revisit it - NVFI_EXTRA_FLAGS=-DNVFI_FUSE_SAFE_WAIT builds the variant that waits for everything, to bisect with.
+#ifdef NVFI_FUSE_SAFE_WAIT
+#define FUSE_WAIT_PARK() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define FUSE_WAIT_PARK() asm volatile("s_waitcnt vmcnt(16)" ::: "memory")
+#endif
 template <class Hook>
 __device__ __forceinline__ void fuse_velnet_bwd(FuseA& A, const float4* const* t4, const float (&r4)[4], const float* zs, float* gs,
                                                 const float* zn, f32x4v& w5, f32x4v (&wq)[16], float (&zp)[16], float (&ge)[16], Hook hook FT_ARG) {
@@ -313,7 +321,7 @@ __device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* 
 #pragma unroll 1
     for (; tile < ntiles; tile += G) {
         if (first_eval) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's DMAs into its parking area have landed
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else FUSE_WAIT_PARK();
         float g3[3] = {active ? park[10 * 64 + lane] : 0.f, active ? park[11 * 64 + lane] : 0.f, active ? park[12 * 64 + lane] : 0.f};     // upstream gradient of the warped position
         const bool more_tiles = tile + G < ntiles;
         const int idx_t = (tile + G) * TILE + j;                 // this lane's sample in the next tile
@@ -339,7 +347,7 @@ __device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* 
                 if (last_of_tile && more_tiles) list_t = ra.list[iin0];      // (first half of the next tile's dependent pair of loads)
                 // this evaluation's record (DMA'd into the parking area during the previous evaluation's last phase, in front of its 16 g_0 stores)
                 if (first_eval) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else FUSE_WAIT_PARK();
                 first_eval = false;
                 float p[3], wv[6];
 #pragma unroll
@@ -494,13 +502,18 @@ int launch_rk2_fuse_bwd(const FuseBwdArgs& a, int64_t cap_samples, int max_slabs
     *nslab_out = 0;
     const int64_t tiles = (cap_samples + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t prop;
-        ncu = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    // per device: the dynamic-LDS attribute and the CU count belong to the device that is current at the call
+    static int ncu_dev[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!ncu_dev[dev]) {
+        hipDeviceProp_t prop;
+        int n = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
         HIPCK(hipFuncSetAttribute((const void*)k_rk2_fuse_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES));
+        ncu_dev[dev] = n;
     }
+    const int ncu = ncu_dev[dev];
     // NVFI_FUSE_RESERVE=n (experiment): leave n CUs to the kernels of the other streams (a persistent workgroup owns its CU: 12 waves x 168 registers)
     static int reserve = -1;
     if (reserve < 0) { const char* e = getenv("NVFI_FUSE_RESERVE"); reserve = e ? atoi(e) : 0; }

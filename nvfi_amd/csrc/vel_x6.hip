@@ -69,23 +69,23 @@ __device__ __forceinline__ void x6_step(const b8_t& A1, const b8_t& A2, const b8
 
 // one gated-velocity network evaluation of the workgroup's NT tiles (velnet_split_vout of vel_split.hip with x6 hidden layers)
 //
-// OPERAND LIFETIME RULE (measured, tools/tmp notes in DESIGN 4.8): the B operand registers of a v_mfma_f32_32x32x16_* must stay intact until
-// the instruction has COMPLETED, not merely issued.  A wave runs ahead of its queued MFMAs; a register set that a later instruction - an LDS
-// or L2 load returning, or a VALU write the allocator placed there - overwrote after the issue reached the matrix pipe with new contents
-// for the columns read last (points 16..31 of a tile off by ~1e-5, 0.1-1 % of the tiles, more with more waves per SIMD; the fp16 kernels
-// of pre16.hip keep a layer's B operands in registers for the whole layer and never showed it).  Hence:
-//   * a tile's whole layer input (8 K steps x 3 terms = 24 operands, 96 registers) is read from LDS BEFORE the layer's first MFMA and
-//     kept until the layer's accumulators have been read by the epilogue (a VALU read of an accumulator waits for the MFMAs that write it),
-//     pinned by an empty asm behind that read;
-//   * the A operands (weights) rotate through four register sets, refilled from L2 behind the MFMAs of a later step (A is consumed at issue:
-//     overwriting it early was never observed to matter - pre16.hip reloads A from LDS for every MFMA).
-template <int NT>
+// Schedule of one layer: the tile's whole layer input (8 K steps x 3 terms = 24 operands, 96 registers) is read from LDS, the A operands
+// (weights) rotate through four register sets refilled from L2 behind the MFMAs of a later step, and the layer ends with the drain - the
+// VALU read of the three accumulators (the compiler puts the s_nop the hardware needs in front of it) - behind which empty asm statements
+// keep every operand register of the layer alive.  The pins and the opaque step on the layer-0 operands are belt and braces from the hunt
+// described at the bottom of this file (they cost nothing); they are NOT what fixed it - tools/probes/mfma_hazard_probe.hip shows that
+// overwriting an MFMA's A or B registers straight behind its issue is harmless on gfx950.
+// STASH (training render): the fp32 pre-activations z of the five hidden layers (wave w = rows 16 w .. 16 w + 15 of each layer) and the encoder
+// slots go to the per-(evaluation, tile) stash in the layout of k_rk2_split_uni<STASH> (vel_split.hip): the fp32 adjoint kernels read it unchanged
+template <int NT, bool STASH = false>
 __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xch, float4* part, const float4* w5l, int w, int lane, int h,
-                                          const float4* q, const float* lb, float (&out6)[NT][6]) {
+                                          const float4* q, const float* lb, float (&out6)[NT][6], float* const* zst = nullptr, float* const* x0st = nullptr) {
     const b8_t* W1 = img; const b8_t* W2 = img + X6_H8; const b8_t* W3 = img + 2 * X6_H8;
     f32x16 a0[NT], a1[NT], a2[NT];
     b8_t Bf[NT][8][3];
     // ---- layer 0: every wave encodes the point itself (28 inputs in 16 slots per lane half = 2 K steps)
+    // v: the fp32 pre-activations of the layer just finished; every layer ends with the drain (the read of its accumulators) and the pins
+    float v[NT][16];
     {
         b8_t A1[2], A2[2], A3[2];
 #pragma unroll
@@ -97,21 +97,21 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
         for (int t = 0; t < NT; ++t) {
             float x0[16];
             vel_encode_slots(q[t], h, x0);
+            if (STASH && w == t) stash_store<16>(x0st[t], lane, x0);
             split3_8(x0, Bf[t][0][0], Bf[t][0][1], Bf[t][0][2]);
             split3_8(x0 + 8, Bf[t][1][0], Bf[t][1][1], Bf[t][1][2]);
+            // one register tuple per operand, alive until the pin behind the drain
+#pragma unroll
+            for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(Bf[t][s][0]), "+v"(Bf[t][s][1]), "+v"(Bf[t][s][2]));
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a0[t][r] = lb[32 * w + (r & 3) + 8 * (r >> 2) + 4 * h]; a1[t][r] = 0.f; a2[t][r] = 0.f; }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int t = 0; t < NT; ++t) x6_step(A1[s], A2[s], A3[s], Bf[t][s][0], Bf[t][s][1], Bf[t][s][2], a0[t], a1[t], a2[t]);
-    }
-#pragma unroll 1
-    for (int l = 0; l < 4; ++l) {
-        // epilogue of layer l, first half: the sums of the three magnitude classes, small ones first - the read of the accumulators is the
-        // point behind which the layer's MFMAs have completed
-        float v[NT][16];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -120,15 +120,26 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(Bf[t][s][0]), "v"(Bf[t][s][1]), "v"(Bf[t][s][2]), "v"(v[t][0]), "v"(v[t][15]));
+            for (int s = 0; s < 2; ++s) asm volatile("" :: "v"(Bf[t][s][0]), "v"(Bf[t][s][1]), "v"(Bf[t][s][2]), "v"(v[t][0]), "v"(v[t][15]));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) asm volatile("" :: "v"(A1[s]), "v"(A2[s]), "v"(A3[s]), "v"(v[0][0]), "v"(v[0][15]));
         __builtin_amdgcn_sched_barrier(0);
-        // the next layer's first three K steps start their trip from L2 now; they land behind the rest of the epilogue and the exchange
+    }
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        // the next layer's first three K steps start their trip from L2 now; they land behind the epilogue and the exchange
         const b8_t* P1 = W1 + X6_LH(l + 1) + (w * 8) * 64 + lane;
         const b8_t* P2 = W2 + X6_LH(l + 1) + (w * 8) * 64 + lane;
         const b8_t* P3 = W3 + X6_LH(l + 1) + (w * 8) * 64 + lane;
         b8_t A1[4], A2[4], A3[4];
 #pragma unroll
         for (int s = 0; s < 3; ++s) { A1[s] = P1[s * 64]; A2[s] = P2[s * 64]; A3[s] = P3[s * 64]; }
+        if (STASH) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) STASH_ST(zst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane], v[t][r]);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -162,6 +173,20 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
             if (s + 3 < 8) { A1[(s + 3) & 3] = P1[(s + 3) * 64]; A2[(s + 3) & 3] = P2[(s + 3) * 64]; A3[(s + 3) & 3] = P3[(s + 3) * 64]; }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // drain: the sums of the three magnitude classes, small ones first - the read of the accumulators is the point behind which the
+        // layer's MFMAs have completed; the pins keep every operand register of the layer untouched up to here
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[t][r] = (a2[t][r] + a1[t][r]) + a0[t][r];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(Bf[t][s][0]), "v"(Bf[t][s][1]), "v"(Bf[t][s][2]), "v"(v[t][0]), "v"(v[t][15]));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(A1[s]), "v"(A2[s]), "v"(A3[s]), "v"(v[0][0]), "v"(v[0][15]));
+        __builtin_amdgcn_sched_barrier(0);
     }
     // ---- 128 -> 6 output layer on the vector pipe (velnet_split_vout): fp32 FMAs over the 16 activations each lane holds
     float p[NT][6];
@@ -170,17 +195,13 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
 #pragma unroll
         for (int o = 0; o < 6; ++o) p[t][o] = 0.f;
     const float4* wl = w5l + (w * 2 + h) * 32;
-    float zl[NT][16];
+    float (&zl)[NT][16] = v;
+    if (STASH) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zl[t][r] = (a2[t][r] + a1[t][r]) + a0[t][r];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(Bf[t][s][0]), "v"(Bf[t][s][1]), "v"(Bf[t][s][2]), "v"(zl[t][0]), "v"(zl[t][15]));
-    __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < 16; ++r) STASH_ST(zst[t][(size_t)(4 * 64 + 16 * w + r) * REGF + lane], zl[t][r]);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if ((r & 1) == 0) __builtin_amdgcn_sched_barrier(0);
@@ -500,19 +521,158 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6(X6Args a
         }
 }
 
+// ---------------------------------------------------------------- render warp: every sample takes the same (dt_s, t_s) sequence
+// (rk2_split_uni_body of vel_split.hip on the x6 evaluation: same compact list, same in-place update, same stash and records)
+template <int NT, bool STASH>
+__global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6_uni(X6UniArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    b8_t* xch = reinterpret_cast<b8_t*>(lds);
+    float4* part = reinterpret_cast<float4*>(xch + NT * X6_XCH_H8);
+    const Rk2Args& ra = a.r;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int count = *ra.count;
+    // whole 128-sample groups when stashing: the adjoint and weight-gradient kernels walk every tile of the last, ragged group
+    if ((int)blockIdx.x * NT * TILE >= (STASH ? (count + WG_SAMPLES - 1) / WG_SAMPLES * WG_SAMPLES : count)) return;
+    bool active[NT]; int n[NT], idx[NT]; float x[NT], y[NT], z[NT], zw[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        idx[t] = (blockIdx.x * NT + t) * TILE + (lane & 31);
+        active[t] = idx[t] < count;
+        n[t] = active[t] ? ra.list[idx[t]] : 0;
+        const float4 q0 = active[t] ? ra.xw[n[t]] : zero4();
+        x[t] = q0.x; y[t] = q0.y; z[t] = q0.z; zw[t] = q0.w;
+    }
+    float* lb = reinterpret_cast<float*>(part + NT * 4 * 2 * 32);
+    for (int k = threadIdx.x; k < 6 * 128; k += WG_THREADS) lb[k] = (k & 127) < (k < 640 ? 128 : 6) ? ra.f.vb[k >> 7][k & 127] : 0.f;
+    float* w5f = lb + 6 * 128;
+    for (int k = threadIdx.x; k < 4 * 2 * 16 * 8; k += WG_THREADS) {
+        const int o = k & 7, r = (k >> 3) & 15, hh = (k >> 7) & 1, ww = k >> 8;
+        w5f[k] = o < 6 ? ra.f.vW[5][o * 128 + 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
+    }
+    const float4* w5l = reinterpret_cast<const float4*>(w5f);
+    const b8_t* img = reinterpret_cast<const b8_t*>(a.img);
+    const int nsteps = ra.sched ? __float_as_int(ra.sched[2]) : ra.nsteps;
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+        const float dt = RK_DT(ra, s), tcur = RK_TC(ra, s), hdt = 0.5f * dt;
+        float* z1[NT]; float* z2[NT]; float* x1[NT]; float* x2[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const size_t tile = (size_t)blockIdx.x * NT + t;
+            const size_t e1 = (size_t)(2 * s) * ra.cap_tiles + tile, e2 = (size_t)(2 * s + 1) * ra.cap_tiles + tile;
+            z1[t] = STASH ? ra.zst + e1 * (VEL_Z_REGS * REGF) : nullptr; z2[t] = STASH ? ra.zst + e2 * (VEL_Z_REGS * REGF) : nullptr;
+            x1[t] = STASH ? ra.x0st + e1 * (VEL_X0_REGS * REGF) : nullptr; x2[t] = STASH ? ra.x0st + e2 * (VEL_X0_REGS * REGF) : nullptr;
+        }
+        float o6[NT][6], px[NT], py[NT], pz[NT], w1[NT][6];
+        bool g1[NT];
+        float4 q[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur);
+        velnet_x6<NT, STASH>(img, xch, part, w5l, w, lane, h, q, lb, o6, z1, x1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float v1[3];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w1[t][k] = o6[t][k];
+            vel_from_w(w1[t], x[t], y[t], z[t], v1);
+            g1[t] = gated_out(ra.f, x[t], y[t], z[t]);
+            if (g1[t]) { v1[0] = v1[1] = v1[2] = 0.f; }
+            px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
+            q[t] = make_float4(px[t], py[t], pz[t], tcur - hdt);
+        }
+        velnet_x6<NT, STASH>(img, xch, part, w5l, w, lane, h, q, lb, o6, z2, x2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float v2[3];
+            const float* w2 = o6[t];
+            vel_from_w(w2, px[t], py[t], pz[t], v2);
+            const bool g2 = gated_out(ra.f, px[t], py[t], pz[t]);
+            if (g2) { v2[0] = v2[1] = v2[2] = 0.f; }
+            const float nx = x[t] - dt * v2[0], ny = y[t] - dt * v2[1], nz = z[t] - dt * v2[2];
+            const bool rej = ra.f.gate_sur && gated_out(ra.f, nx, ny, nz);   // tensorf_keyframe.py:603-605
+            if (STASH && active[t] && h == 0 && w == (t & 3)) {
+                float* rc = ra.rec + (size_t)s * RK_NF * ra.cap + idx[t];
+                rc[0 * ra.cap] = x[t]; rc[1 * ra.cap] = y[t]; rc[2 * ra.cap] = z[t];
+                rc[3 * ra.cap] = px[t]; rc[4 * ra.cap] = py[t]; rc[5 * ra.cap] = pz[t];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { rc[(6 + k) * ra.cap] = w1[t][k]; rc[(12 + k) * ra.cap] = w2[k]; }
+                rc[18 * ra.cap] = __int_as_float((g1[t] ? 1 : 0) | (g2 ? 2 : 0) | (rej ? 4 : 0));
+            }
+            if (active[t] && !rej) { x[t] = nx; y[t] = ny; z[t] = nz; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (active[t] && h == 0 && w == 0) ra.xw[n[t]] = make_float4(x[t], y[t], z[t], zw[t]);
+}
+
+// TWO WORKGROUPS PER CU, AND NO PACKED-FP32 VALU CODE (round 5).  As first built - compiled like every other file - these kernels
+// gave run-to-run differences on the same input in 0.1-0.7 % of the tiles when two workgroups shared a CU: per-layer dumps put the first
+// difference in the positional encoder of a step's SECOND evaluation, one slot (the x component, one frequency) of ONE of the four waves
+// wrong in lanes 48..63, as if its argument had been a small constant.  Never with one workgroup per CU (8 x 524 288 points bit-identical),
+// never in the fp32 kernels (which run two per CU with the same encoder).  Delta debugging on the kernel itself (only run-to-run equality
+// is tested, so parts can be cut out freely): gone without the MFMAs, gone with a trig-free encoder, still there without the LDS exchange,
+// without the output stage, without the range reduction or the v_cndmask selects - and gone as soon as the encoder's arguments are made
+// opaque one by one, which keeps the SLP vectoriser from pairing two evaluations into v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (SGPR
+// pair, op_sel).  So nvfi_amd/build.py compiles this file with -fno-slp-vectorize: no v_pk_* instruction is left in these kernels, the
+// repeats are bit-identical at two workgroups per CU (tests/test_gpu_x6.py: 8 x 524 288 points; the render-warp determinism tests), and
+// the speed is the same (the epilogues hide behind the other workgroup's MFMAs).  The mechanism is NOT understood: none of the pieces
+// reproduces in isolation (tools/probes/mfma_hazard_probe.hip, nine experiments incl. packed fp32 beside this MFMA pattern at 1, 2 and 4
+// waves per SIMD: all clean).  NVFI_X6_ONE_WG=1 asks for more than half of the CU's LDS and so keeps a second workgroup off the CU - the
+// other configuration known to be clean (about 7 % of the step slower).
+#define X6_ONE_WG_LDS (84 * 1024)
+template <typename K>
+static int x6_set_lds(K kernel) {
+    HIPCK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6_ONE_WG_LDS));
+    return 0;
+}
+static int x6_tiles_per_wg() {
+    static int nt = -1;
+    if (nt < 0) { const char* e = getenv("NVFI_X6_NT"); nt = e ? atoi(e) : 1; }      // 1 (default) | 2 | 3: the pipelined two-tile kernel (prefilter only)
+    return nt;
+}
+static size_t x6_lds_nt1() {
+    static int one = -1;
+    if (one < 0) { const char* e = getenv("NVFI_X6_ONE_WG"); one = e ? atoi(e) : 0; }
+    return one ? (size_t)X6_ONE_WG_LDS : (size_t)X6_LDS_BYTES(1);
+}
+
+int launch_rk2_x6_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipStream_t st) {
+    const int64_t tiles = (cap_samples + TILE - 1) / TILE;
+    if (tiles <= 0) return 0;
+    static bool attr = false;
+    if (!attr) {
+        if (x6_set_lds(k_rk2_x6_uni<1, true>) || x6_set_lds(k_rk2_x6_uni<1, false>) || x6_set_lds(k_rk2_x6_uni<2, true>) || x6_set_lds(k_rk2_x6_uni<2, false>)) return 1;
+        attr = true;
+    }
+    ProfScope ps(PK_RK2_FWD, st);
+    const unsigned two = (unsigned)((tiles + 1) / 2);
+    if (x6_tiles_per_wg() == 1) {
+        if (stash) hipLaunchKernelGGL((k_rk2_x6_uni<1, true>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
+        else hipLaunchKernelGGL((k_rk2_x6_uni<1, false>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
+    } else {
+        if (stash) hipLaunchKernelGGL((k_rk2_x6_uni<2, true>), dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);
+        else hipLaunchKernelGGL((k_rk2_x6_uni<2, false>), dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);
+    }
+    LAUNCHCK();
+    return 0;
+}
+
 int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st) {
     const int64_t tiles = (cap_points + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
-    static int nt = -1;
-    if (nt < 0) {
-        const char* e = getenv("NVFI_X6_NT"); nt = e ? atoi(e) : 1;      // (1: 0.97 ms, 2: 1.10 ms for the bench prefilter; 3: the pipelined two-tile kernel)
-        HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES(1)));
-        HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6<2>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES(2)));
-        HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES(2)));
+    static bool attr = false;
+    if (!attr) {
+        if (x6_set_lds(k_rk2_x6<1>) || x6_set_lds(k_rk2_x6<2>) || x6_set_lds(k_rk2_x6<2, true>)) return 1;
+        attr = true;
     }
-    if (nt == 3) hipLaunchKernelGGL((k_rk2_x6<2, true>), dim3((unsigned)((tiles + 1) / 2)), dim3(WG_THREADS), X6_LDS_BYTES(2), st, a);
-    else if (nt == 1) hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), X6_LDS_BYTES(1), st, a);
-    else hipLaunchKernelGGL(k_rk2_x6<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(WG_THREADS), X6_LDS_BYTES(2), st, a);
+    const int nt = x6_tiles_per_wg();
+    const unsigned two = (unsigned)((tiles + 1) / 2);
+    if (nt == 3) hipLaunchKernelGGL((k_rk2_x6<2, true>), dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);
+    else if (nt == 1) hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
+    else hipLaunchKernelGGL(k_rk2_x6<2>, dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);
     LAUNCHCK();
     return 0;
 }

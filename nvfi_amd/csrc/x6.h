@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "engine16.h"
+#include "vel.h"
 
 // the 16-bit term type: bfloat16 (8-bit significand, the exponent range of fp32 - no scaling between the terms, no subnormal terms)
 typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
@@ -56,3 +57,6 @@ struct X6Args {
     const float* pt_t; const float* pt_base; int pt_by_list; float dt_max; int max_steps;
 };
 int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st);
+// the render warp (uniform step schedule, optional training stash) on the x6 evaluation: same arguments as the fp32 kernel + the image
+struct X6UniArgs { Rk2Args r; const void* img; };
+int launch_rk2_x6_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipStream_t st);

@@ -23,14 +23,18 @@ class NVFi(nn.Module):
         """train_nvfi.py:141-142 calls nvfi.train(); renderer.train() every iteration; walking ~180 sub-modules twice per step is 0.7 ms
         of pure host time, so an unchanged mode returns at once.  "Unchanged" is checked on this module, on the field and on the field's
         direct children (tests and drivers call model.nvfi.eval() / .train() on the inner field, and mask_field / alphaMask are attached
-        later): a handful of attribute reads, not the 180-module walk."""
+        later): a handful of attribute reads, not the 180-module walk; every 64th call does the full walk."""
         mode = bool(mode)
-        if self.training == mode and self.__dict__.get("_mode_walked") == mode:
+        d = self.__dict__
+        # (a grandchild toggled on its own - model.nvfi.vel_net.weight_net.eval() - is below what the fast check sees: every 64th call walks
+        # the whole tree anyway, 0.7 ms / 64 per step; ADVICE r4)
+        d["_mode_calls"] = n = d.get("_mode_calls", 0) + 1
+        if self.training == mode and d.get("_mode_walked") == mode and (n & 63):
             f = self._modules.get("nvfi")
             if f is None or (f.training == mode and all(c.training == mode for c in f._modules.values() if c is not None)):
                 return self
         super().train(mode)
-        self.__dict__["_mode_walked"] = mode
+        d["_mode_walked"] = mode
         return self
 
     def render_ray(self, t, ray_o, ray_d, white_bg=True, ndc_ray=False):

@@ -261,6 +261,10 @@ class _RegFn(torch.autograd.Function):
         key = tuple((p.data_ptr(), p._version) for p in planes)
         c = rt.get("_reg_fwd")
         if c is None or c[0] != key:
+            # a new pass = a new iteration: whatever an aborted backward of the previous one left behind (deposited weights, a live count that
+            # never reached zero because its graph was dropped) must not leak into this one's single gradient pass
+            rt.pop("_reg_pending", None)
+            rt["_reg_live"] = 0
             out = torch.empty(3, device=planes[0].device)
             desc = field._desc()
             _lib.check(L.nvfi_plane_regs(C.byref(desc), C.c_float(0.0), C.c_float(0.0), C.c_float(0.0), _lib.ptr(out), None, _stream_ptr()))

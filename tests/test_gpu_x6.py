@@ -3,8 +3,8 @@ bfloat16 terms per operand on the 16-bit matrix pipe (six MFMAs per K step, thre
 
 * accuracy: integrate_pos (tensorf_keyframe.py:575-611) through x6 and through the fp32 MFMA kernels against a float64 restatement on the
   199^3 bench field and on fields A / B: the x6 error is not larger than the fp32 kernels' (both sit on the rounding floor of the fp32
-  RK2 recurrence), no outliers, bit-reproducible from run to run (the operand-lifetime rule of vel_x6.hip: without it 0.1-1 % of the
-  tiles came back with their points 16..31 off by 1e-5);
+  RK2 recurrence), no outliers, bit-reproducible from run to run - 8 x 524 288 points, the size at which the build WITH packed-fp32 VALU
+  code showed 2000-3000 differing points per run at two workgroups per CU (vel_x6.hip, bottom; nvfi_amd/build.py FILE_FLAGS);
 * the PDE occupancy prefilter on x6 (NVFI_PDE_PREFILTER=x6): kept set, loss and gradients against the fp32 prefilter on 10^6 points of
   three fields and the bench field, ragged counts, the reference's PDE goldens, and every keep / drop decision on 10^7 points."""
 import os
@@ -55,6 +55,44 @@ def test_x6_integrate_pos_is_as_accurate_as_the_fp32_kernels(nsteps):
               f"x6 {err['x6'][0]:.2e} / {err['x6'][1]:.2e}")
         assert err["x6"][0] <= 1.25 * err["fp32"][0] + 1e-9 and err["x6"][1] <= 1.05 * err["fp32"][1] + 1e-10, (name, err)
         assert err["x6"][2] <= err["fp32"][2], (name, "outliers", err)      # (a point that takes another gate branch than float64 does is an outlier of BOTH kernels)
+
+
+def test_x6_repeats_bit_for_bit_at_two_workgroups_per_cu():
+    """the glitch hunt of round 5 (vel_x6.hip, bottom): eight runs of 524 288 points through the default launch (two workgroups per CU) must
+    be identical; so must the render warp of an eval render (uniform schedule) and of a training render with a fixed jitter"""
+    import bench
+    m = bench.build_scene(torch.device("cuda"), 199, 128, True)
+    f = m.nvfi
+    f.eval()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    N = 1 << 19
+    ts = f.tmax / (f.num_keyframes - 1)
+    x = torch.rand(N, 3, device="cuda", generator=g) * 1.6 - 0.8
+    tt = torch.full((N, 1), float(np.float32(ts * 0.5 * 4 * 0.999)), device="cuda")
+    base = torch.zeros(N, 1, device="cuda")
+    f.vel_fp16 = 3
+    try:
+        with torch.no_grad():
+            outs = [f.integrate_pos(x.clone(), tt.clone(), base).clone() for _ in range(8)]
+    finally:
+        f.vel_fp16 = False
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), int((o != outs[0]).any(-1).sum())
+    # the render warp (k_rk2_x6_uni): 4096 rays, ~3 x 10^5 warped samples, six renders
+    model, meta = make_model("A")
+    fa = model.nvfi
+    fa.eval()
+    gg = torch.Generator().manual_seed(1)
+    o = torch.tensor([[2.6, -2.2, 2.4]]).expand(4096, 3).contiguous()
+    d = (torch.rand(4096, 3, generator=gg) - 0.5) * 3.0 - o
+    d = (d / d.norm(dim=-1, keepdim=True)).contiguous().cuda()
+    o = o.cuda()
+    with torch.no_grad():
+        r = [[t.clone() for t in fa(0.41, o, d, True)[:4]] for _ in range(6)]
+    assert int(fa.last_counters[3]) > 100000
+    for k in range(1, 6):
+        for a, b in zip(r[0], r[k]):
+            assert torch.equal(a, b)
 
 
 def _run(tmp_path, mode, extra=(), n=262144, **switches):
