@@ -1121,6 +1121,15 @@ def main():
             if k in flops and ms > 0:
                 e["tflops"] = flops[k] / (ms * 1e-3) / 1e12
                 e["frac"] = e["tflops"] / PEAK_FP32_MFMA
+            x6_warp = (k == "rk2_fwd" and os.environ.get("NVFI_RK2_X6", "1") != "0" and os.environ.get("NVFI_RK2_SPLIT", "1") != "0"
+                       and os.environ.get("NVFI_VEL_FP16_TRAIN", "0") != "1")
+            if ((k == "pde_prefilter" and pre_mode == "x6") or x6_warp) and "tflops" in e:
+                # the x6 kernels run on the 16-bit matrix pipe, six MFMAs per fp32 product: their speed of light in ALGORITHMIC fp32 FLOPs is the dense
+                # bfloat16 peak / 6 (416.7 TFLOP/s) - NOT the fp32 MFMA peak, which they may (and do) exceed
+                e["peak"] = PEAK_BF16_MFMA / 6.0
+                e["frac_of_fp32_mfma_peak"] = e["frac"]
+                e["frac"] = e["tflops"] / e["peak"]
+                e["matrix_pipe"] = "bf16 (x6: fp32 products from three bfloat16 terms per operand, six v_mfma_f32_32x32x16_bf16 per K step, fp32 accumulation)"
             if k == "pde_prefilter" and pre_mode == "x6" and "tflops" in e:
                 # vel_x6.hip: every fp32 product of the four 128 x 128 hidden layers and of the input layer is formed from six bfloat16 term products
                 # on the 16-bit matrix pipe (2.5 PFLOP/s dense): `tflops` / `frac` stay the ALGORITHMIC fp32 FLOPs against the fp32 MFMA peak (the figure
@@ -1134,10 +1143,13 @@ def main():
         if dom:
             ms, n = times[dom]
             ach = flops[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=PEAK_FP32_MFMA, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA,
+            dpeak = per_class[dom].get("peak", PEAK_FP32_MFMA)
+            roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=dpeak, unit="TFLOP/s", frac=ach / dpeak,
+                        peak_note=("dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 product (x6 kernel, vel_x6.hip); achieved = algorithmic fp32 FLOPs"
+                                   if dpeak != PEAK_FP32_MFMA else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                         traffic=traffic_all.get(dom), traffic_source=f"static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/{PROFILE_TAG}_traffic.json (PMC counters cannot be read in-process)",
                         launches=int(n), avg_launch_ms=ms / max(n, 1), flop_per_launch=flops[dom] / max(n, 1),
-                        **({k2: per_class[dom][k2] for k2 in ("matrix_pipe", "executed_tflops_bf16", "executed_frac_of_bf16_peak") if k2 in per_class[dom]}),
+                        **({k2: per_class[dom][k2] for k2 in ("matrix_pipe", "executed_tflops_bf16", "executed_frac_of_bf16_peak", "frac_of_fp32_mfma_peak") if k2 in per_class[dom]}),
                         whole_step=dict(tflops=sum(flops.values()) / psteps / (dt / args.steps) / 1e12,
                                         frac=sum(flops.values()) / psteps / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA),
                         per_class=per_class)

@@ -43,13 +43,37 @@ int launch_pack_x6(const float* const* W, void* img, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- three-term split of 8 activations -> the B operands of one K step
+// By TRUNCATION (NVFI_X6_ROUND_SPLIT undefined): t1 = the upper 16 bits of x, r = x - t1 (<= 16 significant bits, exact), t2 = the upper 16
+// bits of r, t3 = r - t2 (<= 8 significant bits: its upper 16 bits ARE the value) - x = t1 + t2 + t3 exactly, like the rounded split the
+// weights get at pack time (x6.h split3), for 3 v_perm_b32 + 4 v_and_b32 + 4 v_sub_f32 per PAIR of values instead of 6 conversions, 4 shifts
+// / masks and 4 subtractions: the epilogue is VALU time the matrix pipe waits for.  The terms are up to twice as large as rounded ones
+// (|t2| < 2^-7 |x|, |t3| < 2^-15 |x|), so the three dropped term products (w2 x3, w3 x2, w3 x3: < 2^-22 of the product) are too; the error
+// against float64 stays at the fp32 kernels' (tests/test_gpu_x6.py).
 __device__ __forceinline__ void split3_8(const float* v, b8_t& b1, b8_t& b2, b8_t& b3) {
+#ifdef NVFI_X6_ROUND_SPLIT
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         __bf16 t1, t2, t3;
         split3(v[j], t1, t2, t3);
         b1[j] = t1; b2[j] = t2; b3[j] = t3;
     }
+#else
+    unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float xa = v[2 * j], xb = v[2 * j + 1];
+        const unsigned ua = __float_as_uint(xa), ub = __float_as_uint(xb);
+        p1[j] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                       // (upper half of xb) << 16 | upper half of xa
+        const float ra = xa - __uint_as_float(ua & 0xffff0000u), rb = xb - __uint_as_float(ub & 0xffff0000u);
+        const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+        p2[j] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+        const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
+        p3[j] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 q1 = {p1[0], p1[1], p1[2], p1[3]}, q2 = {p2[0], p2[1], p2[2], p2[3]}, q3 = {p3[0], p3[1], p3[2], p3[3]};
+    b1 = __builtin_bit_cast(b8_t, q1); b2 = __builtin_bit_cast(b8_t, q2); b3 = __builtin_bit_cast(b8_t, q3);
+#endif
 }
 
 // the six term products of one K step for one tile: a0 += A1 B1 ; a1 += A1 B2 + A2 B1 ; a2 += A2 B2 + A1 B3 + A3 B1

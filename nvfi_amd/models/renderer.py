@@ -1,4 +1,6 @@
 """Renderer: ray chunk loop + reshape to rays.restore_shape (reference models/renderer.py:7-65)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,13 +19,41 @@ class Renderer(nn.Module):
         ray_d = rays.ray_directions.reshape(-1, 3)
         n_all = ray_o.shape[0]
         outs = [[], [], [], [], []]
-        for c in range(n_all // self.ray_chunk + int(n_all % self.ray_chunk > 0)):
-            r_o = ray_o[c * self.ray_chunk:(c + 1) * self.ray_chunk]
-            r_d = ray_d[c * self.ray_chunk:(c + 1) * self.ray_chunk]
-            fn = self.tensorf.render_ray_transfer if transfer_vel else self.tensorf.render_ray
-            res = fn(t, r_o, r_d, white_background, self.ndc)
+        chunk = self.ray_chunk
+        if ray_o.is_cuda and not torch.is_grad_enabled() and not self.tensorf.training:
+            # test-mode rays carry no jitter and are independent (tests/test_gpu_edges.py: every prefix of a render equals the render), so the
+            # reference's ray_chunk - a memory bound for its (R, S, .) torch intermediates - need not be the launch granularity here: a frame
+            # goes through in pieces of NVFI_EVAL_CHUNK rays (default 32768: 16 MB of weights at 128 samples per ray), 16x fewer launches
+            chunk = max(chunk, int(os.environ.get("NVFI_EVAL_CHUNK", "32768")))
+        n_chunks = n_all // chunk + int(n_all % chunk > 0)
+        fn = self.tensorf.render_ray_transfer if transfer_vel else self.tensorf.render_ray
+        # a test-mode frame is some hundred independent chunks: issued alternately on two side streams, one chunk's velocity warp (matrix pipe)
+        # runs beside the other's plane gathers (HBM) - every chunk call owns its workspace and outputs, nothing is shared but the weights.
+        # NVFI_EVAL_STREAMS=1: the reference's plain loop on the current stream
+        side = None
+        if n_chunks >= 4 and ray_o.is_cuda and not torch.is_grad_enabled() and os.environ.get("NVFI_EVAL_STREAMS", "2") != "1":
+            side = self.__dict__.get("_eval_streams")
+            if side is None or side[0].device != ray_o.device:
+                side = self.__dict__["_eval_streams"] = [torch.cuda.Stream(device=ray_o.device) for _ in range(2)]
+            main = torch.cuda.current_stream(ray_o.device)
+            for s_ in side:
+                s_.wait_stream(main)
+        for c in range(n_chunks):
+            r_o = ray_o[c * chunk:(c + 1) * chunk]
+            r_d = ray_d[c * chunk:(c + 1) * chunk]
+            if side is None:
+                res = fn(t, r_o, r_d, white_background, self.ndc)
+            else:
+                with torch.cuda.stream(side[c & 1]):
+                    res = fn(t, r_o, r_d, white_background, self.ndc)
+                for v in res:
+                    if torch.is_tensor(v):
+                        v.record_stream(main)          # allocated on the side stream, consumed (torch.cat below, the caller) on the current one
             for lst, v in zip(outs, res):
                 lst.append(v)
+        if side is not None:
+            for s_ in side:
+                main.wait_stream(s_)
         # (one chunk - every training batch - needs no concatenation: five copy launches less per render)
         rgb_map, depth_map, acc_map, weights, extra = [o[0] if len(o) == 1 else torch.cat(o, 0) for o in outs]
         shp = tuple(rays.restore_shape)
