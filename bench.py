@@ -516,8 +516,107 @@ class GraphedStep:
         s.opt.step(zero_grad=True, hyper_dev=rec[self.HEAD:self.HEAD + self.n_hyper])
         self.loss = loss
 
+    # ---- several ranks: three graphs around the eager exchange (round 5, verdict item 6) ------------------------------------------------
+    # G_H: draw + fragment repack | G_P: the PDE term into the staging buffer (replayed on the PDE stream) | G_R: both renders + regularisers
+    # (replayed on the main stream, render 1 on its own branch).  Between the replays the host issues what cannot be captured with every
+    # backend - the head all-reduce under the PDE chain, the kept-count exchange + commit of the staged PDE gradients, the tail all-reduce -
+    # and the one-launch Adam.  Per iteration the host makes 3 graph launches + the exchange instead of ~55 kernel launches.
+    def body_head(self):
+        s, rec = self.s, self.rec
+        if getattr(s, "draw_desc", None) is None:
+            s._draw_setup()
+        s.draw(it_dev=rec[8:10].view(torch.int64))
+        s.m.nvfi.repack_frags()
+
+    def body_pde(self):
+        s, rec = self.s, self.rec
+        m = s.m
+        s.pde_stage.zero()
+        m.vel_grad_targets = s.pde_stage.views
+        m.vel_loss_weight = rec[5:6]
+        s.last_lv = m.get_vel_loss(s.n_pts, points=s.d_pts, t=s.d_t)
+        self.pde_out = m.nvfi.last_pde_out
+
+    def body_renders(self):
+        s, rec, DT = self.s, self.rec, self.DeviceTime
+        f = s.m.nvfi
+        R = s.n_rays
+        jit = [rec[self.off_jit + k * R: self.off_jit + (k + 1) * R] for k in range(self.renders)]
+        main = torch.cuda.current_stream()
+        s_r1 = s.streams[1] if s.streams is not None else main
+        if s_r1 is not main:
+            start = torch.cuda.Event(); start.record(main)
+            with torch.cuda.stream(s_r1):
+                s_r1.wait_event(start)
+                f.render_mse_backward_(DT(19.0 / 60.0, rec[0:1]), s.d_ro[0], s.d_rd[0], s.d_tg[0], white_bg=True, jitter=jit[0])
+                self.flags.append(f.last_counters)
+        else:
+            f.render_mse_backward_(DT(19.0 / 60.0, rec[0:1]), s.d_ro[0], s.d_rd[0], s.d_tg[0], white_bg=True, jitter=jit[0])
+            self.flags.append(f.last_counters)
+        loss, _ = f.render_mse_backward_(DT(0.05, rec[1:2]), s.d_ro[-1], s.d_rd[-1], s.d_tg[-1], white_bg=True, jitter=jit[-1])
+        self.flags.append(f.last_counters)
+        if s_r1 is not main:
+            main.wait_stream(s_r1)
+        s.last_regs = f.regularizers_backward_(rec[2:5])
+        self.loss = loss
+
+    def _multi_iteration(self, run_h, run_p, run_r):
+        """one iteration of several ranks: run_* either replay the graphs or call the bodies (the eager pass before the capture)"""
+        s, rec = self.s, self.rec
+        main = torch.cuda.current_stream()
+        s_pde = s.streams[0] if s.streams is not None else None
+        run_h()
+        if s_pde is not None:
+            ev = torch.cuda.Event(); ev.record(main)
+            with torch.cuda.stream(s_pde):
+                s_pde.wait_event(ev)
+                run_p()
+            run_r()
+        else:
+            run_r()
+        h = s.bucket.all_reduce_head_start(s.tail_off)      # 38 MB of plane / render-MLP gradients: underneath the PDE chain
+        if s_pde is not None:
+            main.wait_stream(s_pde)
+        else:
+            run_p()
+        s.pde_stage.commit_device(self.pde_out)
+        s.bucket.all_reduce_finish(h, s.tail_off)
+        s.opt.step(zero_grad=True, hyper_dev=rec[self.HEAD:self.HEAD + self.n_hyper])
+        s.stepped = True
+
+    def _capture_multi(self):
+        s = self.s
+        if s.workload != "cfg3" or s.tail_off is None or s.comm is not None or not s.fused_zero:
+            raise SystemExit("--graph on with several ranks: the bat loop with the split torch.distributed exchange and the one-launch Adam only")
+        if not s.stepped:
+            s.bucket.zero()
+        self.host_record()
+        torch.cuda.synchronize()
+        self._multi_iteration(self.body_head, self.body_pde, self.body_renders)      # eager once: allocator pools, plans
+        torch.cuda.synchronize()
+        self.flags.clear()
+        self.host_record()
+        torch.cuda.synchronize()
+        self.gH, self.gP, self.gR = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        for g, body in ((self.gH, self.body_head), (self.gP, self.body_pde), (self.gR, self.body_renders)):
+            cap = torch.cuda.Stream(device=s.dev)
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(g, stream=cap):      # (each graph its own memory pool: G_P and G_R replay side by side)
+                body()
+            torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        self.graph = self.gR
+        self.graphs = [self.gR]
+        self.multi = True
+        self.turn = 0
+        # the captured iteration itself (its record was uploaded above; the captures executed nothing)
+        self._multi_iteration(self.gH.replay, self.gP.replay, self.gR.replay)
+        torch.cuda.synchronize()
+
     def _capture_once(self):
         s = self.s
+        if s.world > 1:
+            return self._capture_multi()
         self.host_record()
         torch.cuda.synchronize()
         cap = torch.cuda.Stream(device=s.dev)
@@ -544,7 +643,7 @@ class GraphedStep:
         in round 3 (every attempt replays at 5.35-5.5 ms); the cause was the depth of the host's run-ahead, see __call__.  Setup, before the W
         warm-up steps; the timed region replays one fixed graph."""
         s = self.s
-        tries = max(1, int(os.environ.get("NVFI_GRAPH_TRIES", "1")))
+        tries = 1 if s.world > 1 else max(1, int(os.environ.get("NVFI_GRAPH_TRIES", "1")))
         best = None
         self.capture_ms = []
         for k in range(tries):
@@ -587,7 +686,10 @@ class GraphedStep:
             q = self.__dict__.setdefault("_inflight", [])
             if len(q) >= depth:
                 q.pop(0).synchronize()
-        if gs:
+        if getattr(self, "multi", False):
+            self.host_record()
+            self._multi_iteration(self.gH.replay, self.gP.replay, self.gR.replay)
+        elif gs:
             gs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(gs):
                 self.host_record()
@@ -1041,9 +1143,7 @@ def main():
     use_graph = args.mode == "fused" and args.graph == "on"
     run = step
     if use_graph:
-        if world > 1:
-            raise SystemExit("--graph on: the captured step is single-GPU (the multi-rank step keeps its eager three-stream order around the RCCL exchange)")
-        run = GraphedStep(step)
+        run = GraphedStep(step)      # several ranks: three graphs around the eager exchange (GraphedStep._multi_iteration)
         run.capture()
     for _ in range(args.warmup):         # the contract's W untimed warm-up steps
         run()
@@ -1185,7 +1285,10 @@ def main():
                    "rays_per_step_per_gpu": n_rays * renders, "pde_points_per_gpu": n_pts if args.workload == "cfg3" else 0,
                    "grid": [int(g) for g in model.nvfi.gridSize.tolist()], "samples_per_ray": int(model.nvfi.nSamples), "parallelism": f"ray-sharded x{world}",
                    "driver": args.mode,
-                   "launch": ("one hipGraph replay per iteration (three captured streams; frame times, loss weights, learning rates and jitter read from a device record uploaded per iteration)"
+                   "launch": (("three hipGraph replays per iteration (draw + fragment repack | PDE term on its stream | both renders + regularisers) around the eager gradient "
+                               "exchange and the one-launch Adam; frame times, loss weights, learning rates and jitter read from a device record uploaded per iteration")
+                              if (use_graph and world > 1) else
+                              "one hipGraph replay per iteration (three captured streams; frame times, loss weights, learning rates and jitter read from a device record uploaded per iteration)"
                               if use_graph else "eager launches"),
                    "field": "live (updated by the optimiser)" if args.live else "stationary (optimiser steps a shadow copy)"},
         "work_per_step": work,
