@@ -213,7 +213,10 @@ def test_pde_loss(gold, models, kind):
     ours_ids, ref_ids = np.nonzero(kept)[0][:64], np.nonzero(ref_kept)[0][:64]
     common, io, ir = np.intersect1d(ours_ids, ref_ids, return_indices=True)
     assert len(common) >= 56, len(common)
+    # rows 0-2 = d v / d (x, y, z, t): all the loss reads (nvfi.py:77-79).  Rows 3-5 of the golden are the Jacobian of the ACCELERATION head, which the
+    # reference's jacrev forms and never uses; neither the oracle nor the kernels form them
     np.testing.assert_allclose(f.last_pde_jac.cpu().numpy()[io, :3], gold[f"{kind}:pde:jac64"][ir, :3], rtol=2e-4, atol=5e-5)
+    assert float(f.last_pde_jac[:, 3:].abs().max()) == 0.0
     np.testing.assert_allclose(float(loss.detach()), gold[f"{kind}:pde:loss"][0], rtol=5e-4)
     (loss * 1.0).backward()
     g = named_grads(model)
