@@ -157,3 +157,18 @@ def test_gpu_maskfield_fp16_mfma_mode(mgold, tag, K):
             assert e < 1e-3, (n, sfx, e)
     mf.mfma_fp16 = False
     assert np.abs(mf(pts).detach().cpu().numpy() - ref).max() < 1e-5          # and back to the exact path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fp16", [False, True])
+def test_gpu_maskfield_repeats_bit_for_bit(mgold, fp16):
+    """round 5: the x6 kernels showed run-to-run differences at two workgroups per CU beside 16-bit MFMAs; the MaskField kernels
+    are the other ones that run two per CU (the fp16-input variant on the 16-bit pipe): 2 x 10^6 points, six forwards, identical bits"""
+    mf = _model(mgold, "K8", 8)
+    mf.mfma_fp16 = fp16
+    g = torch.Generator(device="cuda").manual_seed(2)
+    pts = torch.rand(1 << 21, 3, device="cuda", generator=g) * 2.0 - 1.0
+    with torch.no_grad():
+        outs = [mf(pts).clone() for _ in range(6)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), int((o != outs[0]).any(-1).sum())
