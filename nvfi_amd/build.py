@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["engine.hip", "wgrad_ring.hip", "vel.hip", "render.hip", "scatter.hip", "mask.hip", "pde.hip", "pde_jet.hip", "pre16.hip", "vel_split.hip", "vel_fuse.hip", "pde_fuse.hip", "regs.hip", "optim.hip", "abi.hip", "comm.hip", "frags.hip", "vel_x6.hip"]
+SOURCES = ["engine.hip", "wgrad_ring.hip", "vel.hip", "render.hip", "scatter.hip", "mask.hip", "pde.hip", "pde_jet.hip", "pre16.hip", "vel_split.hip", "vel_fuse.hip", "pde_fuse.hip", "regs.hip", "optim.hip", "abi.hip", "comm.hip", "frags.hip", "vel_x6.hip", "vel_x6w.hip"]
 # every header under csrc/ (engine16.h, ... - a header that is not listed here would leave stale objects behind) + the public ABI
 HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith(".h")) + [os.path.join("..", "..", "include", "nvfi_hip.h")]
 SO = os.environ.get("NVFI_BUILD_SO", os.path.join(CSRC, "libnvfi_hip.so"))   # experiments build a second library elsewhere
@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-file flags.  vel_x6.hip: no SLP vectorisation, i.e. no packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in the
 # kernels that run two workgroups per CU beside 16-bit MFMAs - with them one encoder input of one wave came out wrong in lanes 48..63
 # once per few hundred tiles (delta debugging in DESIGN.md 4.8; tests/test_gpu_x6.py repeats 4 M points bit for bit)
-FILE_FLAGS = {"vel_x6.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"vel_x6.hip": ["-fno-slp-vectorize"], "vel_x6w.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(a, b):

@@ -332,35 +332,51 @@ __device__ __forceinline__ void x6p_slot(const X6P& c, int te, int le, int lm, b
     for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(BfE[s][0]), "v"(BfE[s][1]), "v"(BfE[s][2]), "v"(v[0]), "v"(v[15]));
     __builtin_amdgcn_sched_barrier(0);
     unsigned pk[3][8];          // the split values: term, pair
+    float rr[16];               // first residuals
     b8_t* dst = c.xch + (size_t)te * X6_XCH_H8 + (2 * w) * 64 + lane;
+    // 36 pieces for the 36 MFMA slots in front of the barrier: 16 x SiLU of one value (5 instructions, two of them transcendental) | 16 x half
+    // of a pair's truncation split (5-6 instructions) | 4 slots for the six 16-byte LDS writes
     auto piece = [&](auto Ic) {
         constexpr int I = decltype(Ic)::value;
-        if constexpr (I < 16) v[I] = act_f<1>(v[I]);                                    // SiLU of one value
-        else if constexpr (I < 24) split3_pair(v[2 * (I - 16)], v[2 * (I - 16) + 1], pk[0][I - 16], pk[1][I - 16], pk[2][I - 16]);
-        else if constexpr (I < 30) {                                                    // one of the six 16-byte LDS writes
-            constexpr int term = (I - 24) % 3, k = (I - 24) / 3;
-            const u4_t q = {pk[term][4 * k], pk[term][4 * k + 1], pk[term][4 * k + 2], pk[term][4 * k + 3]};
-            dst[k * 64 + term * 8 * 64] = __builtin_bit_cast(b8_t, q);
+        if constexpr (I < 16) v[I] = act_f<1>(v[I]);
+        else if constexpr (I < 32) {
+            constexpr int pr = (I - 16) >> 1;
+            const float xa = v[2 * pr], xb = v[2 * pr + 1];
+            if constexpr (((I - 16) & 1) == 0) {
+                const unsigned ua = __float_as_uint(xa), ub = __float_as_uint(xb);
+                pk[0][pr] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+                rr[2 * pr] = xa - __uint_as_float(ua & 0xffff0000u); rr[2 * pr + 1] = xb - __uint_as_float(ub & 0xffff0000u);
+            } else {
+                const float ra = rr[2 * pr], rb = rr[2 * pr + 1];
+                const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+                pk[1][pr] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+                const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
+                pk[2][pr] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+            }
+        } else {
+            auto wr = [&](int j) {
+                const int term = j % 3, k = j / 3;
+                const u4_t q = {pk[term][4 * k], pk[term][4 * k + 1], pk[term][4 * k + 2], pk[term][4 * k + 3]};
+                dst[k * 64 + term * 8 * 64] = __builtin_bit_cast(b8_t, q);
+            };
+            if constexpr (I == 32) { wr(0); wr(1); }
+            else if constexpr (I == 33) { wr(2); wr(3); }
+            else if constexpr (I == 34) wr(4);
+            else wr(5);
         }
     };
     if (HAVE_M) {
+        // one MFMA of the other tile, then one piece of this tile's epilogue; the sched_barrier behind every pair pins the interleaving
+        // (sched_group_barrier requests were ignored: the scheduler put the whole epilogue in front of the MFMAs)
         x6p_for(std::make_integer_sequence<int, 36>{}, [&](auto Ic) {
             constexpr int I = decltype(Ic)::value;
             x6p_one<I>(A1, A2, A3, BfM, m0, m1, m2);
             if (I % 6 == 5 && I / 6 + 3 < 8) { constexpr int s = I / 6; A1[(s + 3) & 3] = P1[(s + 3) * 64]; A2[(s + 3) & 3] = P2[(s + 3) * 64]; A3[(s + 3) & 3] = P3[(s + 3) * 64]; }
             piece(Ic);
+            __builtin_amdgcn_sched_barrier(0);
         });
-        // the order asked of the scheduler: one MFMA, then the piece of the epilogue that fits behind it
-#pragma unroll
-        for (int i = 0; i < 36; ++i) {
-            SGB(0x008, 1);
-            if (i < 16) { SGB(0x002, 3); SGB(0x400, 2); }
-            else if (i < 24) SGB(0x002, 11);
-            else if (i < 30) { SGB(0x002, 2); SGB(0x200, 1); }
-            if (i % 6 == 5 && i / 6 + 3 < 8) SGB(0x020, 3);
-        }
     } else {
-        x6p_for(std::make_integer_sequence<int, 30>{}, piece);
+        x6p_for(std::make_integer_sequence<int, 36>{}, piece);
     }
     __syncthreads();                                     // tile te's layer input is complete in LDS (its previous readers finished a slot ago)
     const b8_t* src = c.xch + (size_t)te * X6_XCH_H8 + lane;
@@ -372,9 +388,8 @@ __device__ __forceinline__ void x6p_slot(const X6P& c, int te, int le, int lm, b
             constexpr int o0 = 2 * I, o1 = 2 * I + 1;
             BfE[o0 / 3][o0 % 3] = src[(o0 / 3) * 64 + (o0 % 3) * 8 * 64];
             BfE[o1 / 3][o1 % 3] = src[(o1 / 3) * 64 + (o1 % 3) * 8 * 64];
+            __builtin_amdgcn_sched_barrier(0);
         });
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { SGB(0x008, 1); SGB(0x100, 2); }
     } else {
 #pragma unroll
         for (int s = 0; s < 8; ++s) { BfE[s][0] = src[s * 64]; BfE[s][1] = src[s * 64 + 8 * 64]; BfE[s][2] = src[s * 64 + 16 * 64]; }
@@ -693,6 +708,7 @@ int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st) {
         attr = true;
     }
     const int nt = x6_tiles_per_wg();
+    if (nt == 4) return launch_rk2_x6w(a, cap_points, st);
     const unsigned two = (unsigned)((tiles + 1) / 2);
     if (nt == 3) hipLaunchKernelGGL((k_rk2_x6<2, true>), dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);
     else if (nt == 1) hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);

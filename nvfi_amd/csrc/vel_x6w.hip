@@ -1,0 +1,313 @@
+// x6, one wave per 32-point tile (round 5, late): the velocity net of vel_x6.hip with the WHOLE 128-wide layer in one wave.
+//
+// Why.  k_rk2_x6 (vel_x6.hip) splits a layer's 128 output rows over the four waves of a workgroup.  Counters say where its time goes
+// (profiles/r05_pmc_sq.csv): per wave and evaluation ~250 MFMAs (8 k cycles) stand against ~1 500 VALU instructions - every wave repeats the
+// encoder, the RK2 glue and its own epilogue - and on this part a VALU instruction of one wave never overlaps a matrix instruction of ANOTHER
+// wave (dual_pipe_probe3): the two add up, the matrix pipe is 40 % busy, and a second workgroup per CU only hides latencies.  Inside ONE wave
+// about four VALU instructions per 16-bit MFMA are free.  So: one wave owns a tile and all four 32-row tiles of every layer; while the 48
+// MFMAs of row tile m run, the wave's VALU slots carry the epilogue of row tile m - 1 (drain -> SiLU -> truncation split -> the two K steps of
+// the NEXT layer's B operand, which in this layout are the lane's own registers: no LDS exchange, no barrier); the epilogue of a layer's last
+// row tile rides under K steps 0..5 of the next layer's first tile and is complete before K step 6 needs it.  The A operands (weights) are one
+// linear stream of 136 entries (layer 0: 8, layers 1..4: 32 each) through a four-slot register ring, three entries ahead.
+// Same products, same order of accumulation as k_rk2_x6: results are bit-identical (tests/test_gpu_x6.py).
+#include <stdlib.h>
+#include <utility>
+#include "common.h"
+#include "vel.h"
+#include "pde.h"
+#include "engine16.h"
+#include "x6.h"
+
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+typedef const b8_t __attribute__((address_space(1))) * x6w_gptr;      // (behind the opaque step a generic pointer would load through FLAT)
+#define X6W_ENTRIES 136
+#define X6W_RING 8                            // weight-stream ring: entry en + 7 is requested behind entry en's MFMAs (7 K steps = 1 300 cycles ahead:
+                                             // one wave per SIMD has nobody to hide an L2 round trip behind; 3 ahead stalled every K step)
+#define X6W_OB_H8 (8 * 3 * 64)               // per wave: the layer output on its way to the next layer's input registers, [K step][term][lane]
+#define X6W_LDS_BYTES ((6 * 128 + 4 * 2 * 16 * 8) * 4 + 4 * X6W_OB_H8 * 16)
+
+struct X6W {
+    x6w_gptr W1, W2, W3;           // per lane, RUNNING: the base of the current group of four stream entries (entry x of the lane at [(x & 3) * 64],
+                                   // a 13-bit immediate offset); advanced by 4 KB once per four entries and made opaque, so that the compiler
+                                   // neither re-derives 136 x 3 64-bit addresses from the kernel argument nor keeps them (the first build spilled 265)
+    const float* lb;               // LDS: raw biases [6][128]
+    const float4* w5l;             // LDS: output-layer weights [m][h][r][8]
+    b8_t* ob;                      // LDS, this wave's: + lane
+    int lane, h;
+};
+
+template <int... Is, class F> __device__ __forceinline__ void x6w_for(std::integer_sequence<int, Is...>, F f) { (f(std::integral_constant<int, Is>{}), ...); }
+
+// Register budget (one wave per SIMD, 512 registers): the layer input `in` (8 K steps x 3 terms = 96) lives in registers for the four row tiles
+// that read it; the layer OUTPUT goes through 24 KB of LDS per wave (six 16-byte writes per row tile) and is pulled into `in` K step by K
+// step as the last row tile of the layer releases them - one array, one LDS buffer, no ping-pong (two register arrays spilled 574 registers).
+struct X6WEpi {                    // transient state of one pending epilogue
+    float rr[16];
+    unsigned pk[3][8];
+};
+// piece I (0..35) of the epilogue of a row tile: v = its 16 pre-activations; K steps m2, m2 + 1 of the layer output
+// LAST (last hidden layer): the activations themselves go to LDS (rows m2 * 2 .. of the same buffer, as floats) for the output layer
+// SiLU in three stages over consecutive pieces, so that no instruction waits for the transcendental in front of it:
+//   piece I: t_I = exp2(-log2(e) z_I) | u_{I-1} = rcp(1 + t_{I-1}) | v_{I-2} = z_{I-2} u_{I-2}      (pieces 0..17; the same arithmetic as act_f<1>)
+template <int I, bool LAST>
+__device__ __forceinline__ void x6w_piece(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
+    if constexpr (I < 18) {
+        if constexpr (I < 16) e.rr[I] = __builtin_amdgcn_exp2f(-1.44269504088896341f * v[I]);
+        if constexpr (I >= 1 && I < 17) e.rr[I - 1] = __builtin_amdgcn_rcpf(1.f + e.rr[I - 1]);
+        if constexpr (I >= 2) v[I - 2] = v[I - 2] * e.rr[I - 2];
+    } else if constexpr (LAST) {
+        if constexpr (I < 22) {
+            constexpr int k = I - 18;
+            float4* z = reinterpret_cast<float4*>(c.ob) + (size_t)(m2 * 2 + k) * 64;      // (c.ob already carries + lane)
+            *z = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        }
+    } else if constexpr (I < 34) {
+        constexpr int pr = (I - 18) >> 1;
+        if constexpr (((I - 18) & 1) == 0) {
+            const float xa = v[2 * pr], xb = v[2 * pr + 1];
+            const unsigned ua = __float_as_uint(xa), ub = __float_as_uint(xb);
+            e.pk[0][pr] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+            e.rr[2 * pr] = xa - __uint_as_float(ua & 0xffff0000u); e.rr[2 * pr + 1] = xb - __uint_as_float(ub & 0xffff0000u);
+        } else {
+            const float ra = e.rr[2 * pr], rb = e.rr[2 * pr + 1];
+            const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+            e.pk[1][pr] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+            const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
+            e.pk[2][pr] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+        }
+    } else if constexpr (I < 36) {
+        // the six 16-byte writes of K steps m2, m2 + 1: three per piece
+        constexpr int k = I - 34;
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+            const u32x4w q = {e.pk[term][4 * k], e.pk[term][4 * k + 1], e.pk[term][4 * k + 2], e.pk[term][4 * k + 3]};
+            c.ob[((size_t)(m2 + k) * 3 + term) * 64] = __builtin_bit_cast(b8_t, q);
+        }
+    }
+}
+__device__ __forceinline__ void x6w_load_in(const X6W& c, b8_t (&in)[8][3], int s) {
+    in[s][0] = c.ob[((size_t)s * 3 + 0) * 64]; in[s][1] = c.ob[((size_t)s * 3 + 1) * 64]; in[s][2] = c.ob[((size_t)s * 3 + 2) * 64];
+}
+
+// MFMA j (0..5) of K step s: x6_step's order; the first K step of a row tile starts a1 / a2 from the constant 0 (a0 holds the bias)
+template <int J, bool FIRST>
+__device__ __forceinline__ void x6w_mfma(const b8_t& A1, const b8_t& A2, const b8_t& A3, const b8_t (&B)[3], f32x16& a0, f32x16& a1, f32x16& a2) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (J == 0) a0 = MFMA16B(A1, B[0], a0);
+    else if constexpr (J == 1) a1 = MFMA16B(A1, B[1], FIRST ? zero : a1);
+    else if constexpr (J == 2) a2 = MFMA16B(A2, B[1], FIRST ? zero : a2);
+    else if constexpr (J == 3) a1 = MFMA16B(A2, B[0], a1);
+    else if constexpr (J == 4) a2 = MFMA16B(A1, B[2], a2);
+    else a2 = MFMA16B(A3, B[0], a2);
+}
+
+// KIND of a row tile: 0 layer-0 tile (2 K steps on X0; 3 pieces per MFMA slot) | 1 first tile of a hidden layer (the pending epilogue is the
+// previous layer's last tile: 36 pieces in slots 0..29, its K steps 6, 7 pulled into `in` at slot 30, read at slot 36) | 2 middle tile |
+// 3 last tile of a hidden layer that has a successor (releases in[s] K step by K step and pulls the next layer's input in behind) | 4 last tile
+// of the last hidden layer
+template <int E0, int KIND, int LROW, bool HAVE_PE, bool PE_LAST>
+__device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2)[X6W_RING], b8_t (&A3)[X6W_RING], const b8_t (&X0)[2][3], b8_t (&in)[8][3],
+                                         float (&pv)[16], X6WEpi& e, int pm2, float (&nv)[16], f32x16& bias) {
+    constexpr int NS = KIND == 0 ? 2 : 8;
+    f32x16 a0 = bias, a1, a2;                  // the bias rows of this tile were read from LDS a tile ago
+    x6w_for(std::make_integer_sequence<int, NS * 6>{}, [&](auto Ic) {
+        constexpr int I = decltype(Ic)::value, s = I / 6, j = I % 6, en = E0 + s;
+        if constexpr (KIND == 0) x6w_mfma<j, s == 0>(A1[en % X6W_RING], A2[en % X6W_RING], A3[en % X6W_RING], X0[s], a0, a1, a2);
+        else x6w_mfma<j, s == 0>(A1[en % X6W_RING], A2[en % X6W_RING], A3[en % X6W_RING], in[s], a0, a1, a2);
+        if constexpr (j == 5 && en + X6W_RING - 1 < X6W_ENTRIES) {
+            constexpr int x = en + X6W_RING - 1;
+            if constexpr ((x & 3) == 0) {
+                c.W1 += 256; c.W2 += 256; c.W3 += 256;
+                asm volatile("" : "+v"(c.W1), "+v"(c.W2), "+v"(c.W3));
+            }
+            A1[x % X6W_RING] = c.W1[(x & 3) * 64]; A2[x % X6W_RING] = c.W2[(x & 3) * 64]; A3[x % X6W_RING] = c.W3[(x & 3) * 64];
+        }
+        if constexpr (HAVE_PE) {
+            if constexpr (KIND == 0) {
+                x6w_piece<3 * I, PE_LAST>(c, pv, e, pm2); x6w_piece<3 * I + 1, PE_LAST>(c, pv, e, pm2); x6w_piece<3 * I + 2, PE_LAST>(c, pv, e, pm2);
+            } else if constexpr (KIND == 1) {
+                if constexpr (I < 6) { x6w_piece<2 * I, PE_LAST>(c, pv, e, pm2); x6w_piece<2 * I + 1, PE_LAST>(c, pv, e, pm2); }
+                else if constexpr (I < 30) x6w_piece<I + 6, PE_LAST>(c, pv, e, pm2);
+            } else if constexpr (I < 36) x6w_piece<I, PE_LAST>(c, pv, e, pm2);
+        }
+        if constexpr (KIND == 1 && I == 30) { x6w_load_in(c, in, 6); x6w_load_in(c, in, 7); }
+        if constexpr (I == 1 && LROW + 32 < 640) {     // the next row tile's bias (behind the first MFMA, which has just consumed this one's)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bias[r] = c.lb[LROW + 32 + (r & 3) + 8 * (r >> 2) + 4 * c.h];
+        }
+        if constexpr (KIND == 3) {
+            if constexpr (j == 5 && s < 4) x6w_load_in(c, in, s);
+            if constexpr (I == 36) { x6w_load_in(c, in, 4); x6w_load_in(c, in, 5); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nv[r] = (a2[r] + a1[r]) + a0[r];
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// one evaluation of the net for the wave's 32 points
+__device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float (&out6)[6]) {
+    X6W c = c0;                    // (the stream pointers run through one evaluation)
+    asm volatile("" : "+v"(c.W1), "+v"(c.W2), "+v"(c.W3));
+    b8_t X0[2][3], in[8][3];
+    b8_t A1[X6W_RING], A2[X6W_RING], A3[X6W_RING];
+    X6WEpi e;
+    float va[16], vb[16];
+    {
+        float x0[16];
+        vel_encode_slots(q, c.h, x0);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xa = x0[8 * k + 2 * j], xb = x0[8 * k + 2 * j + 1];
+                const unsigned ua = __float_as_uint(xa), ub = __float_as_uint(xb);
+                p1[j] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+                const float ra = xa - __uint_as_float(ua & 0xffff0000u), rb = xb - __uint_as_float(ub & 0xffff0000u);
+                const unsigned wa = __float_as_uint(ra), wb = __float_as_uint(rb);
+                p2[j] = __builtin_amdgcn_perm(wb, wa, 0x07060302u);
+                const float sa = ra - __uint_as_float(wa & 0xffff0000u), sb = rb - __uint_as_float(wb & 0xffff0000u);
+                p3[j] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+            }
+            const u32x4w q1 = {p1[0], p1[1], p1[2], p1[3]}, q2 = {p2[0], p2[1], p2[2], p2[3]}, q3 = {p3[0], p3[1], p3[2], p3[3]};
+            X0[k][0] = __builtin_bit_cast(b8_t, q1); X0[k][1] = __builtin_bit_cast(b8_t, q2); X0[k][2] = __builtin_bit_cast(b8_t, q3);
+        }
+    }
+#pragma unroll
+    for (int en = 0; en < X6W_RING - 1; ++en) {
+        if (en == 4) { c.W1 += 256; c.W2 += 256; c.W3 += 256; }
+        A1[en] = c.W1[(en & 3) * 64]; A2[en] = c.W2[(en & 3) * 64]; A3[en] = c.W3[(en & 3) * 64];
+    }
+    f32x16 bias;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = c.lb[(r & 3) + 8 * (r >> 2) + 4 * c.h];
+    // layer 0 (28 -> 128): four row tiles of two K steps
+    x6w_tile<0, 0, 0, false, false>(c, A1, A2, A3, X0, in, va, e, 0, va, bias);
+    x6w_tile<2, 0, 32, true, false>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
+    x6w_tile<4, 0, 64, true, false>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
+    x6w_tile<6, 0, 96, true, false>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) x6w_load_in(c, in, s);
+    // layers 1..3: first | middle | middle | last-with-successor
+    x6w_tile<8, 1, 128, true, false>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
+    x6w_tile<16, 2, 160, true, false>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
+    x6w_tile<24, 2, 192, true, false>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
+    x6w_tile<32, 3, 224, true, false>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+    x6w_tile<40, 1, 256, true, false>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
+    x6w_tile<48, 2, 288, true, false>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
+    x6w_tile<56, 2, 320, true, false>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
+    x6w_tile<64, 3, 352, true, false>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+    x6w_tile<72, 1, 384, true, false>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
+    x6w_tile<80, 2, 416, true, false>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
+    x6w_tile<88, 2, 448, true, false>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
+    x6w_tile<96, 3, 480, true, false>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+    // layer 4: its activations go to LDS as floats (rows [m][4][lane] float4 of the same buffer, free once in[6..7] are in registers)
+    x6w_tile<104, 1, 512, true, false>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
+    x6w_tile<112, 2, 544, true, true>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
+    x6w_tile<120, 2, 576, true, true>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
+    x6w_tile<128, 4, 608, true, true>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+    // ---- 128 -> 6: fp32 FMAs in velnet_x6's order (per row tile: a chain over its 16 activations, the two lane halves added, then the tiles in order)
+#pragma unroll
+    for (int o = 0; o < 6; ++o) out6[o] = c.lb[128 * 5 + o];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float zl[16];
+        if (m < 3) {
+            const float4* z = reinterpret_cast<const float4*>(c.ob) + (size_t)(m * 4) * 64;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float4 t = z[k * 64]; zl[4 * k] = t.x; zl[4 * k + 1] = t.y; zl[4 * k + 2] = t.z; zl[4 * k + 3] = t.w; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zl[r] = act_f<1>(vb[r]);
+        }
+        float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float4* wl = c.w5l + (m * 2 + c.h) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float4 wa = wl[2 * r], wb = wl[2 * r + 1];
+            const float av = zl[r];
+            p[0] = __builtin_fmaf(av, wa.x, p[0]); p[1] = __builtin_fmaf(av, wa.y, p[1]); p[2] = __builtin_fmaf(av, wa.z, p[2]);
+            p[3] = __builtin_fmaf(av, wa.w, p[3]); p[4] = __builtin_fmaf(av, wb.x, p[4]); p[5] = __builtin_fmaf(av, wb.y, p[5]);
+        }
+#pragma unroll
+        for (int o = 0; o < 6; ++o) { p[o] += __shfl_xor(p[o], 32); out6[o] += p[o]; }
+    }
+}
+
+// the recurrence of k_rk2_x6 (vel_x6.hip), one wave per tile
+__global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lb = lds;
+    float* w5f = lb + 6 * 128;
+    b8_t* obase = reinterpret_cast<b8_t*>(w5f + 4 * 2 * 16 * 8);
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int count = a.count ? *a.count : (int)a.n_direct;
+    if ((int)blockIdx.x * 4 * TILE >= count) return;
+    for (int k = threadIdx.x; k < 6 * 128; k += WG_THREADS) lb[k] = (k & 127) < (k < 640 ? 128 : 6) ? a.f.vb[k >> 7][k & 127] : 0.f;
+    for (int k = threadIdx.x; k < 4 * 2 * 16 * 8; k += WG_THREADS) {
+        const int o = k & 7, r = (k >> 3) & 15, hh = (k >> 7) & 1, ww = k >> 8;
+        w5f[k] = o < 6 ? a.f.vW[5][o * 128 + 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
+    }
+    __syncthreads();
+    const int tile = blockIdx.x * 4 + wv;
+    if (tile * TILE >= count) return;                      // (no barrier behind this point: the waves are independent)
+    const int i = tile * TILE + (lane & 31);
+    const bool active = i < count;
+    const int n = active ? (a.list ? a.list[i] : i) : 0;
+    const float4 q0 = active ? a.xw[n] : zero4();
+    float x = q0.x, y = q0.y, z = q0.z;
+    const float zw = q0.w;
+    const int ti = a.pt_by_list ? n : i;
+    float tcur = active ? a.pt_t[ti] : 0.f;
+    float off = active ? tcur - a.pt_base[ti] : 0.f;
+    X6W c;
+    const b8_t* img = reinterpret_cast<const b8_t*>(a.img);
+    c.W1 = (x6w_gptr)(img + lane); c.W2 = (x6w_gptr)(img + X6_H8 + lane); c.W3 = (x6w_gptr)(img + 2 * X6_H8 + lane);
+    c.lb = lb; c.w5l = reinterpret_cast<const float4*>(w5f); c.ob = obase + (size_t)wv * X6W_OB_H8 + lane; c.lane = lane; c.h = h;
+#pragma unroll 1
+    for (int s = 0; s < a.max_steps; ++s) {
+        const bool live = active && fabsf(off) > 0.f;
+        const float mm = fminf(fabsf(off), a.dt_max);
+        const float dt = off > 0.f ? mm : (off < 0.f ? -mm : 0.f);
+        if (!__any(live)) break;
+        const float hdt = 0.5f * dt;
+        float px = x, py = y, pz = z;
+        float o6[6];
+        // two evaluations through ONE copy of the network code (it is ~30 KB of instructions)
+#pragma unroll 1
+        for (int ev = 0; ev < 2; ++ev) {
+            const float4 q = make_float4(px, py, pz, ev ? tcur - hdt : tcur);
+            velnet_x6w(c, q, o6);
+            if (ev == 0) {
+                float v1[3];
+                vel_from_w(o6, x, y, z, v1);
+                if (gated_out(a.f, x, y, z)) { v1[0] = v1[1] = v1[2] = 0.f; }
+                px = x - hdt * v1[0]; py = y - hdt * v1[1]; pz = z - hdt * v1[2];
+            }
+        }
+        float v2[3];
+        vel_from_w(o6, px, py, pz, v2);
+        if (gated_out(a.f, px, py, pz)) { v2[0] = v2[1] = v2[2] = 0.f; }
+        const float nx = x - dt * v2[0], ny = y - dt * v2[1], nz = z - dt * v2[2];
+        const bool rej = a.f.gate_sur && gated_out(a.f, nx, ny, nz);   // tensorf_keyframe.py:603-605
+        if (live && !rej) { x = nx; y = ny; z = nz; }
+        if (live) { off = off - dt; tcur = tcur - dt; }
+    }
+    if (active && h == 0) {
+        if (a.xout3) { float* o = a.xout3 + 3 * (size_t)n; o[0] = x; o[1] = y; o[2] = z; }
+        else a.xw[n] = make_float4(x, y, z, zw);
+    }
+}
+
+int launch_rk2_x6w(const X6Args& a, int64_t cap_points, hipStream_t st) {
+    const int64_t tiles = (cap_points + TILE - 1) / TILE;
+    if (tiles <= 0) return 0;
+    static bool attr = false;
+    if (!attr) { HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6w, hipFuncAttributeMaxDynamicSharedMemorySize, X6W_LDS_BYTES)); attr = true; }
+    hipLaunchKernelGGL(k_rk2_x6w, dim3((unsigned)((tiles + 3) / 4)), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
+    LAUNCHCK();
+    return 0;
+}

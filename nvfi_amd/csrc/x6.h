@@ -57,6 +57,7 @@ struct X6Args {
     const float* pt_t; const float* pt_base; int pt_by_list; float dt_max; int max_steps;
 };
 int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st);
+int launch_rk2_x6w(const X6Args& a, int64_t cap_points, hipStream_t st);      // vel_x6w.hip: one wave per tile, the epilogue in the MFMAs' VALU slots
 // the render warp (uniform step schedule, optional training stash) on the x6 evaluation: same arguments as the fp32 kernel + the image
 struct X6UniArgs { Rk2Args r; const void* img; };
 int launch_rk2_x6_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipStream_t st);
