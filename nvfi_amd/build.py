@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-file flags.  vel_x6.hip: no SLP vectorisation, i.e. no packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in the
 # kernels that run two workgroups per CU beside 16-bit MFMAs - with them one encoder input of one wave came out wrong in lanes 48..63
 # once per few hundred tiles (delta debugging in DESIGN.md 4.8; tests/test_gpu_x6.py repeats 4 M points bit for bit)
-FILE_FLAGS = {"vel_x6.hip": ["-fno-slp-vectorize"], "vel_x6w.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"vel_x6.hip": ["-fno-slp-vectorize"], "vel_x6w.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}      # (accumulators in VGPRs: the drain reads them without 48 v_accvgpr_read per tile)
 
 
 def _newer(a, b):

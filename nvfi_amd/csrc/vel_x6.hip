@@ -76,15 +76,17 @@ __device__ __forceinline__ void split3_8(const float* v, b8_t& b1, b8_t& b2, b8_
 #endif
 }
 
-// the six term products of one K step for one tile: a0 += A1 B1 ; a1 += A1 B2 + A2 B1 ; a2 += A2 B2 + A1 B3 + A3 B1
+// the six term products of one K step for one tile: a0 += A1 B1 (the leading terms: the sum the fp32 MFMA forms, in the same order) ;
+// a1 += A1 B2 + A2 B2 + A2 B1 + A1 B3 + A3 B1 (everything <= 2^-8 of it: rounding among these is 2^-32 of the result).  Two accumulators since
+// round 5 late (three before: a separate one for the 2^-16 class bought nothing measurable and cost 16 registers and 16 adds per drain)
 __device__ __forceinline__ void x6_step(const b8_t& A1, const b8_t& A2, const b8_t& A3, const b8_t& B1, const b8_t& B2, const b8_t& B3,
-                                        f32x16& a0, f32x16& a1, f32x16& a2) {
+                                        f32x16& a0, f32x16& a1) {
     a0 = MFMA16B(A1, B1, a0);
     a1 = MFMA16B(A1, B2, a1);
-    a2 = MFMA16B(A2, B2, a2);
+    a1 = MFMA16B(A2, B2, a1);
     a1 = MFMA16B(A2, B1, a1);
-    a2 = MFMA16B(A1, B3, a2);
-    a2 = MFMA16B(A3, B1, a2);
+    a1 = MFMA16B(A1, B3, a1);
+    a1 = MFMA16B(A3, B1, a1);
 }
 
 // LDS exchange image of one tile: [term][K step 0..7][lane] h8
@@ -105,7 +107,7 @@ template <int NT, bool STASH = false>
 __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xch, float4* part, const float4* w5l, int w, int lane, int h,
                                           const float4* q, const float* lb, float (&out6)[NT][6], float* const* zst = nullptr, float* const* x0st = nullptr) {
     const b8_t* W1 = img; const b8_t* W2 = img + X6_H8; const b8_t* W3 = img + 2 * X6_H8;
-    f32x16 a0[NT], a1[NT], a2[NT];
+    f32x16 a0[NT], a1[NT];
     b8_t Bf[NT][8][3];
     // ---- layer 0: every wave encodes the point itself (28 inputs in 16 slots per lane half = 2 K steps)
     // v: the fp32 pre-activations of the layer just finished; every layer ends with the drain (the read of its accumulators) and the pins
@@ -128,18 +130,18 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
 #pragma unroll
             for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(Bf[t][s][0]), "+v"(Bf[t][s][1]), "+v"(Bf[t][s][2]));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { a0[t][r] = lb[32 * w + (r & 3) + 8 * (r >> 2) + 4 * h]; a1[t][r] = 0.f; a2[t][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { a0[t][r] = lb[32 * w + (r & 3) + 8 * (r >> 2) + 4 * h]; a1[t][r] = 0.f; }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) x6_step(A1[s], A2[s], A3[s], Bf[t][s][0], Bf[t][s][1], Bf[t][s][2], a0[t], a1[t], a2[t]);
+            for (int t = 0; t < NT; ++t) x6_step(A1[s], A2[s], A3[s], Bf[t][s][0], Bf[t][s][1], Bf[t][s][2], a0[t], a1[t]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[t][r] = (a2[t][r] + a1[t][r]) + a0[t][r];
+            for (int r = 0; r < 16; ++r) v[t][r] = a1[t][r] + a0[t][r];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -187,12 +189,12 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
                 Bf[t][s][0] = src[0]; Bf[t][s][1] = src[8 * 64]; Bf[t][s][2] = src[16 * 64];
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { a0[t][r] = lb[128 * (l + 1) + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h]; a1[t][r] = 0.f; a2[t][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { a0[t][r] = lb[128 * (l + 1) + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h]; a1[t][r] = 0.f; }
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) x6_step(A1[s & 3], A2[s & 3], A3[s & 3], Bf[t][s][0], Bf[t][s][1], Bf[t][s][2], a0[t], a1[t], a2[t]);
+            for (int t = 0; t < NT; ++t) x6_step(A1[s & 3], A2[s & 3], A3[s & 3], Bf[t][s][0], Bf[t][s][1], Bf[t][s][2], a0[t], a1[t]);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 3 < 8) { A1[(s + 3) & 3] = P1[(s + 3) * 64]; A2[(s + 3) & 3] = P2[(s + 3) * 64]; A3[(s + 3) & 3] = P3[(s + 3) * 64]; }
             __builtin_amdgcn_sched_barrier(0);
@@ -202,7 +204,7 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[t][r] = (a2[t][r] + a1[t][r]) + a0[t][r];
+            for (int r = 0; r < 16; ++r) v[t][r] = a1[t][r] + a0[t][r];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -260,230 +262,8 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
     }
 }
 
-// ---------------------------------------------------------------- the same evaluation, software-pipelined over two tiles in ONE wave per SIMD
-// The 16-bit MFMA leaves 4-5 issue slots per instruction to the issuing wave's own VALU / LDS work and nothing to the other waves of the SIMD
-// (dual_pipe_probe3), so the epilogue of a layer - sum of the three accumulators, SiLU, three-term split, exchange through LDS: ~350 VALU
-// instructions per tile - only disappears behind matrix work that the SAME wave issues.  Here a workgroup (four waves, one per SIMD, the whole
-// 512-register file each) owns two tiles X and Y and alternates: while the 48 MFMAs of one tile's layer are issued, the other tile's epilogue
-// runs between them -   E(X,0) | L0(Y)    E(Y,l) | M(X,l)    E(X,l+1) | M(Y,l)   ...   VOUT(X) | M(Y,3)    VOUT(Y).
-// A tile's exchange buffer is written in one slot and read in the same slot behind ONE barrier; its previous readers finished a slot earlier.
-// Operand lifetime rule as above: Bf[T] is refilled inside E(T), behind the read of T's accumulators.
-__device__ __forceinline__ void x6_step0(const b8_t& A1, const b8_t& A2, const b8_t& A3, const b8_t& B1, const b8_t& B2, const b8_t& B3,
-                                         f32x16& a0, f32x16& a1, f32x16& a2) {
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // (the SrcC inline constant 0: no register clears)
-    a0 = MFMA16B(A1, B1, zero);
-    a1 = MFMA16B(A1, B2, zero);
-    a2 = MFMA16B(A2, B2, zero);
-    a1 = MFMA16B(A2, B1, a1);
-    a2 = MFMA16B(A1, B3, a2);
-    a2 = MFMA16B(A3, B1, a2);
-}
-#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
-
-struct X6P {
-    const b8_t *W1, *W2, *W3; b8_t* xch; const float* lb; int w, lane, h;
-};
-typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-// three-term split of a PAIR of values: one packed conversion per term (v_cvt_pk_bf16_f32), the residuals exact
-__device__ __forceinline__ void split3_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
-    const b2_t t1 = {(__bf16)x, (__bf16)y};
-    const float rx = x - (float)t1[0], ry = y - (float)t1[1];
-    const b2_t t2 = {(__bf16)rx, (__bf16)ry};
-    const b2_t t3 = {(__bf16)(rx - (float)t2[0]), (__bf16)(ry - (float)t2[1])};
-    p1 = __builtin_bit_cast(unsigned, t1); p2 = __builtin_bit_cast(unsigned, t2); p3 = __builtin_bit_cast(unsigned, t3);
-}
-// MFMA number I (0..47) of a tile's layer: K step I / 6, product I % 6 in x6_step's order; the first of every accumulator starts from SrcC = 0
-template <int I>
-__device__ __forceinline__ void x6p_one(const b8_t (&A1)[4], const b8_t (&A2)[4], const b8_t (&A3)[4], const b8_t (&Bf)[8][3], f32x16& a0, f32x16& a1, f32x16& a2) {
-    constexpr int s = I / 6, j = I % 6, k = s & 3;
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (j == 0) a0 = MFMA16B(A1[k], Bf[s][0], s == 0 ? zero : a0);
-    else if (j == 1) a1 = MFMA16B(A1[k], Bf[s][1], s == 0 ? zero : a1);
-    else if (j == 2) a2 = MFMA16B(A2[k], Bf[s][1], s == 0 ? zero : a2);
-    else if (j == 3) a1 = MFMA16B(A2[k], Bf[s][0], a1);
-    else if (j == 4) a2 = MFMA16B(A1[k], Bf[s][2], a2);
-    else a2 = MFMA16B(A3[k], Bf[s][0], a2);
-}
-template <int... Is, class F> __device__ __forceinline__ void x6p_for(std::integer_sequence<int, Is...>, F f) { (f(std::integral_constant<int, Is>{}), ...); }
-
-// one slot: the epilogue of tile `te` (its layer `le` output -> its layer le + 1 input) between the MFMAs of the other tile (layer lm + 1),
-// interleaved BY HAND - one MFMA, then a piece of the epilogue that fits the issue slots the MFMA leaves (the scheduler, asked through
-// sched_group_barrier, put the whole epilogue in front of the MFMAs); a sched_barrier after every piece pins the order
-// HAVE_M = false: nothing to interleave (the first slot runs beside layer 0 of Y, issued by the caller)
-template <bool HAVE_M>
-__device__ __forceinline__ void x6p_slot(const X6P& c, int te, int le, int lm, b8_t (&BfE)[8][3], f32x16& e0, f32x16& e1, f32x16& e2,
-                                         const b8_t (&BfM)[8][3], f32x16& m0, f32x16& m1, f32x16& m2) {
-    const int w = c.w, lane = c.lane, h = c.h;
-    const b8_t* P1 = c.W1 + X6_LH(lm + 1) + (w * 8) * 64 + lane;
-    const b8_t* P2 = c.W2 + X6_LH(lm + 1) + (w * 8) * 64 + lane;
-    const b8_t* P3 = c.W3 + X6_LH(lm + 1) + (w * 8) * 64 + lane;
-    b8_t A1[4], A2[4], A3[4];
-    if (HAVE_M) {
-#pragma unroll
-        for (int s = 0; s < 3; ++s) { A1[s] = P1[s * 64]; A2[s] = P2[s * 64]; A3[s] = P3[s * 64]; }
-    }
-    // the read of tile te's accumulators: behind it its MFMAs have completed and BfE may be refilled
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = ((e2[r] + e1[r]) + e0[r]) + c.lb[128 * le + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(BfE[s][0]), "v"(BfE[s][1]), "v"(BfE[s][2]), "v"(v[0]), "v"(v[15]));
-    __builtin_amdgcn_sched_barrier(0);
-    unsigned pk[3][8];          // the split values: term, pair
-    float rr[16];               // first residuals
-    b8_t* dst = c.xch + (size_t)te * X6_XCH_H8 + (2 * w) * 64 + lane;
-    // 36 pieces for the 36 MFMA slots in front of the barrier: 16 x SiLU of one value (5 instructions, two of them transcendental) | 16 x half
-    // of a pair's truncation split (5-6 instructions) | 4 slots for the six 16-byte LDS writes
-    auto piece = [&](auto Ic) {
-        constexpr int I = decltype(Ic)::value;
-        if constexpr (I < 16) v[I] = act_f<1>(v[I]);
-        else if constexpr (I < 32) {
-            constexpr int pr = (I - 16) >> 1;
-            const float xa = v[2 * pr], xb = v[2 * pr + 1];
-            if constexpr (((I - 16) & 1) == 0) {
-                const unsigned ua = __float_as_uint(xa), ub = __float_as_uint(xb);
-                pk[0][pr] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-                rr[2 * pr] = xa - __uint_as_float(ua & 0xffff0000u); rr[2 * pr + 1] = xb - __uint_as_float(ub & 0xffff0000u);
-            } else {
-                const float ra = rr[2 * pr], rb = rr[2 * pr + 1];
-                const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
-                pk[1][pr] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
-                const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
-                pk[2][pr] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-            }
-        } else {
-            auto wr = [&](int j) {
-                const int term = j % 3, k = j / 3;
-                const u4_t q = {pk[term][4 * k], pk[term][4 * k + 1], pk[term][4 * k + 2], pk[term][4 * k + 3]};
-                dst[k * 64 + term * 8 * 64] = __builtin_bit_cast(b8_t, q);
-            };
-            if constexpr (I == 32) { wr(0); wr(1); }
-            else if constexpr (I == 33) { wr(2); wr(3); }
-            else if constexpr (I == 34) wr(4);
-            else wr(5);
-        }
-    };
-    if (HAVE_M) {
-        // one MFMA of the other tile, then one piece of this tile's epilogue; the sched_barrier behind every pair pins the interleaving
-        // (sched_group_barrier requests were ignored: the scheduler put the whole epilogue in front of the MFMAs)
-        x6p_for(std::make_integer_sequence<int, 36>{}, [&](auto Ic) {
-            constexpr int I = decltype(Ic)::value;
-            x6p_one<I>(A1, A2, A3, BfM, m0, m1, m2);
-            if (I % 6 == 5 && I / 6 + 3 < 8) { constexpr int s = I / 6; A1[(s + 3) & 3] = P1[(s + 3) * 64]; A2[(s + 3) & 3] = P2[(s + 3) * 64]; A3[(s + 3) & 3] = P3[(s + 3) * 64]; }
-            piece(Ic);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    } else {
-        x6p_for(std::make_integer_sequence<int, 36>{}, piece);
-    }
-    __syncthreads();                                     // tile te's layer input is complete in LDS (its previous readers finished a slot ago)
-    const b8_t* src = c.xch + (size_t)te * X6_XCH_H8 + lane;
-    if (HAVE_M) {
-        x6p_for(std::make_integer_sequence<int, 12>{}, [&](auto Ic) {
-            constexpr int I = decltype(Ic)::value;
-            x6p_one<36 + I>(A1, A2, A3, BfM, m0, m1, m2);
-            // two of the 24 B operands of tile te's next layer per MFMA
-            constexpr int o0 = 2 * I, o1 = 2 * I + 1;
-            BfE[o0 / 3][o0 % 3] = src[(o0 / 3) * 64 + (o0 % 3) * 8 * 64];
-            BfE[o1 / 3][o1 % 3] = src[(o1 / 3) * 64 + (o1 % 3) * 8 * 64];
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    } else {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) { BfE[s][0] = src[s * 64]; BfE[s][1] = src[s * 64 + 8 * 64]; BfE[s][2] = src[s * 64 + 16 * 64]; }
-    }
-}
-
-__device__ __forceinline__ void x6p_vout(const X6P& c, int t, float4* part, const float4* w5l, const b8_t (&Bf)[8][3], const f32x16& a0, const f32x16& a1, const f32x16& a2) {
-    const int w = c.w, lane = c.lane, h = c.h;
-    float zl[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zl[r] = ((a2[r] + a1[r]) + a0[r]) + c.lb[128 * 4 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(Bf[s][0]), "v"(Bf[s][1]), "v"(Bf[s][2]), "v"(zl[0]), "v"(zl[15]));
-    __builtin_amdgcn_sched_barrier(0);
-    float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float4* wl = w5l + (w * 2 + h) * 32;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float4 wa = wl[2 * r], wb = wl[2 * r + 1];
-        const float av = act_f<1>(zl[r]);
-        p[0] = __builtin_fmaf(av, wa.x, p[0]); p[1] = __builtin_fmaf(av, wa.y, p[1]); p[2] = __builtin_fmaf(av, wa.z, p[2]);
-        p[3] = __builtin_fmaf(av, wa.w, p[3]); p[4] = __builtin_fmaf(av, wb.x, p[4]); p[5] = __builtin_fmaf(av, wb.y, p[5]);
-    }
-#pragma unroll
-    for (int o = 0; o < 6; ++o) p[o] += __shfl_xor(p[o], 32);
-    if (h == 0) {
-        part[((t * 4 + w) * 2 + 0) * 32 + lane] = make_float4(p[0], p[1], p[2], p[3]);
-        part[((t * 4 + w) * 2 + 1) * 32 + lane] = make_float4(p[4], p[5], 0.f, 0.f);
-    }
-}
-
-__device__ __forceinline__ void velnet_x6p(const b8_t* __restrict__ img, b8_t* xch, float4* part, const float4* w5l, int w, int lane, int h,
-                                           const float4* q, const float* lb, float (&out6)[2][6]) {
-    X6P c; c.W1 = img; c.W2 = img + X6_H8; c.W3 = img + 2 * X6_H8; c.xch = xch; c.lb = lb; c.w = w; c.lane = lane; c.h = h;
-    f32x16 a0[2], a1[2], a2[2];
-    b8_t Bf[2][8][3];
-    // ---- layer 0 of both tiles (the bias of every layer is added in the epilogue: the accumulators start from the SrcC constant 0)
-    {
-        b8_t A1[2], A2[2], A3[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int o = X6_L0 + (w * 2 + s) * 64 + lane;
-            A1[s] = c.W1[o]; A2[s] = c.W2[o]; A3[s] = c.W3[o];
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float x0[16];
-            vel_encode_slots(q[t], h, x0);
-            split3_8(x0, Bf[t][0][0], Bf[t][0][1], Bf[t][0][2]);
-            split3_8(x0 + 8, Bf[t][1][0], Bf[t][1][1], Bf[t][1][2]);
-            x6_step0(A1[0], A2[0], A3[0], Bf[t][0][0], Bf[t][0][1], Bf[t][0][2], a0[t], a1[t], a2[t]);
-            x6_step(A1[1], A2[1], A3[1], Bf[t][1][0], Bf[t][1][1], Bf[t][1][2], a0[t], a1[t], a2[t]);
-        }
-    }
-    // ---- E(X,0) beside L0(Y) (already issued), then the alternation
-    x6p_slot<false>(c, 0, 0, 0, Bf[0], a0[0], a1[0], a2[0], Bf[1], a0[1], a1[1], a2[1]);
-#pragma unroll 1
-    for (int l = 0; l < 4; ++l) {
-        x6p_slot<true>(c, 1, l, l, Bf[1], a0[1], a1[1], a2[1], Bf[0], a0[0], a1[0], a2[0]);            // E(Y,l) | M(X,l)
-        if (l < 3) x6p_slot<true>(c, 0, l + 1, l, Bf[0], a0[0], a1[0], a2[0], Bf[1], a0[1], a1[1], a2[1]);   // E(X,l+1) | M(Y,l)
-    }
-    // ---- VOUT(X) | M(Y,3), VOUT(Y)
-    {
-        const b8_t* P1 = c.W1 + X6_LH(4) + (w * 8) * 64 + lane;
-        const b8_t* P2 = c.W2 + X6_LH(4) + (w * 8) * 64 + lane;
-        const b8_t* P3 = c.W3 + X6_LH(4) + (w * 8) * 64 + lane;
-        b8_t A1[4], A2[4], A3[4];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) { A1[s] = P1[s * 64]; A2[s] = P2[s * 64]; A3[s] = P3[s * 64]; }
-        // (VOUT(X) needs X's accumulators only: it is issued first, the 48 MFMAs of Y behind it fill the pipe while nothing else is left to do)
-        x6p_vout(c, 0, part, w5l, Bf[0], a0[0], a1[0], a2[0]);
-        x6p_for(std::make_integer_sequence<int, 48>{}, [&](auto Ic) {
-            constexpr int I = decltype(Ic)::value;
-            x6p_one<I>(A1, A2, A3, Bf[1], a0[1], a1[1], a2[1]);
-            if (I % 6 == 5 && I / 6 + 3 < 8) { constexpr int s = I / 6; A1[(s + 3) & 3] = P1[(s + 3) * 64]; A2[(s + 3) & 3] = P2[(s + 3) * 64]; A3[(s + 3) & 3] = P3[(s + 3) * 64]; }
-        });
-        x6p_vout(c, 1, part, w5l, Bf[1], a0[1], a1[1], a2[1]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int o = 0; o < 6; ++o) out6[t][o] = lb[128 * 5 + o];
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-            const float4 A = part[((t * 4 + ww) * 2 + 0) * 32 + (lane & 31)], B = part[((t * 4 + ww) * 2 + 1) * 32 + (lane & 31)];
-            out6[t][0] += A.x; out6[t][1] += A.y; out6[t][2] += A.z; out6[t][3] += A.w; out6[t][4] += B.x; out6[t][5] += B.y;
-        }
-    }
-}
-
 // the recurrence of k_rk2_split<NT, true> (vel_split.hip), per-point times
-template <int NT, bool PIPE = false>
+template <int NT>
 __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6(X6Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     b8_t* xch = reinterpret_cast<b8_t*>(lds);
@@ -530,7 +310,7 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6(X6Args a
         float4 q[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur[t]);
-        if constexpr (PIPE) velnet_x6p(img, xch, part, w5l, w, lane, h, q, lb, o6); else velnet_x6<NT>(img, xch, part, w5l, w, lane, h, q, lb, o6);
+        velnet_x6<NT>(img, xch, part, w5l, w, lane, h, q, lb, o6);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v1[3];
@@ -540,7 +320,7 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6(X6Args a
             px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
             q[t] = make_float4(px[t], py[t], pz[t], tcur[t] - hdt);
         }
-        if constexpr (PIPE) velnet_x6p(img, xch, part, w5l, w, lane, h, q, lb, o6); else velnet_x6<NT>(img, xch, part, w5l, w, lane, h, q, lb, o6);
+        velnet_x6<NT>(img, xch, part, w5l, w, lane, h, q, lb, o6);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v2[3];
@@ -669,7 +449,7 @@ static int x6_set_lds(K kernel) {
 }
 static int x6_tiles_per_wg() {
     static int nt = -1;
-    if (nt < 0) { const char* e = getenv("NVFI_X6_NT"); nt = e ? atoi(e) : 1; }      // 1 (default) | 2 | 3: the pipelined two-tile kernel (prefilter only)
+    if (nt < 0) { const char* e = getenv("NVFI_X6_NT"); nt = e ? atoi(e) : 1; }      // 1 (default) | 2 | 4: one wave per tile (vel_x6w.hip, prefilter / integrate_pos only)
     return nt;
 }
 static size_t x6_lds_nt1() {
@@ -704,14 +484,17 @@ int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st) {
     if (tiles <= 0) return 0;
     static bool attr = false;
     if (!attr) {
-        if (x6_set_lds(k_rk2_x6<1>) || x6_set_lds(k_rk2_x6<2>) || x6_set_lds(k_rk2_x6<2, true>)) return 1;
+        if (x6_set_lds(k_rk2_x6<1>) || x6_set_lds(k_rk2_x6<2>)) return 1;
         attr = true;
     }
     const int nt = x6_tiles_per_wg();
-    if (nt == 4) return launch_rk2_x6w(a, cap_points, st);
+    // default since round 5 (late): one wave per tile, the epilogue in the MFMAs' VALU slots (vel_x6w.hip; bit-identical results, the bench
+    // prefilter 0.89 -> 0.83 ms).  NVFI_X6W=0: the four-waves-per-tile kernel below
+    static int x6w = -1;
+    if (x6w < 0) { const char* e = getenv("NVFI_X6W"); x6w = e ? atoi(e) : 1; }
+    if (x6w || nt == 4) return launch_rk2_x6w(a, cap_points, st);
     const unsigned two = (unsigned)((tiles + 1) / 2);
-    if (nt == 3) hipLaunchKernelGGL((k_rk2_x6<2, true>), dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);
-    else if (nt == 1) hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
+    if (nt == 1) hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
     else hipLaunchKernelGGL(k_rk2_x6<2>, dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);
     LAUNCHCK();
     return 0;

@@ -47,89 +47,111 @@ struct X6WEpi {                    // transient state of one pending epilogue
 };
 // piece I (0..35) of the epilogue of a row tile: v = its 16 pre-activations; K steps m2, m2 + 1 of the layer output
 // LAST (last hidden layer): the activations themselves go to LDS (rows m2 * 2 .. of the same buffer, as floats) for the output layer
-// SiLU in three stages over consecutive pieces, so that no instruction waits for the transcendental in front of it:
-//   piece I: t_I = exp2(-log2(e) z_I) | u_{I-1} = rcp(1 + t_{I-1}) | v_{I-2} = z_{I-2} u_{I-2}      (pieces 0..17; the same arithmetic as act_f<1>)
-template <int I, bool LAST>
-__device__ __forceinline__ void x6w_piece(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
-    if constexpr (I < 18) {
-        if constexpr (I < 16) e.rr[I] = __builtin_amdgcn_exp2f(-1.44269504088896341f * v[I]);
-        if constexpr (I >= 1 && I < 17) e.rr[I - 1] = __builtin_amdgcn_rcpf(1.f + e.rr[I - 1]);
-        if constexpr (I >= 2) v[I - 2] = v[I - 2] * e.rr[I - 2];
-    } else if constexpr (LAST) {
-        if constexpr (I < 22) {
-            constexpr int k = I - 18;
+// The epilogue of a row tile as 38 micro-slots of about one transcendental + four plain VALU instructions each - what one 16-bit MFMA leaves
+// room for in the same wave (dual_pipe_probe3; a slot with two transcendentals or six plain instructions costs ~45 cycles instead of 34):
+//   u = 2 r      E_r: t = exp2(-log2(e) z_r)            u = 2 r + 1   R_r: s = rcp(1 + t)            u = 2 r + 2   M_r: z_r s       (act_f<1>'s arithmetic)
+//   pair p = (2 p, 2 p + 1), complete at u = 4 p + 4:  u = 4 p + 5 .. 4 p + 8: the truncation split in four parts (3, 2, 3, 3 instructions)
+//   u = 22, u = 37: the three 16-byte LDS writes of K step m2 / m2 + 1 of the layer output
+// LAST (last hidden layer): no split - the activations go to LDS as floats (four float4 per tile, at u = 9, 17, 25, 33)
+template <int U, bool LAST>
+__device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
+    if constexpr (U < 32) {
+        constexpr int r = U >> 1;
+        if constexpr ((U & 1) == 0) e.rr[r] = __builtin_amdgcn_exp2f(-1.44269504088896341f * v[r]);
+        else e.rr[r] = __builtin_amdgcn_rcpf(1.f + e.rr[r]);
+    }
+    if constexpr (U >= 2 && U <= 32 && (U & 1) == 0) { constexpr int r = (U - 2) >> 1; v[r] = v[r] * e.rr[r]; }
+    if constexpr (LAST) {
+        if constexpr (U >= 9 && U <= 33 && ((U - 9) & 7) == 0) {
+            constexpr int k = (U - 9) >> 3;
             float4* z = reinterpret_cast<float4*>(c.ob) + (size_t)(m2 * 2 + k) * 64;      // (c.ob already carries + lane)
             *z = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
         }
-    } else if constexpr (I < 34) {
-        constexpr int pr = (I - 18) >> 1;
-        if constexpr (((I - 18) & 1) == 0) {
-            const float xa = v[2 * pr], xb = v[2 * pr + 1];
-            const unsigned ua = __float_as_uint(xa), ub = __float_as_uint(xb);
-            e.pk[0][pr] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-            e.rr[2 * pr] = xa - __uint_as_float(ua & 0xffff0000u); e.rr[2 * pr + 1] = xb - __uint_as_float(ub & 0xffff0000u);
-        } else {
-            const float ra = e.rr[2 * pr], rb = e.rr[2 * pr + 1];
-            const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
-            e.pk[1][pr] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
-            const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
-            e.pk[2][pr] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+    } else {
+        if constexpr (U >= 5 && U <= 36) {
+            constexpr int p = (U - 5) >> 2, part = (U - 5) & 3;
+            if constexpr (part == 0) {
+                const unsigned ua = __float_as_uint(v[2 * p]), ub = __float_as_uint(v[2 * p + 1]);
+                e.pk[0][p] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+                e.rr[2 * p] = v[2 * p] - __uint_as_float(ua & 0xffff0000u);
+            } else if constexpr (part == 1) {
+                e.rr[2 * p + 1] = v[2 * p + 1] - __uint_as_float(__float_as_uint(v[2 * p + 1]) & 0xffff0000u);
+            } else if constexpr (part == 2) {
+                const unsigned va = __float_as_uint(e.rr[2 * p]), vb = __float_as_uint(e.rr[2 * p + 1]);
+                e.pk[1][p] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+                e.rr[2 * p] = e.rr[2 * p] - __uint_as_float(va & 0xffff0000u);
+            } else {
+                const float sb = e.rr[2 * p + 1] - __uint_as_float(__float_as_uint(e.rr[2 * p + 1]) & 0xffff0000u);
+                e.pk[2][p] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(e.rr[2 * p]), 0x07060302u);
+            }
         }
-    } else if constexpr (I < 36) {
-        // the six 16-byte writes of K steps m2, m2 + 1: three per piece
-        constexpr int k = I - 34;
+        if constexpr (U == 22 || U == 37) {
+            constexpr int k = U == 22 ? 0 : 1;
 #pragma unroll
-        for (int term = 0; term < 3; ++term) {
-            const u32x4w q = {e.pk[term][4 * k], e.pk[term][4 * k + 1], e.pk[term][4 * k + 2], e.pk[term][4 * k + 3]};
-            c.ob[((size_t)(m2 + k) * 3 + term) * 64] = __builtin_bit_cast(b8_t, q);
+            for (int term = 0; term < 3; ++term) {
+                const u32x4w q = {e.pk[term][4 * k], e.pk[term][4 * k + 1], e.pk[term][4 * k + 2], e.pk[term][4 * k + 3]};
+                c.ob[((size_t)(m2 + k) * 3 + term) * 64] = __builtin_bit_cast(b8_t, q);
+            }
         }
     }
+}
+template <int U0, int N, bool LAST>
+__device__ __forceinline__ void x6w_micros(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
+    x6w_for(std::make_integer_sequence<int, N>{}, [&](auto Uc) {
+        constexpr int U = U0 + decltype(Uc)::value;
+        if constexpr (U < 38) x6w_micro<U, LAST>(c, v, e, m2);
+    });
 }
 __device__ __forceinline__ void x6w_load_in(const X6W& c, b8_t (&in)[8][3], int s) {
     in[s][0] = c.ob[((size_t)s * 3 + 0) * 64]; in[s][1] = c.ob[((size_t)s * 3 + 1) * 64]; in[s][2] = c.ob[((size_t)s * 3 + 2) * 64];
 }
 
-// MFMA j (0..5) of K step s: x6_step's order; the first K step of a row tile starts a1 / a2 from the constant 0 (a0 holds the bias)
+// MFMA j (0..5) of K step s: x6_step's order; the first K step of a row tile starts a1 from the constant 0 (a0 holds the bias)
 template <int J, bool FIRST>
-__device__ __forceinline__ void x6w_mfma(const b8_t& A1, const b8_t& A2, const b8_t& A3, const b8_t (&B)[3], f32x16& a0, f32x16& a1, f32x16& a2) {
+__device__ __forceinline__ void x6w_mfma(const b8_t& A1, const b8_t& A2, const b8_t& A3, const b8_t (&B)[3], f32x16& a0, f32x16& a1) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (J == 0) a0 = MFMA16B(A1, B[0], a0);
     else if constexpr (J == 1) a1 = MFMA16B(A1, B[1], FIRST ? zero : a1);
-    else if constexpr (J == 2) a2 = MFMA16B(A2, B[1], FIRST ? zero : a2);
+    else if constexpr (J == 2) a1 = MFMA16B(A2, B[1], a1);
     else if constexpr (J == 3) a1 = MFMA16B(A2, B[0], a1);
-    else if constexpr (J == 4) a2 = MFMA16B(A1, B[2], a2);
-    else a2 = MFMA16B(A3, B[0], a2);
+    else if constexpr (J == 4) a1 = MFMA16B(A1, B[2], a1);
+    else a1 = MFMA16B(A3, B[0], a1);
 }
 
-// KIND of a row tile: 0 layer-0 tile (2 K steps on X0; 3 pieces per MFMA slot) | 1 first tile of a hidden layer (the pending epilogue is the
-// previous layer's last tile: 36 pieces in slots 0..29, its K steps 6, 7 pulled into `in` at slot 30, read at slot 36) | 2 middle tile |
+// KIND of a row tile: 0 layer-0 tile (2 K steps on X0; 3-4 micro-slots per MFMA slot) | 1 first tile of a hidden layer (the pending epilogue is the
+// previous layer's last tile: its 38 micro-slots in slots 0..29, its K steps 6, 7 pulled into `in` at slot 30, read at slot 36) | 2 middle tile |
 // 3 last tile of a hidden layer that has a successor (releases in[s] K step by K step and pulls the next layer's input in behind) | 4 last tile
 // of the last hidden layer
 template <int E0, int KIND, int LROW, bool HAVE_PE, bool PE_LAST>
 __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2)[X6W_RING], b8_t (&A3)[X6W_RING], const b8_t (&X0)[2][3], b8_t (&in)[8][3],
                                          float (&pv)[16], X6WEpi& e, int pm2, float (&nv)[16], f32x16& bias) {
     constexpr int NS = KIND == 0 ? 2 : 8;
-    f32x16 a0 = bias, a1, a2;                  // the bias rows of this tile were read from LDS a tile ago
+    f32x16 a0 = bias, a1;                  // the bias rows of this tile were read from LDS a tile ago
     x6w_for(std::make_integer_sequence<int, NS * 6>{}, [&](auto Ic) {
         constexpr int I = decltype(Ic)::value, s = I / 6, j = I % 6, en = E0 + s;
-        if constexpr (KIND == 0) x6w_mfma<j, s == 0>(A1[en % X6W_RING], A2[en % X6W_RING], A3[en % X6W_RING], X0[s], a0, a1, a2);
-        else x6w_mfma<j, s == 0>(A1[en % X6W_RING], A2[en % X6W_RING], A3[en % X6W_RING], in[s], a0, a1, a2);
+        if constexpr (KIND == 0) x6w_mfma<j, s == 0>(A1[en % X6W_RING], A2[en % X6W_RING], A3[en % X6W_RING], X0[s], a0, a1);
+        else x6w_mfma<j, s == 0>(A1[en % X6W_RING], A2[en % X6W_RING], A3[en % X6W_RING], in[s], a0, a1);
         if constexpr (j == 5 && en + X6W_RING - 1 < X6W_ENTRIES) {
             constexpr int x = en + X6W_RING - 1;
             if constexpr ((x & 3) == 0) {
+#ifndef X6W_PROBE_SAME_ENTRIES      // (timing probe: every wave re-reads the first four entries - 12 KB that stay in the CU's L1)
                 c.W1 += 256; c.W2 += 256; c.W3 += 256;
+#endif
                 asm volatile("" : "+v"(c.W1), "+v"(c.W2), "+v"(c.W3));
             }
             A1[x % X6W_RING] = c.W1[(x & 3) * 64]; A2[x % X6W_RING] = c.W2[(x & 3) * 64]; A3[x % X6W_RING] = c.W3[(x & 3) * 64];
         }
+#ifndef X6W_PROBE_NO_EPILOGUE          // (timing probe: the MFMA stream alone)
         if constexpr (HAVE_PE) {
-            if constexpr (KIND == 0) {
-                x6w_piece<3 * I, PE_LAST>(c, pv, e, pm2); x6w_piece<3 * I + 1, PE_LAST>(c, pv, e, pm2); x6w_piece<3 * I + 2, PE_LAST>(c, pv, e, pm2);
-            } else if constexpr (KIND == 1) {
-                if constexpr (I < 6) { x6w_piece<2 * I, PE_LAST>(c, pv, e, pm2); x6w_piece<2 * I + 1, PE_LAST>(c, pv, e, pm2); }
-                else if constexpr (I < 30) x6w_piece<I + 6, PE_LAST>(c, pv, e, pm2);
-            } else if constexpr (I < 36) x6w_piece<I, PE_LAST>(c, pv, e, pm2);
+            if constexpr (KIND == 0) {                        // 12 slots: 4 micro-slots in the first two, 3 in the others
+                if constexpr (I < 2) x6w_micros<4 * I, 4, PE_LAST>(c, pv, e, pm2);
+                else x6w_micros<8 + 3 * (I - 2), 3, PE_LAST>(c, pv, e, pm2);
+            } else if constexpr (KIND == 1) {                 // done by slot 29: two micro-slots in each of the first eight
+                if constexpr (I < 8) x6w_micros<2 * I, 2, PE_LAST>(c, pv, e, pm2);
+                else if constexpr (I < 30) x6w_micros<I + 8, 1, PE_LAST>(c, pv, e, pm2);
+            } else if constexpr (I < 38) x6w_micros<I, 1, PE_LAST>(c, pv, e, pm2);
         }
+#endif
         if constexpr (KIND == 1 && I == 30) { x6w_load_in(c, in, 6); x6w_load_in(c, in, 7); }
         if constexpr (I == 1 && LROW + 32 < 640) {     // the next row tile's bias (behind the first MFMA, which has just consumed this one's)
 #pragma unroll
@@ -137,12 +159,12 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
         }
         if constexpr (KIND == 3) {
             if constexpr (j == 5 && s < 4) x6w_load_in(c, in, s);
-            if constexpr (I == 36) { x6w_load_in(c, in, 4); x6w_load_in(c, in, 5); }
+            if constexpr (I == 40) { x6w_load_in(c, in, 4); x6w_load_in(c, in, 5); }      // (K step 5 of the output is written in micro-slot 37)
         }
         __builtin_amdgcn_sched_barrier(0);
     });
 #pragma unroll
-    for (int r = 0; r < 16; ++r) nv[r] = (a2[r] + a1[r]) + a0[r];
+    for (int r = 0; r < 16; ++r) nv[r] = a1[r] + a0[r];
     __builtin_amdgcn_sched_barrier(0);
 }
 

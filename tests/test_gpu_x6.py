@@ -95,6 +95,19 @@ def test_x6_repeats_bit_for_bit_at_two_workgroups_per_cu():
             assert torch.equal(a, b)
 
 
+def test_one_wave_per_tile_kernel_is_bit_identical_to_the_four_wave_kernel(tmp_path):
+    """vel_x6w.hip (the default for the prefilter / integrate_pos since round 5 late: a whole 128-wide layer per wave, the epilogue in the MFMAs'
+    VALU slots, no LDS exchange) forms the same products in the same order as k_rk2_x6: identical positions, ragged count, 0..19 evaluations
+    per point"""
+    outs = []
+    for w in ("0", "1"):
+        out = str(tmp_path / f"x6w{w}.npy")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "x6w_check.py"), out], env=dict(os.environ, NVFI_X6W=w), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "repeat identical: True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1]), int((outs[0] != outs[1]).any(1).sum())
+
+
 def _run(tmp_path, mode, extra=(), n=262144, **switches):
     out = str(tmp_path / f"x6_{mode}_{n}_{'_'.join(f'{k}{v}' for k, v in switches.items())}.npz")
     env = dict(os.environ, NVFI_PDE_PREFILTER=mode, **{k: str(v) for k, v in switches.items()})

@@ -12,7 +12,7 @@ import sys
 # reported on stderr instead of silently becoming 0)
 CLASSES = {
     "wgrad": [r"k_wgrad$", r"k_wgrad_ring8$"],
-    "pde_prefilter": [r"k_rk2_fwd<false, false>", r"k_rk2_split<", r"k_rk2_pre16", r"k_rk2_x6<"],
+    "pde_prefilter": [r"k_rk2_fwd<false, false>", r"k_rk2_split<", r"k_rk2_pre16", r"k_rk2_x6<", r"k_rk2_x6w"],
     "rk2_fwd": [r"k_rk2_fwd<true, true>", r"k_rk2_split_uni<", r"k_rk2_x6_uni<"],
     "rk2_bwd": [r"k_rk2_bwd", r"k_rk2_split_bwd<", r"k_rk2_fuse_bwd"],
     "pde_bwd": [r"k_pde_jet_bwd", r"k_pde_tangent_bwd", r"k_pde_value_bwd", r"k_pde_fuse_bwd"],
