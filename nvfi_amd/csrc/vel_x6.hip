@@ -467,6 +467,11 @@ int launch_rk2_x6_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipSt
         attr = true;
     }
     ProfScope ps(PK_RK2_FWD, st);
+    // NVFI_X6W_UNI: 1 (default) eval renders on the one-wave-per-tile kernel of vel_x6w.hip (bit-identical; an 800 x 800 test frame 134 -> 120 ms),
+    // 2 training renders too (same stash and records; no faster there: 0.35 against 0.37 ms, the stash stores are not hidden), 0 neither
+    static int wuni = -1;
+    if (wuni < 0) { const char* e = getenv("NVFI_X6W_UNI"); wuni = e ? atoi(e) : 1; }
+    if ((wuni >= 1 && !stash) || wuni >= 2) return launch_rk2_x6w_uni(a, cap_samples, stash, st);
     const unsigned two = (unsigned)((tiles + 1) / 2);
     if (x6_tiles_per_wg() == 1) {
         if (stash) hipLaunchKernelGGL((k_rk2_x6_uni<1, true>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);

@@ -33,6 +33,7 @@ struct X6W {
     const float* lb;               // LDS: raw biases [6][128]
     const float4* w5l;             // LDS: output-layer weights [m][h][r][8]
     b8_t* ob;                      // LDS, this wave's: + lane
+    float* zp;                     // STASH: the z rows of the current row tile (+ lane), RUNNING like the weight stream: 4 KB per row tile
     int lane, h;
 };
 
@@ -122,7 +123,7 @@ __device__ __forceinline__ void x6w_mfma(const b8_t& A1, const b8_t& A2, const b
 // previous layer's last tile: its 38 micro-slots in slots 0..29, its K steps 6, 7 pulled into `in` at slot 30, read at slot 36) | 2 middle tile |
 // 3 last tile of a hidden layer that has a successor (releases in[s] K step by K step and pulls the next layer's input in behind) | 4 last tile
 // of the last hidden layer
-template <int E0, int KIND, int LROW, bool HAVE_PE, bool PE_LAST>
+template <int E0, int KIND, int LROW, bool HAVE_PE, bool PE_LAST, bool STASH = false>
 __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2)[X6W_RING], b8_t (&A3)[X6W_RING], const b8_t (&X0)[2][3], b8_t (&in)[8][3],
                                          float (&pv)[16], X6WEpi& e, int pm2, float (&nv)[16], f32x16& bias) {
     constexpr int NS = KIND == 0 ? 2 : 8;
@@ -165,12 +166,20 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
     });
 #pragma unroll
     for (int r = 0; r < 16; ++r) nv[r] = a1[r] + a0[r];
+    if constexpr (STASH) {                     // the fp32 pre-activations, rows (l * 64 + 16 m + r) of the evaluation's stash: k_rk2_split_uni<STASH>'s layout
+#pragma unroll
+        for (int r = 0; r < 16; ++r) STASH_ST(c.zp[r * REGF], nv[r]);
+        c.zp += 16 * REGF;
+        asm volatile("" : "+v"(c.zp));
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // one evaluation of the net for the wave's 32 points
-__device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float (&out6)[6]) {
-    X6W c = c0;                    // (the stream pointers run through one evaluation)
+template <bool STASH = false>
+__device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float (&out6)[6], float* zst = nullptr, float* x0st = nullptr) {
+    X6W c = c0;
+    c.zp = STASH ? zst + c0.lane : nullptr;                    // (the stream pointers run through one evaluation)
     asm volatile("" : "+v"(c.W1), "+v"(c.W2), "+v"(c.W3));
     b8_t X0[2][3], in[8][3];
     b8_t A1[X6W_RING], A2[X6W_RING], A3[X6W_RING];
@@ -179,6 +188,7 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float
     {
         float x0[16];
         vel_encode_slots(q, c.h, x0);
+        if (STASH) stash_store<16>(x0st, c.lane, x0);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             unsigned p1[4], p2[4], p3[4];
@@ -206,30 +216,30 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias[r] = c.lb[(r & 3) + 8 * (r >> 2) + 4 * c.h];
     // layer 0 (28 -> 128): four row tiles of two K steps
-    x6w_tile<0, 0, 0, false, false>(c, A1, A2, A3, X0, in, va, e, 0, va, bias);
-    x6w_tile<2, 0, 32, true, false>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
-    x6w_tile<4, 0, 64, true, false>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
-    x6w_tile<6, 0, 96, true, false>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+    x6w_tile<0, 0, 0, false, false, STASH>(c, A1, A2, A3, X0, in, va, e, 0, va, bias);
+    x6w_tile<2, 0, 32, true, false, STASH>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
+    x6w_tile<4, 0, 64, true, false, STASH>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
+    x6w_tile<6, 0, 96, true, false, STASH>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
 #pragma unroll
     for (int s = 0; s < 6; ++s) x6w_load_in(c, in, s);
     // layers 1..3: first | middle | middle | last-with-successor
-    x6w_tile<8, 1, 128, true, false>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
-    x6w_tile<16, 2, 160, true, false>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
-    x6w_tile<24, 2, 192, true, false>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
-    x6w_tile<32, 3, 224, true, false>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
-    x6w_tile<40, 1, 256, true, false>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
-    x6w_tile<48, 2, 288, true, false>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
-    x6w_tile<56, 2, 320, true, false>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
-    x6w_tile<64, 3, 352, true, false>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
-    x6w_tile<72, 1, 384, true, false>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
-    x6w_tile<80, 2, 416, true, false>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
-    x6w_tile<88, 2, 448, true, false>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
-    x6w_tile<96, 3, 480, true, false>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+    x6w_tile<8, 1, 128, true, false, STASH>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
+    x6w_tile<16, 2, 160, true, false, STASH>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
+    x6w_tile<24, 2, 192, true, false, STASH>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
+    x6w_tile<32, 3, 224, true, false, STASH>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+    x6w_tile<40, 1, 256, true, false, STASH>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
+    x6w_tile<48, 2, 288, true, false, STASH>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
+    x6w_tile<56, 2, 320, true, false, STASH>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
+    x6w_tile<64, 3, 352, true, false, STASH>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+    x6w_tile<72, 1, 384, true, false, STASH>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
+    x6w_tile<80, 2, 416, true, false, STASH>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
+    x6w_tile<88, 2, 448, true, false, STASH>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
+    x6w_tile<96, 3, 480, true, false, STASH>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
     // layer 4: its activations go to LDS as floats (rows [m][4][lane] float4 of the same buffer, free once in[6..7] are in registers)
-    x6w_tile<104, 1, 512, true, false>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
-    x6w_tile<112, 2, 544, true, true>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
-    x6w_tile<120, 2, 576, true, true>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
-    x6w_tile<128, 4, 608, true, true>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+    x6w_tile<104, 1, 512, true, false, STASH>(c, A1, A2, A3, X0, in, vb, e, 6, va, bias);
+    x6w_tile<112, 2, 544, true, true, STASH>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
+    x6w_tile<120, 2, 576, true, true, STASH>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
+    x6w_tile<128, 4, 608, true, true, STASH>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
     // ---- 128 -> 6: fp32 FMAs in velnet_x6's order (per row tile: a chain over its 16 activations, the two lane halves added, then the tiles in order)
 #pragma unroll
     for (int o = 0; o < 6; ++o) out6[o] = c.lb[128 * 5 + o];
@@ -322,6 +332,93 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
         if (a.xout3) { float* o = a.xout3 + 3 * (size_t)n; o[0] = x; o[1] = y; o[2] = z; }
         else a.xw[n] = make_float4(x, y, z, zw);
     }
+}
+
+// ---------------------------------------------------------------- render warp (uniform schedule; k_rk2_x6_uni of vel_x6.hip, one wave per tile)
+// A workgroup = four consecutive tiles = one 128-sample group of the stash geometry (training: the adjoint walks whole groups)
+template <bool STASH>
+__global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w_uni(X6UniArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lb = lds;
+    float* w5f = lb + 6 * 128;
+    b8_t* obase = reinterpret_cast<b8_t*>(w5f + 4 * 2 * 16 * 8);
+    const Rk2Args& ra = a.r;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int count = *ra.count;
+    if ((int)blockIdx.x * WG_SAMPLES >= count) return;
+    for (int k = threadIdx.x; k < 6 * 128; k += WG_THREADS) lb[k] = (k & 127) < (k < 640 ? 128 : 6) ? ra.f.vb[k >> 7][k & 127] : 0.f;
+    for (int k = threadIdx.x; k < 4 * 2 * 16 * 8; k += WG_THREADS) {
+        const int o = k & 7, r = (k >> 3) & 15, hh = (k >> 7) & 1, ww = k >> 8;
+        w5f[k] = o < 6 ? ra.f.vW[5][o * 128 + 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
+    }
+    __syncthreads();
+    const size_t tile = (size_t)blockIdx.x * 4 + wv;
+    if (!STASH && (int)(tile * TILE) >= count) return;
+    const int idx = (int)tile * TILE + (lane & 31);
+    const bool active = idx < count;
+    const int n = active ? ra.list[idx] : 0;
+    const float4 q0 = active ? ra.xw[n] : zero4();
+    float x = q0.x, y = q0.y, z = q0.z;
+    const float zw = q0.w;
+    X6W c;
+    const b8_t* img = reinterpret_cast<const b8_t*>(a.img);
+    c.W1 = (x6w_gptr)(img + lane); c.W2 = (x6w_gptr)(img + X6_H8 + lane); c.W3 = (x6w_gptr)(img + 2 * X6_H8 + lane);
+    c.lb = lb; c.w5l = reinterpret_cast<const float4*>(w5f); c.ob = obase + (size_t)wv * X6W_OB_H8 + lane; c.lane = lane; c.h = h; c.zp = nullptr;
+    const int nsteps = ra.sched ? __float_as_int(ra.sched[2]) : ra.nsteps;
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+        const float dt = RK_DT(ra, s), tcur = RK_TC(ra, s), hdt = 0.5f * dt;
+        float px = x, py = y, pz = z;
+        float o6[6], w1[6];
+        bool g1 = false;
+#pragma unroll 1
+        for (int ev = 0; ev < 2; ++ev) {
+            const size_t e = (size_t)(2 * s + ev) * ra.cap_tiles + tile;
+            const float4 q = make_float4(px, py, pz, ev ? tcur - hdt : tcur);
+            velnet_x6w<STASH>(c, q, o6, STASH ? ra.zst + e * (VEL_Z_REGS * REGF) : nullptr, STASH ? ra.x0st + e * (VEL_X0_REGS * REGF) : nullptr);
+            if (ev == 0) {
+                float v1[3];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) w1[k] = o6[k];
+                vel_from_w(w1, x, y, z, v1);
+                g1 = gated_out(ra.f, x, y, z);
+                if (g1) { v1[0] = v1[1] = v1[2] = 0.f; }
+                px = x - hdt * v1[0]; py = y - hdt * v1[1]; pz = z - hdt * v1[2];
+            }
+        }
+        float v2[3];
+        vel_from_w(o6, px, py, pz, v2);
+        const bool g2 = gated_out(ra.f, px, py, pz);
+        if (g2) { v2[0] = v2[1] = v2[2] = 0.f; }
+        const float nx = x - dt * v2[0], ny = y - dt * v2[1], nz = z - dt * v2[2];
+        const bool rej = ra.f.gate_sur && gated_out(ra.f, nx, ny, nz);   // tensorf_keyframe.py:603-605
+        if (STASH && active && h == 0) {
+            float* rc = ra.rec + (size_t)s * RK_NF * ra.cap + idx;
+            rc[0 * ra.cap] = x; rc[1 * ra.cap] = y; rc[2 * ra.cap] = z;
+            rc[3 * ra.cap] = px; rc[4 * ra.cap] = py; rc[5 * ra.cap] = pz;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { rc[(6 + k) * ra.cap] = w1[k]; rc[(12 + k) * ra.cap] = o6[k]; }
+            rc[18 * ra.cap] = __int_as_float((g1 ? 1 : 0) | (g2 ? 2 : 0) | (rej ? 4 : 0));
+        }
+        if (active && !rej) { x = nx; y = ny; z = nz; }
+    }
+    if (active && h == 0) ra.xw[n] = make_float4(x, y, z, zw);
+}
+
+int launch_rk2_x6w_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipStream_t st) {
+    const int64_t groups = (cap_samples + WG_SAMPLES - 1) / WG_SAMPLES;
+    if (groups <= 0) return 0;
+    static bool attr = false;
+    if (!attr) {
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6w_uni<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6W_LDS_BYTES));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6w_uni<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X6W_LDS_BYTES));
+        attr = true;
+    }
+    if (stash) hipLaunchKernelGGL(k_rk2_x6w_uni<true>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(k_rk2_x6w_uni<false>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
+    LAUNCHCK();
+    return 0;
 }
 
 int launch_rk2_x6w(const X6Args& a, int64_t cap_points, hipStream_t st) {

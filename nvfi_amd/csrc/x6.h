@@ -61,3 +61,4 @@ int launch_rk2_x6w(const X6Args& a, int64_t cap_points, hipStream_t st);      //
 // the render warp (uniform step schedule, optional training stash) on the x6 evaluation: same arguments as the fp32 kernel + the image
 struct X6UniArgs { Rk2Args r; const void* img; };
 int launch_rk2_x6_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipStream_t st);
+int launch_rk2_x6w_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipStream_t st);   // vel_x6w.hip

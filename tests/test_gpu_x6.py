@@ -102,10 +102,15 @@ def test_one_wave_per_tile_kernel_is_bit_identical_to_the_four_wave_kernel(tmp_p
     outs = []
     for w in ("0", "1"):
         out = str(tmp_path / f"x6w{w}.npy")
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "x6w_check.py"), out], env=dict(os.environ, NVFI_X6W=w), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "x6w_check.py"), out], env=dict(os.environ, NVFI_X6W=w, NVFI_X6W_UNI="2" if w == "1" else "0"),
+                           capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "repeat identical: True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
-        outs.append(np.load(out))
-    assert np.array_equal(outs[0], outs[1]), int((outs[0] != outs[1]).any(1).sum())
+        outs.append((np.load(out), np.load(out + ".render.npz")))
+    assert np.array_equal(outs[0][0], outs[1][0]), int((outs[0][0] != outs[1][0]).any(1).sum())
+    # the render warp: eval render and training render (same stash -> same forward; the gradient through the fp32 adjoint differs by its atomics only)
+    for k in ("rgb", "depth", "train_rgb"):
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+    assert relerr(outs[1][1]["g"], outs[0][1]["g"]) < 2e-5
 
 
 def _run(tmp_path, mode, extra=(), n=262144, **switches):

@@ -17,3 +17,20 @@ with torch.no_grad():
 torch.cuda.synchronize()
 print("repeat identical:", all(torch.equal(o, outs[0]) for o in outs[1:]))
 np.save(sys.argv[1], outs[0].cpu().numpy())
+# the render warp (uniform schedule): an eval render of 4097 rays on field A, and a training render's stash consumers (gradients) on the same rays
+sys.path.insert(0, os.path.join(root, "tests"))
+from helpers import make_model
+model, meta = make_model("A"); fa = model.nvfi; fa.eval()
+gg = torch.Generator().manual_seed(1)
+o = torch.tensor([[2.6, -2.2, 2.4]]).expand(4097, 3).contiguous()
+d = (torch.rand(4097, 3, generator=gg) - 0.5) * 3.0 - o
+d = (d / d.norm(dim=-1, keepdim=True)).contiguous().cuda(); o = o.cuda()
+with torch.no_grad():
+    r = fa(0.41, o, d, True)
+fa.train(); model.zero_grad(set_to_none=True)
+fa.jitter_override = torch.rand(4097, 1, generator=gg)
+out = fa(0.41, o, d, True)
+fa.jitter_override = None
+out[0].square().mean().backward()
+gv = fa.vel_net.weight_net[4][0].weight.grad
+np.savez(sys.argv[1] + ".render.npz", rgb=r[0].cpu().numpy(), depth=r[1].cpu().numpy(), train_rgb=out[0].detach().cpu().numpy(), g=gv.cpu().numpy())
