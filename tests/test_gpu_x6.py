@@ -93,6 +93,35 @@ def test_x6_repeats_bit_for_bit_at_two_workgroups_per_cu():
     for k in range(1, 6):
         for a, b in zip(r[0], r[k]):
             assert torch.equal(a, b)
+    # training renders keep the four-waves-per-tile kernel at TWO workgroups per CU (k_rk2_x6_uni<1, stash>) - the configuration the glitch lived
+    # in: six forwards with one fixed jitter, 4096 rays (~3 x 10^5 warped samples each), identical bits
+    fa.train()
+    fa.jitter_override = torch.rand(4096, 1, generator=gg)
+    try:
+        with torch.no_grad():
+            rt = [[t.clone() for t in fa(0.41, o, d, True)[:4]] for _ in range(6)]
+    finally:
+        fa.jitter_override = None
+        fa.eval()
+    for k in range(1, 6):
+        for a, b in zip(rt[0], rt[k]):
+            assert torch.equal(a, b)
+    f.train()
+    # ... and on the bench field: 2 x 2048 rays at a non-keyframe time, the shape of the headline step
+    ob, db = bench.camera_bundle(torch.device("cuda"))
+    sel = torch.randperm(ob.shape[0], generator=torch.Generator().manual_seed(3))[:4096].cuda()
+    ob, db = ob[sel].contiguous(), db[sel].contiguous()
+    f.jitter_override = torch.rand(4096, 1, generator=gg)
+    try:
+        with torch.no_grad():
+            rb = [[t.clone() for t in f(19.0 / 60.0, ob, db, True)[:4]] for _ in range(6)]
+    finally:
+        f.jitter_override = None
+        f.eval()
+    assert int(f.last_counters[3]) > 100000
+    for k in range(1, 6):
+        for a, b in zip(rb[0], rb[k]):
+            assert torch.equal(a, b)
 
 
 def test_one_wave_per_tile_kernel_is_bit_identical_to_the_four_wave_kernel(tmp_path):
