@@ -6,10 +6,12 @@
 // wave (dual_pipe_probe3): the two add up, the matrix pipe is 40 % busy, and a second workgroup per CU only hides latencies.  Inside ONE wave
 // about four VALU instructions per 16-bit MFMA are free.  So: one wave owns a tile and all four 32-row tiles of every layer; while the 48
 // MFMAs of row tile m run, the wave's VALU slots carry the epilogue of row tile m - 1 (drain -> SiLU -> truncation split -> the two K steps of
-// the NEXT layer's B operand, which in this layout are the lane's own registers: no LDS exchange, no barrier); the epilogue of a layer's last
+// the NEXT layer's B operand, which in this layout are the lane's own: nothing is exchanged BETWEEN waves and there is no barrier; the layer
+// output travels through 24 KB of LDS of the wave's own only because two register arrays of 96 do not fit); the epilogue of a layer's last
 // row tile rides under K steps 0..5 of the next layer's first tile and is complete before K step 6 needs it.  The A operands (weights) are one
-// linear stream of 136 entries (layer 0: 8, layers 1..4: 32 each) through a four-slot register ring, three entries ahead.
-// Same products, same order of accumulation as k_rk2_x6: results are bit-identical (tests/test_gpu_x6.py).
+// linear stream of 136 entries (layer 0: 8, layers 1..4: 32 each) through an eight-slot register ring, seven entries ahead.
+// Same products, same order of accumulation as k_rk2_x6 / k_rk2_x6_uni: results are bit-identical (tests/test_gpu_x6.py); DESIGN.md 4.8.2 has the
+// counters of both kernels and what was tried.
 #include <stdlib.h>
 #include <utility>
 #include "common.h"

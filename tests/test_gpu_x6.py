@@ -151,11 +151,13 @@ def _run(tmp_path, mode, extra=(), n=262144, **switches):
     return np.load(out)
 
 
-@pytest.mark.parametrize("n,extra,nt", [(1000000, (), 1), (262144, ("--bench",), 1), (262144, ("--bench",), 2), (37, (), 1), (1000, (), 2)])
+@pytest.mark.parametrize("n,extra,nt", [(1000000, (), 0), (1000000, (), 1), (262144, ("--bench",), 0), (262144, ("--bench",), 1), (262144, ("--bench",), 2), (37, (), 0), (1000, (), 2)])
 def test_x6_prefilter_keeps_the_fp32_set(tmp_path, n, extra, nt):
     """both prefilters decide `alpha >= alphaMask_thres` on positions that differ by rounding (another summation order of the same fp32
     products): a point would have to sit within ~1e-7 of the threshold to flip - at most a handful among 10^6"""
-    a, b = _run(tmp_path, "fp32", extra, n), _run(tmp_path, "x6", extra, n, NVFI_X6_NT=nt)
+    # nt = 0: the default one-wave-per-tile kernel (vel_x6w.hip); 1 / 2: the four-waves-per-tile kernels with one / two tiles per workgroup
+    sw = dict(NVFI_X6W=1) if nt == 0 else dict(NVFI_X6W=0, NVFI_X6_NT=nt)
+    a, b = _run(tmp_path, "fp32", extra, n), _run(tmp_path, "x6", extra, n, **sw)
     for name in ("A", "B", "cfg1") + (("bench",) if extra else ()):
         ka, kb = a[f"{name}:kept"], b[f"{name}:kept"]
         flips = int((ka != kb).sum())
