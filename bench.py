@@ -601,8 +601,13 @@ class GraphedStep:
         for g, body in ((self.gH, self.body_head), (self.gP, self.body_pde), (self.gR, self.body_renders)):
             cap = torch.cuda.Stream(device=s.dev)
             cap.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.graph(g, stream=cap):      # (each graph its own memory pool: G_P and G_R replay side by side)
-                body()
+            # G_P and G_R read the fragment cache that G_H's pack node fills: every iteration replays G_H first (_multi_iteration)
+            s.m.nvfi.frags_packed_by_earlier_graph(g is not self.gH)
+            try:
+                with torch.cuda.graph(g, stream=cap):      # (each graph its own memory pool: G_P and G_R replay side by side)
+                    body()
+            finally:
+                s.m.nvfi.frags_packed_by_earlier_graph(False)
             torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         self.graph = self.gR

@@ -141,6 +141,10 @@ int nvfi_render_fwd_mse(const nvfi_field_desc* f, int64_t R, const float* rays_o
  *      after every change of the weights (once per optimiser step) and orders the readers behind the repack. */
 int nvfi_frag_cache_bytes(const nvfi_field_desc* f, int64_t* bytes);
 int nvfi_pack_frags(const nvfi_field_desc* f, void* cache, int64_t cache_bytes, void* stream);
+/* id of the hipGraph capture `stream` is part of (0: not capturing; forked streams of one capture share the id).  A caller that bakes the
+ * cache pointer into a captured call must have a nvfi_pack_frags node in the SAME capture (or replay the graph that holds it first): the
+ * Python mirror uses this id to refuse a cache that was packed outside the capture, whatever its key says. */
+int nvfi_stream_capture_id(void* stream, uint64_t* id);
 
 /* ---- PDE regulariser: replaces NVFi.get_vel_loss (models/nvfi.py:42-84) with explicit collocation
  *      points (world space (P,3)) and raw times (P).  out (device float[4]): loss, n_kept, sum div^2,
@@ -279,7 +283,9 @@ int nvfi_gen_rays(const float* pose3x4, int H, int W, float focal, int64_t n, co
  *      uniform in the box, times uniform in [0,1)), from a counter-based generator (Philox4x32-10 keyed by `seed`; counter = element, segment,
  *      iteration): same (seed, iteration) -> same batch, whatever the launch configuration.  Per batch b < n_batches: R pixel indices uniform in
  *      [0, n_pixels) -> rays_o/rays_d[b] gathered from the camera bundle (n_pixels,3), target[b] gathered from target_img (n_pixels,3) or, when
- *      that is NULL, uniform in [0,1) (synthetic benchmark targets); pixel_ids[b] (int64, optional) receives the indices.  P points + times. */
+ *      that is NULL, uniform in [0,1) (synthetic benchmark targets); pixel_ids[b] (int64, optional) receives the indices.  P points + times.
+ *      The R pixels of a batch are DISTINCT (np.random.choice(replace=False), camera.py:160): pixel r = perm_b(r), a keyed bijection of
+ *      [0, n_pixels) (four-round Feistel network, cycle-walked); R > n_pixels is refused like the reference's draw raises. */
 typedef struct nvfi_draw_desc {
     uint64_t seed, iteration;
     const uint64_t* iteration_dev;   /* optional: the iteration counter in DEVICE memory (hipGraph replay) */

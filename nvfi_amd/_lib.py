@@ -59,7 +59,7 @@ class DrawDesc(C.Structure):
 EXPORTS = [
     "nvfi_last_error", "nvfi_abi_version",
     "nvfi_render_workspace_bytes", "nvfi_render_workspace_bytes_t", "nvfi_render_fwd", "nvfi_render_bwd", "nvfi_render_fwd_t", "nvfi_render_bwd_t",
-    "nvfi_pde_loss_dev", "nvfi_adam_step_dev", "nvfi_frag_cache_bytes", "nvfi_pack_frags", "nvfi_render_fwd_mse", "nvfi_draw_batch",
+    "nvfi_pde_loss_dev", "nvfi_adam_step_dev", "nvfi_frag_cache_bytes", "nvfi_pack_frags", "nvfi_stream_capture_id", "nvfi_render_fwd_mse", "nvfi_draw_batch",
     "nvfi_pde_workspace_bytes", "nvfi_pde_loss", "nvfi_pde_loss_ex", "nvfi_pde_loss_split", "nvfi_plane_regs", "nvfi_plane_regs_dev", "nvfi_adam_step", "nvfi_mse", "nvfi_render_mask", "nvfi_render_export_masked", "nvfi_maskfield_workspace_bytes", "nvfi_maskfield_fwd", "nvfi_maskfield_bwd", "nvfi_sh_render", "nvfi_compute_alpha", "nvfi_gen_rays",
     "nvfi_vel_eval", "nvfi_vel_workspace_bytes", "nvfi_integrate_pos", "nvfi_density_at", "nvfi_app_at", "nvfi_render_mlp", "nvfi_app_workspace_bytes", "nvfi_alpha_workspace_bytes",
     "nvfi_comm_unique_id", "nvfi_comm_init", "nvfi_allreduce_grads", "nvfi_comm_destroy", "nvfi_selftest", "nvfi_debug_act", "nvfi_prof_enable", "nvfi_prof_collect", "nvfi_prof_nclasses",
@@ -90,6 +90,13 @@ def lib():
 def check(rc):
     if rc != 0:
         raise NvfiError(f"libnvfi_hip error {rc}: {lib().nvfi_last_error().decode()}")
+
+
+def capture_id(stream_handle):
+    """id (> 0) of the hipGraph capture the stream takes part in, 0 when it is not capturing"""
+    cid = C.c_uint64(0)
+    check(lib().nvfi_stream_capture_id(C.c_void_p(stream_handle), C.byref(cid)))
+    return cid.value
 
 
 def ptr(t):

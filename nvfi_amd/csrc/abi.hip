@@ -18,6 +18,13 @@ int nvfi_fail(int code, const char* fmt, ...) {
 }
 extern "C" const char* nvfi_last_error(void) { return g_err; }
 extern "C" int nvfi_abi_version(void) { return NVFI_ABI_VERSION; }
+extern "C" int nvfi_stream_capture_id(void* stream, uint64_t* id) {
+    hipStreamCaptureStatus stt = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    HIPCK(hipStreamGetCaptureInfo((hipStream_t)stream, &stt, &cid));
+    *id = stt == hipStreamCaptureStatusActive ? (uint64_t)cid + 1 : 0;
+    return 0;
+}
 
 // ---------------------------------------------------------------- VelBasis evaluation
 extern "C" int nvfi_vel_workspace_bytes(const nvfi_field_desc* f, int64_t N, int64_t* bytes) {
@@ -192,6 +199,28 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.f / 16777216.f); }     // [0, 1): 24 random bits, like torch.rand
+// a bijection of [0, n): four-round balanced Feistel network on the smallest 4^half >= n, cycle-walked back into range (x < n stays on
+// its own cycle, so distinct inputs give distinct outputs): pixel r of a batch is perm(r) - R DISTINCT pixels, as Camera.sample_rays'
+// np.random.choice(..., replace=False) draws them (models/camera.py:160)
+__device__ __forceinline__ unsigned feistel_perm(unsigned r, unsigned n, const unsigned (&key)[4]) {
+    if (n <= 1) return 0;
+    const int bits = 32 - __clz((int)(n - 1));
+    const int half = (bits + 1) >> 1;
+    const unsigned mask = (1u << half) - 1u;
+    unsigned x = r;
+    do {
+        unsigned L = x >> half, R = x & mask;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned f = (R + key[k]) * 0x9E3779B1u;
+            f ^= f >> 15; f *= 0x85EBCA77u; f ^= f >> 13;
+            const unsigned nl = R;
+            R = (L ^ f) & mask; L = nl;
+        }
+        x = (L << half) | R;
+    } while (x >= n);
+    return x;
+}
 __global__ __launch_bounds__(256) void k_draw_batch(nvfi_draw_desc a) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const unsigned long long it = a.iteration_dev ? *a.iteration_dev : a.iteration;
@@ -200,8 +229,10 @@ __global__ __launch_bounds__(256) void k_draw_batch(nvfi_draw_desc a) {
     if (i < a.R * a.n_batches) {
         const int b = (int)(i / a.R);
         const int64_t r = i - (int64_t)b * a.R;
+        unsigned key[4];
+        philox4x32_10(0xffffffffu, 0x40000000u | (unsigned)b, (unsigned)it, (unsigned)(it >> 32), k0, k1, key);     // the batch's permutation key
         philox4x32_10((unsigned)r, (unsigned)b, (unsigned)it, (unsigned)(it >> 32), k0, k1, w);
-        const int64_t pix = (int64_t)(((unsigned long long)w[0] * (unsigned long long)a.n_pixels) >> 32);     // uniform in [0, n_pixels)
+        const int64_t pix = (int64_t)feistel_perm((unsigned)r, (unsigned)a.n_pixels, key);     // R distinct pixels of [0, n_pixels)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             a.rays_o[b][3 * r + c] = a.bundle_o[3 * pix + c];
@@ -220,6 +251,8 @@ __global__ __launch_bounds__(256) void k_draw_batch(nvfi_draw_desc a) {
 extern "C" int nvfi_draw_batch(const nvfi_draw_desc* d, void* stream) {
     if (d->n_batches < 0 || d->n_batches > 2) return nvfi_fail(2, "nvfi_draw_batch: n_batches must be 0, 1 or 2");
     if (d->n_batches > 0 && (d->R <= 0 || d->n_pixels <= 0 || !d->bundle_o || !d->bundle_d)) return nvfi_fail(2, "nvfi_draw_batch: ray batches need R, n_pixels and the camera bundle");
+    if (d->n_batches > 0 && (d->R > d->n_pixels || d->n_pixels >= (1ll << 31)))
+        return nvfi_fail(2, "nvfi_draw_batch: R = %lld distinct pixels of %lld (the draw is without replacement, like np.random.choice(replace=False))", (long long)d->R, (long long)d->n_pixels);
     for (int b = 0; b < d->n_batches; ++b) if (!d->rays_o[b] || !d->rays_d[b] || !d->target[b]) return nvfi_fail(2, "nvfi_draw_batch: batch %d has a NULL output", b);
     if (d->P > 0 && (!d->points || !d->t)) return nvfi_fail(2, "nvfi_draw_batch: points / t are NULL");
     int64_t n = d->R * d->n_batches;

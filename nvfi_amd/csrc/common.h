@@ -16,6 +16,25 @@ int nvfi_fail(int code, const char* fmt, ...);
     } while (0)
 #define LAUNCHCK() HIPCK(hipGetLastError())
 
+// per-device one-time set-up of a launcher (hipFuncSetAttribute applies to the CURRENT device): `apply` runs under a lock until it has
+// succeeded once on the device - a failed or racing first call leaves nothing marked as done
+#ifdef __cplusplus
+#include <mutex>
+struct DeviceOnce {
+    std::mutex mu;
+    bool done[64] = {false};
+    template <class F> int run(F apply) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        std::lock_guard<std::mutex> g(mu);
+        if (done[dev]) return 0;
+        const int rc = apply();
+        if (rc == 0) done[dev] = true;
+        return rc;
+    }
+};
+#endif
+
 // optional per-kernel-class HIP-event timing (bench.py): events are recorded on the launch stream
 enum { PK_RK2_FWD = 0, PK_RK2_BWD, PK_APP_FWD, PK_APP_BWD, PK_WGRAD, PK_PDE_FWD, PK_PDE_BWD, PK_DENSITY_FWD, PK_DENSITY_BWD,
        PK_PDE_PREFILTER, PK_DENSITY_SCATTER, PK_APP_SCATTER, PK_OTHER, PK_COUNT };

@@ -444,13 +444,6 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6_uni(X6Un
 #define X6_ONE_WG_LDS (84 * 1024)
 // (per device: hipFuncSetAttribute applies to the device that is current - one process per GPU never sees a second one, a host that drives
 // several devices from one process does)
-static bool x6_first_call_on_device(bool (&seen)[64]) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (seen[dev]) return false;
-    seen[dev] = true;
-    return true;
-}
 template <typename K>
 static int x6_set_lds(K kernel) {
     HIPCK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6_ONE_WG_LDS));
@@ -470,10 +463,8 @@ static size_t x6_lds_nt1() {
 int launch_rk2_x6_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipStream_t st) {
     const int64_t tiles = (cap_samples + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
-    static bool seen[64] = {false};
-    if (x6_first_call_on_device(seen)) {
-        if (x6_set_lds(k_rk2_x6_uni<1, true>) || x6_set_lds(k_rk2_x6_uni<1, false>) || x6_set_lds(k_rk2_x6_uni<2, true>) || x6_set_lds(k_rk2_x6_uni<2, false>)) return 1;
-    }
+    static DeviceOnce once;
+    if (once.run([] { return (x6_set_lds(k_rk2_x6_uni<1, true>) || x6_set_lds(k_rk2_x6_uni<1, false>) || x6_set_lds(k_rk2_x6_uni<2, true>) || x6_set_lds(k_rk2_x6_uni<2, false>)) ? 1 : 0; })) return 1;
     ProfScope ps(PK_RK2_FWD, st);
     // NVFI_X6W_UNI: 1 (default) eval renders on the one-wave-per-tile kernel of vel_x6w.hip (bit-identical; an 800 x 800 test frame 134 -> 120 ms),
     // 2 training renders too (same stash and records; no faster there: 0.35 against 0.37 ms, the stash stores are not hidden), 0 neither
@@ -495,10 +486,8 @@ int launch_rk2_x6_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipSt
 int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st) {
     const int64_t tiles = (cap_points + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
-    static bool seen[64] = {false};
-    if (x6_first_call_on_device(seen)) {
-        if (x6_set_lds(k_rk2_x6<1>) || x6_set_lds(k_rk2_x6<2>)) return 1;
-    }
+    static DeviceOnce once;
+    if (once.run([] { return (x6_set_lds(k_rk2_x6<1>) || x6_set_lds(k_rk2_x6<2>)) ? 1 : 0; })) return 1;
     const int nt = x6_tiles_per_wg();
     // default since round 5 (late): one wave per tile, the epilogue in the MFMAs' VALU slots (vel_x6w.hip; bit-identical results, the bench
     // prefilter 0.89 -> 0.83 ms).  NVFI_X6W=0: the four-waves-per-tile kernel below

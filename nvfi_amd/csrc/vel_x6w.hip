@@ -337,13 +337,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
 }
 
 // (per device: hipFuncSetAttribute applies to the device that is current - one process per GPU never sees a second one, a host that drives
-// several devices from one process does)
-static bool x6_first_call_on_device(bool (&seen)[64]) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (seen[dev]) return false;
-    seen[dev] = true;
-    return true;
+// several devices from one process does; common.h: DeviceOnce)
+template <typename K>
+static int x6w_set_lds(K kernel) {
+    HIPCK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6W_LDS_BYTES));
+    return 0;
 }
 // ---------------------------------------------------------------- render warp (uniform schedule; k_rk2_x6_uni of vel_x6.hip, one wave per tile)
 // A workgroup = four consecutive tiles = one 128-sample group of the stash geometry (training: the adjoint walks whole groups)
@@ -420,11 +418,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w_uni(X6UniArgs a) {
 int launch_rk2_x6w_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipStream_t st) {
     const int64_t groups = (cap_samples + WG_SAMPLES - 1) / WG_SAMPLES;
     if (groups <= 0) return 0;
-    static bool seen[64] = {false};
-    if (x6_first_call_on_device(seen)) {
-        HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6w_uni<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6W_LDS_BYTES));
-        HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6w_uni<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X6W_LDS_BYTES));
-    }
+    static DeviceOnce once;
+    if (once.run([] { return (x6w_set_lds(k_rk2_x6w_uni<true>) || x6w_set_lds(k_rk2_x6w_uni<false>)) ? 1 : 0; })) return 1;
     if (stash) hipLaunchKernelGGL(k_rk2_x6w_uni<true>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
     else hipLaunchKernelGGL(k_rk2_x6w_uni<false>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
     LAUNCHCK();
@@ -434,8 +429,8 @@ int launch_rk2_x6w_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipS
 int launch_rk2_x6w(const X6Args& a, int64_t cap_points, hipStream_t st) {
     const int64_t tiles = (cap_points + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
-    static bool seen[64] = {false};
-    if (x6_first_call_on_device(seen)) { HIPCK(hipFuncSetAttribute((const void*)k_rk2_x6w, hipFuncAttributeMaxDynamicSharedMemorySize, X6W_LDS_BYTES)); }
+    static DeviceOnce once;
+    if (once.run([] { return x6w_set_lds(k_rk2_x6w); })) return 1;
     hipLaunchKernelGGL(k_rk2_x6w, dim3((unsigned)((tiles + 3) / 4)), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
     LAUNCHCK();
     return 0;

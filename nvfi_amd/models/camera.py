@@ -127,11 +127,12 @@ class Camera(object):
 
     def sample_rays_device(self, n_rays, generator=None):
         """Device-side variant of sample_rays (next-row f-2): pixel ids drawn on the GPU, rays generated by nvfi_gen_rays without
-        materialising the H*W bundle.  (Sampling is with replacement, unlike np.random.choice(replace=False).)"""
+        materialising the H*W bundle.  n_rays DISTINCT pixels, like np.random.choice(replace=False) below (a device-side permutation;
+        the fused driver's nvfi_draw_batch draws without replacement too, through a keyed bijection of the pixel range)."""
         import ctypes as C
         from .. import _lib
         dev = self.pose.device
-        ids = torch.randint(0, self.height * self.width, (n_rays,), device=dev, generator=generator)
+        ids = torch.randperm(self.height * self.width, device=dev, generator=generator)[:n_rays].contiguous()
         ro = torch.empty(n_rays, 3, device=dev)
         rd = torch.empty(n_rays, 3, device=dev)
         pose = self.pose[:3, :4].contiguous().float()

@@ -582,7 +582,7 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         """every host-side attribute nvfi_field_desc's scalar fields are derived from (attributes a caller may assign at any time)"""
         am = self.alphaMask
         vel = self.__dict__["_modules"].get("vel") if self.use_vel else None
-        return (self.nSamples, self._step_host, id(self._aabb_host), id(self._grid_host), self.num_keyframes, self.use_vel, self.shadingMode,
+        return (self.nSamples, self._step_host, tuple(self._aabb_host), tuple(self._grid_host), self.num_keyframes, self.use_vel, self.shadingMode,
                 self.vel_fp16, self.__dict__.get("vel_fp16_train", False), self.density_shift, self.distance_scale, self.rayMarch_weight_thres,
                 self.alphaMask_thres, self.tmax, self.near_far[0], self.near_far[1], self.app_dim,
                 0 if am is None else am.alpha_volume.data_ptr(), id(vel), getattr(vel, "eps", None) if vel is not None else None)
@@ -664,8 +664,18 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         key = (tuple(p.data_ptr() for p in lin), tuple(p._version for p in lin), _optim.GENERATION, rt.get("_frag_epoch", 0))
         fc = rt.get("_frag_cache")
         cur = torch.cuda.current_stream()
-        if fc is None or fc["key"] != key or fc["buf"].device != ps[0].device:
-            if torch.cuda.is_current_stream_capturing() and not rt.get("_frag_capture_ok"):
+        # Under hipGraph capture the pointer is BAKED into the graph: a cache that is current now says nothing about the replays, which run
+        # after optimiser steps the key will never see.  So while capturing, the cache is used only if its pack launch is a node
+        # of THIS capture (repack_frags() at the head of the captured iteration; forked streams share the capture id) - or if the driver
+        # vouches that it replays the graph holding the pack node first (frags_packed_by_earlier_graph, the three-graph multi-rank step);
+        # everything else packs per call, whatever the key says.
+        cap = _lib.capture_id(cur.cuda_stream) if torch.cuda.is_current_stream_capturing() else 0
+        repack_now = bool(rt.get("_frag_capture_ok"))
+        if cap and not repack_now and not rt.get("_frag_trust_graph"):
+            if fc is None or fc["key"] != key or fc.get("capture") != cap:
+                return None
+        if repack_now or fc is None or fc["key"] != key or fc["buf"].device != ps[0].device:
+            if cap and not repack_now:
                 return None         # (a captured iteration repacks explicitly at its head: repack_frags(); anything else packs per call)
             L = _lib.lib()
             buf = fc["buf"] if fc is not None and fc["buf"].device == ps[0].device else None
@@ -677,7 +687,8 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             _lib.check(L.nvfi_pack_frags(C.byref(d), _lib.ptr(buf), C.c_int64(buf.numel()), C.c_void_p(cur.cuda_stream)))
             ev = torch.cuda.Event()
             ev.record(cur)
-            fc = rt["_frag_cache"] = dict(key=key, buf=buf, event=ev, stream=cur, waited=set())
+            fc = rt["_frag_cache"] = dict(key=key, buf=buf, event=ev, stream=cur, waited=set(), capture=cap)
+            rt["_frag_capture_ok"] = False
         elif cur != fc["stream"] and cur.cuda_stream not in fc["waited"]:
             cur.wait_event(fc["event"])
             fc["waited"].add(cur.cuda_stream)
@@ -690,7 +701,8 @@ class TensorVMKeyframeTimeKplane(nn.Module):
 
     def repack_frags(self):
         """Repack the fragment cache NOW on the current stream (one launch) whatever its key says, and leave it current: a driver that forks
-        the iteration's chains over several streams - or captures the iteration as a hipGraph - calls this at the head of the iteration."""
+        the iteration's chains over several streams - or captures the iteration as a hipGraph - calls this at the head of the iteration.
+        Under capture the pack launch becomes a node of the graph and only calls of the SAME capture read the cache (_frags)."""
         self.invalidate_frags()
         rt = _rt(self)
         rt["_frag_capture_ok"] = True
@@ -698,6 +710,12 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             self._desc()
         finally:
             rt["_frag_capture_ok"] = False
+
+    def frags_packed_by_earlier_graph(self, on=True):
+        """A driver that captures the iteration as SEVERAL graphs (bench.py: the multi-rank step) packs in the first and replays it before
+        the others: it tells the field so for the duration of the later captures - the only case in which a captured call may read a cache
+        whose pack launch is not a node of its own capture."""
+        _rt(self)["_frag_trust_graph"] = bool(on)
 
     def _grads_struct(self, grads):
         G = _lib.Grads()

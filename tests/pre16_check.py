@@ -69,8 +69,32 @@ def flips_run(path, total):
     np.savez(path, kept=np.concatenate(masks), band=np.int64(band), n=np.int64(len(masks) * B))
 
 
+def repeat_run(total):
+    """the prefilter pre-pass eight times on the same `total` points of the bench field: kept mask and counters must not change"""
+    import bench
+    model = bench.build_scene(torch.device("cuda"))
+    f = model.nvfi
+    rng = np.random.default_rng(5)
+    aabb = f.aabb.detach().cpu().numpy()
+    pts = torch.from_numpy((rng.uniform(0, 1, (total, 3)) * (aabb[1] - aabb[0]) + aabb[0]).astype(np.float32)).cuda()
+    t = torch.from_numpy(rng.uniform(0, 1, (total, 1)).astype(np.float32)).cuda()
+    outs = []
+    with torch.no_grad():
+        for _ in range(8):
+            f.pde_debug = 1
+            try:
+                model.get_vel_loss(points=pts, t=t)
+            finally:
+                f.pde_debug = 0
+            outs.append((f.last_pde_kept.clone(), f.last_pde_counters.clone()))
+    same = all(torch.equal(a[0], outs[0][0]) and torch.equal(a[1][:6], outs[0][1][:6]) for a in outs[1:])
+    print("kept", int(outs[0][0].sum()), "counters", outs[0][1].tolist(), "repeat identical:", same)
+
+
 def main():
     path = sys.argv[1]
+    if "--repeat" in sys.argv:
+        return repeat_run(int(sys.argv[sys.argv.index("--repeat") + 1]))
     if "--flips" in sys.argv:
         return flips_run(path, int(sys.argv[sys.argv.index("--flips") + 1]))
     N = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else 262144

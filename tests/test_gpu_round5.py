@@ -253,3 +253,82 @@ def test_draw_batch_is_a_counter_based_generator():
     assert float((cc - torch.eye(4, device=dev, dtype=cc.dtype)).abs().max()) < 1e-2
     pid = ids[0].double() / n_pix
     assert abs(float(pid.mean()) - 0.5) < 0.04
+    # round 6: the R pixels of a batch are DISTINCT, like np.random.choice(replace=False) (models/camera.py:160) ...
+    for bch in range(2):
+        assert int(torch.unique(ids[bch]).numel()) == R
+    # ... also when the batch is the whole image (a permutation), and every pixel is equally likely over many iterations
+    small = 1000
+    bo2, bd2 = bo[:small].contiguous(), bd[:small].contiguous()
+    ds = _lib.DrawDesc()
+    ro2, rd2, tg2 = torch.empty(small, 3, device=dev), torch.empty(small, 3, device=dev), torch.empty(small, 3, device=dev)
+    id2 = torch.empty(small, dtype=torch.int64, device=dev)
+    ds.seed, ds.iteration, ds.n_batches, ds.R, ds.n_pixels = 11, 0, 1, small, small
+    ds.bundle_o, ds.bundle_d, ds.target_img = _lib.ptr(bo2), _lib.ptr(bd2), None
+    ds.rays_o[0], ds.rays_d[0], ds.target[0], ds.pixel_ids[0] = _lib.ptr(ro2), _lib.ptr(rd2), _lib.ptr(tg2), _lib.ptr(id2)
+    _draw(ds); torch.cuda.synchronize()
+    assert torch.equal(torch.sort(id2)[0], torch.arange(small, device=dev))
+    ds.R = 100
+    hits = torch.zeros(small, device=dev)
+    first = torch.zeros(small, device=dev)
+    for it in range(400):
+        ds.iteration = it
+        _draw(ds)
+        hits.index_add_(0, id2[:100], torch.ones(100, device=dev))
+        first[id2[0]] += 1
+    torch.cuda.synchronize()
+    # 400 x 100 draws over 1000 pixels: 40 expected per pixel (sigma 6), 0.4 as the first pixel of a batch
+    assert float(hits.sum()) == 40000 and float((hits - 40).abs().max()) < 6 * 6.0, (float(hits.min()), float(hits.max()))
+    assert float(first.max()) <= 6
+    ds.R, ds.n_pixels = 200, 100
+    assert _lib.lib().nvfi_draw_batch(C.byref(ds), C.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0
+    assert b"without replacement" in _lib.lib().nvfi_last_error()
+
+
+def test_captured_call_never_bakes_in_a_cache_it_did_not_pack():
+    """the fragment-cache pointer of a CAPTURED call is baked into the graph.  A cache that is current at capture time (an eval
+    render ran after the last optimiser step) must not be used unless its pack launch is a node of the same capture - otherwise every replay
+    would render stale fragments while the optimiser keeps moving the weights.  (a) without repack_frags() the captured call packs per call
+    (frags NULL) and the replay follows the weights; (b) with repack_frags() at the head of the capture the cache is used AND the replay
+    follows the weights; (c) a second capture without a pack node does not inherit the first one's permission."""
+    from nvfi_amd.models.tensorf_keyframe import _rt
+    from nvfi_amd.optim import Adam
+    gold = np.load(os.path.join(GOLD, "hotpath.npz"))
+    model, meta = make_model("A")
+    f = model.nvfi
+    f.eval()
+    o, d = _cu(gold["A:rays_o"]), _cu(gold["A:rays_d"])
+    t = 0.38 * f.tmax / (f.num_keyframes - 1)
+    mlp = [p for n, p in model.named_parameters() if "renderModule" in n or "vel_net.weight_net" in n]
+    opt = Adam(mlp, lr=5e-2)
+
+    def eager():
+        with torch.no_grad():
+            return f(t, o, d, True)[0].clone()
+
+    def step():
+        for p in mlp:
+            p.grad = torch.randn_like(p)
+        opt.step()
+
+    for repack in (False, True, False):
+        eager()                                    # the cache is current for today's weights
+        assert _rt(f)["_frag_cache"] is not None
+        seen = []
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            if repack:
+                f.repack_frags()
+            seen.append(f._desc().frags)
+            with torch.no_grad():
+                out = f(t, o, d, True)[0]
+        torch.cuda.current_stream().wait_stream(cap)
+        assert (seen[0] is not None) == repack, (repack, seen)
+        before = eager()
+        step()
+        after = eager()
+        assert not torch.equal(before, after)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, after), ("replay rendered stale fragments", repack, float((out - after).abs().max()))

@@ -223,3 +223,70 @@ def test_gpu_training_render_with_fp16_forward_warp_matches_the_fp16_oracle(gold
     dv = np.abs(g16["vel_net.weight_net.4.0.weight"] - g32["vel_net.weight_net.4.0.weight"]).max() / np.abs(g32["vel_net.weight_net.4.0.weight"]).max()
     assert 1e-6 < dv < 5e-2, dv
     print(f"[{kind}] fp16-forward training warp: {n} gradients within 1e-3 of the fp16 oracle; velocity-net gradient differs from the fp32 path by {dv:.2e} (max-norm)")
+
+
+def test_fp16_input_kernels_repeat_bit_for_bit():
+    """round 6: pre16.hip carries 16-bit MFMAs for eight waves per workgroup - two per SIMD, the occupancy at which the
+    x6 kernels once glitched with packed-fp32 VALU code beside them.  The unit is compiled with the same fence now
+    (nvfi_amd/build.py: -fno-slp-vectorize + check_no_packed_f32) and gets the same run-to-run identity test as x6: 8 x 524 288 points
+    through k_rk2_inf16 per-point (vel_fp16 = 1 and the two-term mode 2), six eval renders (uniform schedule), six training forwards
+    with the fp16 warp (stash variant), and the fp16band / split16band PDE prefilters (k_rk2_pre16) in a subprocess."""
+    import os
+    import subprocess
+    import sys
+    import bench
+    from conftest import ROOT
+    from helpers import make_model
+    m = bench.build_scene(torch.device("cuda"), 199, 128, True)
+    f = m.nvfi
+    f.eval()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    N = 1 << 19
+    ts = f.tmax / (f.num_keyframes - 1)
+    x = torch.rand(N, 3, device="cuda", generator=g) * 1.6 - 0.8
+    tt = torch.full((N, 1), float(np.float32(ts * 0.5 * 4 * 0.999)), device="cuda")
+    base = torch.zeros(N, 1, device="cuda")
+    for mode in (1, 2):
+        f.vel_fp16 = mode
+        try:
+            with torch.no_grad():
+                outs = [f.integrate_pos(x.clone(), tt.clone(), base).clone() for _ in range(8)]
+        finally:
+            f.vel_fp16 = False
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), (mode, int((o != outs[0]).any(-1).sum()))
+    model, meta = make_model("A")
+    fa = model.nvfi
+    gg = torch.Generator().manual_seed(1)
+    o = torch.tensor([[2.6, -2.2, 2.4]]).expand(4096, 3).contiguous()
+    d = (torch.rand(4096, 3, generator=gg) - 0.5) * 3.0 - o
+    d = (d / d.norm(dim=-1, keepdim=True)).contiguous().cuda()
+    o = o.cuda()
+    fa.eval()
+    fa.vel_fp16 = 1
+    try:
+        with torch.no_grad():
+            r = [[t.clone() for t in fa(0.41, o, d, True)[:4]] for _ in range(6)]
+    finally:
+        fa.vel_fp16 = False
+    assert int(fa.last_counters[3]) > 100000
+    for k in range(1, 6):
+        for a, b in zip(r[0], r[k]):
+            assert torch.equal(a, b)
+    fa.train()
+    fa.vel_fp16_train = True
+    fa.jitter_override = torch.rand(4096, 1, generator=gg)
+    try:
+        with torch.no_grad():
+            rt = [[t.clone() for t in fa(0.41, o, d, True)[:4]] for _ in range(6)]
+    finally:
+        fa.jitter_override = None
+        fa.vel_fp16_train = False
+        fa.eval()
+    for k in range(1, 6):
+        for a, b in zip(rt[0], rt[k]):
+            assert torch.equal(a, b)
+    for mode in ("fp16band", "split16band"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pre16_check.py"), "-", "--repeat", str(N)], env=dict(os.environ, NVFI_PDE_PREFILTER=mode),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "repeat identical: True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
