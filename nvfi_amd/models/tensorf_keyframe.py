@@ -694,6 +694,14 @@ class TensorVMKeyframeTimeKplane(nn.Module):
             fc["waited"].add(cur.cuda_stream)
         return fc["buf"].data_ptr()
 
+    def render_workspace_bytes(self, R, t, train=False, transfer=False):
+        """bytes nvfi_render_fwd[_t] plans for R rays at time t (include/nvfi_hip.h: nvfi_render_workspace_bytes_t)"""
+        nb = C.c_int64(0)
+        desc = self._desc()
+        flags = (_lib.NVFI_TRAIN if train else 0) | (_lib.NVFI_TRANSFER if transfer else 0)
+        _lib.check(_lib.lib().nvfi_render_workspace_bytes_t(C.byref(desc), C.c_int64(int(R)), C.c_int(flags), C.c_float(float(t)), C.byref(nb)))
+        return int(nb.value)
+
     def invalidate_frags(self):
         """the weights were edited behind torch's version counters (p.data.copy_(), a raw kernel): the next call repacks"""
         rt = _rt(self)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Pins BASELINE.json's "PSNR within 0.05 dB of reference" (VERDICT r5 missing 1): the REFERENCE (PyTorch CPU, /root/reference, build
+container only) runs its own training loop - tests/psnr_loop.py: the body of train_nvfi.py:139-249 and the validation PSNR of
+train_nvfi.py:275-330 / utils/metrics.py:11 - on a teacher / student pair derived from field A (tests/golden/field_A.npz: 20 x 18 x 16
+grid, K = 4, 60 samples per ray), 300 iterations, three seeds of the training draws, and records the validation PSNR it reaches at a
+keyframe and at a non-keyframe time.  The fixture (psnr.npz) holds numbers only.
+
+    python tests/golden/make_golden_psnr.py [iters] [seeds]        # ~10 min on 8 cores
+"""
+import contextlib
+import io
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from make_golden import import_reference, build_field  # noqa: E402
+import psnr_loop  # noqa: E402
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seeds = [int(s) for s in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 3]
+    R = import_reference()
+    import torch
+    torch.set_num_threads(8)
+    B = types.SimpleNamespace(Renderer=R["Renderer"], Camera=R["Camera"], Ray=R["Ray"], TVLoss=R["TVLoss"])
+    out = {"iters": np.int64(iters), "seeds": np.asarray(seeds, np.int64)}
+    rows = []
+    for seed in seeds:
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, teacher = build_field(R, "A")
+            _, student = build_field(R, "A")
+        sd = psnr_loop.student_state(teacher.state_dict())
+        student.load_state_dict(sd)
+        t0 = time.time()
+        r = psnr_loop.run(B, teacher, student, "cpu", seed, iters=iters, log=lambda s: print(s, f"({time.time() - t0:.0f} s)", flush=True))
+        print(seed, r, flush=True)
+        rows.append([r["psnr_key"], r["psnr_nonkey"], r["psnr_key_before"], r["psnr_nonkey_before"], r["loss_first"], r["loss_last"]])
+    out["columns"] = np.asarray(["psnr_key", "psnr_nonkey", "psnr_key_before", "psnr_nonkey_before", "loss_first", "loss_last"])
+    out["reference"] = np.asarray(rows, np.float64)
+    np.savez(os.path.join(HERE, "psnr.npz"), **out)
+    a = out["reference"]
+    print("reference PSNR after", iters, "iterations: key", a[:, 0], "non-key", a[:, 1], "| spread", a[:, :2].max(0) - a[:, :2].min(0))
+
+
+if __name__ == "__main__":
+    main()
