@@ -849,11 +849,16 @@ class SegmStep:
         self.mf.mfma_fp16 = bool(fp16)
         self.opt = torch.optim.Adam(self.mf.parameters(), lr=0.005, betas=(0.9, 0.999), fused=True)
         self.points, self.steps_rk = 0, 0
+        self.time_advect, self.advect_events, self.advect_evals = False, [], 0
 
     def __call__(self):
         from nvfi_amd.utils.segm_utils import segm_points
         f = self.f
-        xyz, flow, t = segm_points(f, self.res, min_t=0.5, alpha_scale=10.0)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.time_advect else None
+        xyz, flow, t = segm_points(f, self.res, min_t=0.5, alpha_scale=10.0, advect_events=ev)
+        if ev is not None:
+            self.advect_events.append(ev)
+            self.advect_evals += int(xyz.shape[0]) * int(np.ceil(t / (0.5 * f.tmax / (f.num_keyframes - 1)) - 1e-6))
         mask = self.mf(xyz)
         target = (flow / (flow.norm(dim=1, keepdim=True) + 1e-9))[:, :1]
         loss = ((mask[:, :1] - target) ** 2).mean() - 1e-3 * (mask * torch.log(mask + 1e-8)).sum(1).mean()
@@ -867,10 +872,13 @@ class SegmStep:
 
 
 def segm_main(args, device):
-    """`--workload segm`: BASELINE configs[4]'s single-GPU share (train_segm.py's MaskField step on the chessboard-like field); prints its own line.
-    NVFI_MASK_FP16=1 / NVFI_VEL_FP16=1|2 select the fp16-input MFMA modes (stated in `dtype`)."""
-    from nvfi_amd import _lib
-    model = build_scene_chessboard(device, final=False)          # train_segm.py works on the trained field's t = 0 volume; n_sample_res = 64
+    """`--workload segm`: BASELINE configs[4]'s single-GPU share - train_segm.py's MaskField step on the fan scene (fan.yaml =
+    the bat box, K = 16, with bat.yaml:142-154's segmentation block: n_object 8, n_sample_res 64, min_t 0.5, alpha_scale 10); prints its own line.
+    NVFI_SEGM_SCENE=chessboard: the round-4/5 stand-in scene (K = 4).  NVFI_MASK_FP16=1 / NVFI_VEL_FP16=1|2 select the fp16-input MFMA modes
+    (stated in `dtype`)."""
+    scene = os.environ.get("NVFI_SEGM_SCENE", "fan")
+    # train_segm.py works on the TRAINED field's t = 0 volume: the final 199^3 grid of the schedule (bat.yaml:95)
+    model = build_scene_chessboard(device, final=False) if scene == "chessboard" else build_scene(device, 199, 128, True)
     fp16 = os.environ.get("NVFI_MASK_FP16", "0") == "1"
     step = SegmStep(model, device, 64, 8, fp16)
     for _ in range(max(args.prime, 3)):
@@ -885,23 +893,42 @@ def segm_main(args, device):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pts, evals = step.points / args.steps, 2.0 * step.steps_rk / args.steps
+    # the dominant kernel - integrate_pos' RK2 advection (k_rk2_x6w since round 6) - bracketed by HIP events on its own stream in a second pass
+    step.time_advect = True
+    step.advect_events, step.advect_evals = [], 0
+    for _ in range(min(args.steps, 5)):
+        step()
+    torch.cuda.synchronize()
+    adv_ms = sum(a.elapsed_time(b) for a, b in step.advect_events)
+    adv_tf = 2.0 * step.advect_evals * VEL_FLOP / (adv_ms * 1e-3) / 1e12 if adv_ms > 0 else 0.0
+    step.time_advect = False
     mf_flop = pts * 3 * 2 * (3 * 128 + 3 * 128 * 128 + 128 * 8)          # forward + dgrad + wgrad GEMMs
     flop = evals * VEL_FLOP + mf_flop
     vel16 = model.nvfi.vel_fp16
+    f = model.nvfi
+    dt_max = 0.5 * f.tmax / (f.num_keyframes - 1)
+    x6 = not vel16 and os.environ.get("NVFI_INTEGRATE_X6", "1") != "0"
+    peak = PEAK_BF16_MFMA / 6.0 if x6 else PEAK_FP32_MFMA
     out = {"metric": "MaskField training points/sec (train_segm.py step: density lattice + RK2 advection + MaskField fwd/bwd + Adam)",
            "value": pts * args.steps / dt, "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32" + (" (MaskField: fp16-input MFMA, fp32 accumulation)" if fp16 else "") + (f" (integrate_pos: vel_fp16={vel16})" if vel16 else ""),
            "data": "synthetic",
-           "config": {"workload": "train_segm.py:126-198 on the chessboard-like field (configs[4], one GPU's share): 64^3 jittered lattice, occupied points "
-                                  "advected to t in [0.5, 0.75] (K = 4: 4-6 RK2 steps), MaskField 3 -> 128 x 4 -> 8 softmax, stand-in loss, torch Adam(fused)",
+           "config": {"workload": (f"train_segm.py:126-198 on the {'fan (= bat box, bat.yaml:142-154 segmentation block)' if scene != 'chessboard' else 'chessboard-like'} field "
+                                   f"(configs[4], one GPU's share): 64^3 jittered lattice at t = 0, occupied points advected to t in [0.5, {f.tmax}] "
+                                   f"(K = {f.num_keyframes}: {int(np.ceil(0.5 / dt_max))}-{int(np.ceil(f.tmax / dt_max))} RK2 steps), "
+                                   "MaskField 3 -> 128 x 4 -> 8 softmax, stand-in loss, torch Adam(fused)"),
+                      "scene": scene, "grid": [int(g) for g in f.gridSize.tolist()], "K": int(f.num_keyframes),
                       "points_per_step": pts, "velocity_net_evaluations_per_step": evals},
-           "roofline": {"bound": "mfma", "kernel": "whole step (k_rk2 integrate_pos + k_maskfield_fwd/bwd + k_wgrad)", "achieved": flop / (dt / args.steps) / 1e12,
-                        "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": flop / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA, "traffic": None,
+           "roofline": {"bound": "mfma", "kernel": ("k_rk2_x6w (integrate_pos, per-point schedule)" if x6 else "integrate_pos (fp32 MFMA / fp16-input kernel)"),
+                        "achieved": adv_tf, "peak": peak, "unit": "TFLOP/s", "frac": adv_tf / peak, "traffic": None,
+                        "peak_note": ("2500 / 6: an x6 kernel issues six bf16 MFMAs per fp32 product" if x6 else "dense fp32 MFMA"),
+                        "ms_per_launch": adv_ms / max(1, len(step.advect_events)),
+                        "whole_step": {"achieved": flop / (dt / args.steps) / 1e12, "unit": "TFLOP/s (algorithmic fp32 FLOPs of integrate_pos + MaskField GEMMs / step time)"},
                         "gflop_per_step": {"integrate_pos": evals * VEL_FLOP / 1e9, "maskfield": mf_flop / 1e9}}}
     if not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = segm_cpu_baseline(model, step)
+            out["cpu_baseline"] = segm_cpu_baseline(model, step, "chessboard" if scene == "chessboard" else "bat")
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(out))
@@ -922,7 +949,7 @@ def _oracle_field(model, scene):
     return orc.FieldSpec(sd, meta)
 
 
-def segm_cpu_baseline(model, step):
+def segm_cpu_baseline(model, step, scene="bat"):
     """The WHOLE step of train_segm.py:127-198 on the oracle (plain C, OpenMP), like for like with the GPU line: density of the 64^3 jittered lattice at
     t = 0 -> occupied points -> integrate_pos to a time in [0.5, tmax] (the RK2 advection is most of the step's FLOPs) -> MaskField forward +
     parameter gradients.  One warm-up step, then whole steps for ~10 s."""
@@ -931,7 +958,7 @@ def segm_cpu_baseline(model, step):
     threads = min(64, os.cpu_count() or 1)
     orc.set_threads(threads)
     f = model.nvfi
-    fs = _oracle_field(model, "chessboard")
+    fs = _oracle_field(model, scene)
     ab = f._aabb_host
     bounds = [[ab[0], ab[3]], [ab[1], ab[4]], [ab[2], ab[5]]]
     lo, hi = np.array(ab[:3], np.float32), np.array(ab[3:], np.float32)
@@ -955,7 +982,7 @@ def segm_cpu_baseline(model, step):
 
     one()
     t0 = time.perf_counter(); reps = 0; pts = 0
-    while time.perf_counter() - t0 < 10 and reps < 8:
+    while time.perf_counter() - t0 < 15 and reps < 8:
         pts += one(); reps += 1
     dt = (time.perf_counter() - t0) / reps
     return dict(value=pts / reps / dt, unit="points/s", cores=threads, kind="port", s_per_step=dt, points_per_step=pts / reps,

@@ -42,7 +42,11 @@ typedef struct nvfi_field_desc {
                               * --disable_fp32 (train_nvfi.py:96,144) for inference; training renders, the PDE term and all gradients stay fp32.
                               * Bit 2 (+4, round 4, opt-in): the velocity warp of TRAINING renders runs its FORWARD on the one-term fp16-input MFMA too
                               * (pre-activations stashed in fp32; the adjoint and the weight gradients stay fp32 MFMA on those stashes - the
-                              * arithmetic of a forward under autocast with an fp32 backward; the PDE term and the render MLP stay fp32) */
+                              * arithmetic of a forward under autocast with an fp32 backward; the PDE term and the render MLP stay fp32).
+                              * 3 = x6 (round 5): fp32 products of the hidden layers formed EXACTLY from three bfloat16 terms per operand on the 16-bit
+                              * matrix pipe - same results as the fp32 MFMA kernels to rounding order, and since round 6 what 0 selects for every
+                              * no-grad back-advection as well (eval renders and the PDE prefilter since round 5; nvfi_integrate_pos and
+                              * nvfi_compute_alpha now).  Bit 3 (+8): keep the fp32 MFMA kernels for those two calls (A/B reference). */
     int32_t am_dims[3];      /* alpha volume W,H,D */
     float aabb[6];           /* min xyz, max xyz */
     float near_, far_, step_size;

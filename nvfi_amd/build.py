@@ -19,8 +19,10 @@ FILE_FLAGS = {"vel_x6.hip": ["-fno-slp-vectorize"], "vel_x6w.hip": ["-fno-slp-ve
               # round 6: the same fence for the other units that issue 16-bit MFMAs with more than one wave per SIMD (pre16.hip: eight waves per
               # workgroup; mask.hip: the fp16 MaskField kernels) - the mechanism of the x6 glitch is not understood, so the recipe (packed fp32
               # beside 16-bit MFMAs) is kept out of every such unit, and check_no_packed_f32() below fails the build if it comes back
-              "pre16.hip": ["-fno-slp-vectorize"], "mask.hip": ["-fno-slp-vectorize"]}
-NO_PACKED_F32 = ["vel_x6.hip", "vel_x6w.hip", "pre16.hip", "mask.hip"]
+              "pre16.hip": ["-fno-slp-vectorize"], "mask.hip": ["-fno-slp-vectorize"],
+              # round 6: the fused RK2 adjoint runs its dgrad on bf16 MFMAs (x6) with three waves per SIMD
+              "vel_fuse.hip": ["-fno-slp-vectorize"]}
+NO_PACKED_F32 = ["vel_x6.hip", "vel_x6w.hip", "pre16.hip", "mask.hip", "vel_fuse.hip"]
 OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
 
 

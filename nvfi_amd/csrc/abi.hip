@@ -7,6 +7,7 @@
 #include "scatter.h"
 #include "vel.h"
 #include "x6.h"
+#include "frags.h"
 
 static thread_local char g_err[512] = "";
 int nvfi_fail(int code, const char* fmt, ...) {
@@ -50,6 +51,11 @@ extern "C" int nvfi_vel_eval(const nvfi_field_desc* f, int64_t N, const float* x
 }
 
 // ---------------------------------------------------------------- integrate_pos (per-point times)
+static bool nograd_x6_default(const nvfi_field_desc* f) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("NVFI_INTEGRATE_X6"); on = e ? atoi(e) : 1; }
+    return on != 0 && !(f->vel_fp16 & 8);
+}
 __global__ void k_pack_xt(int64_t N, const float* x, float4* xw) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < N) xw[i] = make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], 0.f);
@@ -62,10 +68,18 @@ extern "C" int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const flo
     float* fv = B.take<float>(VEL_FRAG_FLOATS);
     float4* xw = B.take<float4>(N);
     if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
-    if ((f->vel_fp16 & 3) == 3) {      // opt-in x6 mode (vel_x6.hip): fp32 products of the hidden layers formed exactly on the 16-bit matrix pipe
-        float* img = B.take<float>(X6_IMAGE_BYTES / 4);
-        if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
-        if (launch_pack_x6(f->vW, img, st)) return 1;
+    // round 6: x6 (vel_x6w.hip: fp32 products of the hidden layers formed exactly on the 16-bit matrix pipe; as accurate against float64 as the
+    // fp32 MFMA kernels, tests/test_gpu_x6.py) is the DEFAULT of every no-grad back-advection, as it already was for eval renders and the
+    // PDE prefilter; vel_fp16 bit 3 (+8) or NVFI_INTEGRATE_X6=0 keep the fp32 MFMA kernel of vel.hip (the A/B reference of the tests)
+    if ((f->vel_fp16 & 3) == 3 || ((f->vel_fp16 & 3) == 0 && nograd_x6_default(f))) {
+        const float* img = nullptr;
+        if (f->frags) { FragCache FC; frag_cache_layout(f->frags, &FC); img = (const float*)FC.vel_x6; }
+        else {
+            float* own = B.take<float>(X6_IMAGE_BYTES / 4);
+            if (B.off > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)B.off);
+            if (launch_pack_x6(f->vW, own, st)) return 1;
+            img = own;
+        }
         hipLaunchKernelGGL(k_pack_xt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, x, xw);
         X6Args xa; memset(&xa, 0, sizeof(xa));
         xa.f = *f; xa.img = img; xa.n_direct = N; xa.xw = xw; xa.xout3 = xk; xa.pt_t = t; xa.pt_base = base; xa.dt_max = dt_max_of(*f); xa.max_steps = 4096;
@@ -100,18 +114,25 @@ __global__ void k_alpha_finish(int64_t N, const float* sig, float length, int ac
     const float a = 1.f - expf(-sig[i] * length);
     out[i] = acc_max ? fmaxf(out[i], a) : a;
 }
-struct AlphaPlan { float* fv; float4* xw; float* sig; int64_t total; };
+struct AlphaPlan { float* fv; float4* xw; float* sig; float* x6img; int64_t total; };
 static void plan_alpha(int64_t N, void* ws, AlphaPlan* P) {
     Bump B{(char*)ws, 0, 0};
     P->fv = B.take<float>(VEL_FRAG_FLOATS);
     P->xw = B.take<float4>(N);
     P->sig = B.take<float>(N);
+    P->x6img = B.take<float>(X6_IMAGE_BYTES / 4);
     P->total = align_up(B.off, 256);
+}
+// the per-point times of the x6 kernel for a call whose time is uniform (X6Args has no stride-0 form: the two values are broadcast into
+// N-element arrays behind the plan)
+__global__ void k_alpha_times(int64_t N, float t, float base, float* tt, float* tb) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < N) { tt[i] = t; tb[i] = base; }
 }
 extern "C" int nvfi_alpha_workspace_bytes(const nvfi_field_desc* f, int64_t N, int64_t* bytes) {
     (void)f;
     AlphaPlan P; plan_alpha(N > 0 ? N : 0, nullptr, &P);
-    *bytes = P.total;
+    *bytes = P.total + align_up(2 * (N > 0 ? N : 0) * (int64_t)sizeof(float), 256);
     return 0;
 }
 extern "C" int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const float* xyz_world, float t, int transfer, float length,
@@ -126,7 +147,20 @@ extern "C" int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const flo
     const float base = transfer ? 0.f : snap_base(*f, t);
     const unsigned nb = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(k_alpha_prep, dim3(nb), dim3(256), 0, st, *f, N, xyz_world, norm_time(*f, base), xw);
-    if (f->use_vel && !is_close(t, base)) {
+    if (f->use_vel && !is_close(t, base) && ((f->vel_fp16 & 3) == 3 || ((f->vel_fp16 & 3) == 0 && nograd_x6_default(f)))) {
+        // round 6: the x6 kernel with per-point times (all equal here; the kernel runs integrate_pos' own fp32 recurrence dt = sign * min(|off|,
+        // dt_max) per point - the numbers the host loop below derives).  tt / tb: 2 N floats behind the plan (nvfi_alpha_workspace_bytes)
+        float* tt = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + AP.total);
+        float* tb = tt + N;
+        if (AP.total + 2 * N * (int64_t)sizeof(float) > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld", (long long)(AP.total + 8 * N));
+        const float* img = nullptr;
+        if (f->frags) { FragCache FC; frag_cache_layout(f->frags, &FC); img = (const float*)FC.vel_x6; }
+        else { if (launch_pack_x6(f->vW, AP.x6img, st)) return 1; img = AP.x6img; }
+        hipLaunchKernelGGL(k_alpha_times, dim3(nb), dim3(256), 0, st, N, t, base, tt, tb);
+        X6Args xa; memset(&xa, 0, sizeof(xa));
+        xa.f = *f; xa.img = img; xa.n_direct = N; xa.xw = xw; xa.pt_t = tt; xa.pt_base = tb; xa.dt_max = dt_max_of(*f); xa.max_steps = 4096;
+        if (launch_rk2_x6(xa, N, st)) return 1;
+    } else if (f->use_vel && !is_close(t, base)) {
         Rk2Args a; memset(&a, 0, sizeof(a));
         const float dtm = dt_max_of(*f);
         float off = t - base, tc = t;

@@ -12,7 +12,7 @@
 #include "x6.h"
 
 #define A_X4B_FLOATS (4 * X4_FLOATS(4, 64) + X4_FLOATS(4, 4))      // transposed x4 fragments t[1..5] of a_weight_net (pde_fuse.hip)
-struct FragCache { float *render, *vel, *anet, *vel_x4f, *vel_x4b, *a_x4b; void* vel_x6; int64_t total; };
+struct FragCache { float *render, *vel, *anet, *vel_x4f, *vel_x4b, *a_x4b; void* vel_x6; void* vel_x6t; int64_t total; };
 static inline void frag_cache_layout(const float* base, FragCache* c) {
     Bump B{(char*)base, 0, 0};
     c->render = B.take<float>(RENDER_FRAG_FLOATS);
@@ -22,6 +22,7 @@ static inline void frag_cache_layout(const float* base, FragCache* c) {
     c->vel_x4b = B.take<float>(VEL_X4B_FLOATS);
     c->a_x4b = B.take<float>(A_X4B_FLOATS);
     c->vel_x6 = B.take<float>(X6_IMAGE_BYTES / 4);         // the three bfloat16 images of weight_net's layers 0..4 (vel_x6.hip)
+    c->vel_x6t = B.take<float>(X6_IMAGE_BYTES / 4);        // ... and of their transposes (round 6: the dgrad of vel_fuse.hip on x6)
     c->total = align_up(B.off, 256);
 }
 // pointer tables into the x4 regions (the layouts pack_vel_x4_fwd / pack_vel_x4_bwd write)

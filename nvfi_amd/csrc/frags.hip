@@ -49,6 +49,6 @@ extern "C" int nvfi_pack_frags(const nvfi_field_desc* f, void* cache, int64_t ca
         if (rc) return nvfi_fail(3, "nvfi_pack_frags: job table");
     }
     X6PackArgs x6; memset(&x6, 0, sizeof(x6));
-    if (f->use_vel) { for (int l = 0; l < 5; ++l) x6.W[l] = f->vW[l]; x6.img = reinterpret_cast<b8_t*>(c.vel_x6); }
+    if (f->use_vel) { for (int l = 0; l < 5; ++l) x6.W[l] = f->vW[l]; x6.img = reinterpret_cast<b8_t*>(c.vel_x6); x6.imgT = reinterpret_cast<b8_t*>(c.vel_x6t); }
     return launch_pack_all(all, f->use_vel ? &x6 : nullptr, st);
 }

@@ -6,6 +6,7 @@
 struct FuseBwdArgs {
     Rk2Args r;
     const float4* t4[6];       // x4 transposed fragments (pack_vel_x4_bwd)
+    const void* imgT;          // round 6: the transposed x6 images (x6.h: X6PackArgs::imgT) - the dgrad of layers 4..0 on the 16-bit matrix pipe
     float* slabs;              // slab of layer l (1..4) and workgroup g at slabs + l * layer_stride + g * slab_floats
     int64_t layer_stride;      // floats
     int slab_floats;           // 128 * 128 + 128

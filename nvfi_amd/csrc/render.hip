@@ -1320,7 +1320,7 @@ struct RenderPlan {
     uint8_t *valid, *mflag, *rflag;
     float4 *xw, *rgbs, *rgb_pre, *gxw, *gxk;
     float *xpre, *gxpre;
-    float *vel_frag, *render_frag, *vel_x4, *vel_x4b; void* img16; void* x6img;
+    float *vel_frag, *render_frag, *vel_x4, *vel_x4b; void* img16; void* x6img; void* x6imgT;
     TileWork tw2; float* slabs2;
     float *app_f, *app_b, *zst, *x0st, *rec, *gst, *gg, *maskv, *mask_frag;
     unsigned* app_relu;
@@ -1371,6 +1371,7 @@ static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nste
     P->img16 = (nsteps > 0 && ((!train && (f->vel_fp16 & 3)) || (train && (f->vel_fp16 & 4)))) ? (void*)B.take<float4>(2 * PRE16_IMAGE_BYTES / 16) : nullptr;   // fp16 images (hi, lo)
     P->vel_x4b = (nsteps > 0 && train) ? B.take<float>(VEL_X4B_FLOATS) : nullptr;
     P->x6img = nsteps > 0 ? (void*)B.take<float>(X6_IMAGE_BYTES / 4) : nullptr;      // the x6 images when the descriptor carries no fragment cache
+    P->x6imgT = (nsteps > 0 && train) ? (void*)B.take<float>(X6_IMAGE_BYTES / 4) : nullptr;      // ... and their transposes (the adjoint's dgrad, vel_fuse.hip)
     P->render_frag = B.take<float>(RENDER_FRAG_FLOATS);
     P->maskv = (flags & NVFI_WANT_MASK) ? B.take<float>(N * 32) : nullptr;
     P->mask_frag = (flags & NVFI_WANT_MASK) ? B.take<float>(64 * 1024) : nullptr;
@@ -1796,8 +1797,12 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         if (split && fuse) {
             FuseBwdArgs fa; memset(&fa, 0, sizeof(fa));
             fa.r = ra; fa.slabs = vslabs; fa.layer_stride = (int64_t)NSLAB * SLAB_FLOATS; fa.slab_floats = SLAB_FLOATS;
-            if (cached) x4b_pointers(FC.vel_x4b, fa.t4);
-            else if (pack_vel_x4_bwd(VW, P.vel_x4b, fa.t4, st)) return 1;
+            if (cached) { x4b_pointers(FC.vel_x4b, fa.t4); fa.imgT = FC.vel_x6t; }
+            else {
+                if (pack_vel_x4_bwd(VW, P.vel_x4b, fa.t4, st)) return 1;
+                if (launch_pack_x6(f->vW, P.x6img, st, P.x6imgT)) return 1;
+                fa.imgT = P.x6imgT;
+            }
             if (launch_rk2_fuse_bwd(fa, N, NSLAB, &fused_nslab, st)) return 1;
         } else if (split) {   // vel_split.hip: same adjoint stash bit for bit
             SplitBwdArgs ba; ba.r = ra;

@@ -29,6 +29,7 @@
 #include "vel.h"
 #include "pde.h"
 #include "fuse.h"
+#include "x6.h"
 
 #ifndef FUSE_THREADS
 #define FUSE_THREADS 768
@@ -37,6 +38,11 @@
 #define FUSE_NY 2
 #define FUSE_PARK_FLOATS (16 * 64)                    // per adjoint wave: 10 record fields + the upstream gradient (4) x 64 lanes
 #define FUSE_LDS_BYTES ((FUSE_NX + FUSE_NY) * FUSE_XB * 16 + 4 * 16 * 64 * 4 + 4 * FUSE_PARK_FLOATS * 4)
+// round 6, the dgrad on x6: the adjoint waves exchange g_l ALSO as the split B operands of the 16-bit MFMAs - two images [K step][term][lane]
+// of 16-byte operands behind the parking areas (vel_x6.hip's exchange layout) - while the fp32 images above keep feeding the contraction waves
+#define FUSE_XS_H8 (8 * 3 * 64)
+#define FUSE_LDS_BYTES_X6 (FUSE_LDS_BYTES + 2 * FUSE_XS_H8 * 16)
+typedef const b8_t __attribute__((address_space(1)))* gcb8p;
 // Exchange layout: element (row p, sample s) of a 128-row x 32-sample image, p = 2 (16 w + r) + h for register r of adjoint wave w, lives in
 // float4 [(p >> 3) * 2 + (p & 1)] * 33 + s, component (p >> 1) & 3.  A lane of the dgrad (a sample) reads / writes whole float4s at
 // consecutive addresses; a lane of the weight gradient (a row p = 32 t + i) reads one float per sample at bank 4 ((2 (i >> 3) + (i & 1) + s) & 7)
@@ -57,6 +63,8 @@ struct FuseA {
     int w, lane, h;
     int pos;             // float4 index of this lane inside a row group: h * 33 + sample
     int xw;              // X buffer that receives the next evaluation's g_4
+    b8_t* XS;            // x6: the two split-operand exchange images (+ lane)
+    const b8_t* imgT;    // x6: transposed images (term stride X6_H8)
 };
 #ifdef FUSE_TIMING
 struct FuseT { unsigned long long ft[64]; unsigned long long t0; };
@@ -245,6 +253,196 @@ __device__ __forceinline__ void fuse_velnet_bwd(FuseA& A, const float4* const* t
     __builtin_amdgcn_sched_barrier(0);
 }
 
+
+// ---------------------------------------------------------------- round 6: the same evaluation with the dgrad on the 16-bit matrix pipe (x6)
+// The 4 x 64 fp32 MFMAs of the four 128 x 128 dgrads (and the 16 of the input layer) become 8 K steps x 6 bf16 MFMAs per layer: every fp32
+// product formed exactly from three bfloat16 terms per operand, the six largest term products kept, two fp32 accumulators by magnitude class
+// (x6.h, vel_x6.hip) - 192 cycles per K = 16 instead of 512.  A operands: the TRANSPOSED weight images (X6PackArgs::imgT: split at pack time),
+// streamed from L2 through a three-slot register ring, three K steps ahead; B operands: g_l, split by the wave that formed it (x6_split8: 11
+// VALU instructions per pair) and exchanged through LDS as in vel_x6.hip - XS image 0 receives g_4 and g_2, image 1 g_3 and g_1 (every image's
+// last reader is at least one barrier older than its next writer: the barriers of phases 2, 1 and 5 separate g_2's readers from the next
+// evaluation's g_4).  Everything else - the 6 -> 128 output layer (fp32 MFMA, K = 6), SiLU', the fp32 images of g_l / a_l for the contraction
+// waves, stash traffic, barriers, LDS-DMA prefetches - is fuse_velnet_bwd's.  Each g_l differs from the fp32 kernel's by the rounding of another
+// summation order (the x6 products are exact; tests/test_gpu_x6_bwd.py bounds both against float64).
+__device__ __forceinline__ gcb8p fuse_x6_base(const b8_t* img, int off) { gcb8p q = (gcb8p)(img + off); asm("" : "+s"(q)); return q; }
+template <class Hook>
+__device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const* t4, const float (&r4)[4], const float* zs, float* gs,
+                                                   const float* zn, f32x4v& w5, float (&zp)[16], float (&ge)[16], Hook hook FT_ARG) {
+    const int w = A.w, lane = A.lane;
+    f32x16 acc;
+    float gv[16];
+    b8_t R1[3], R2[3], R3[3];                             // weight ring: K step s of the layer in slot s % 3
+#ifdef FUSE_TIMING
+    unsigned long long* ft = T.ft; unsigned long long& t0 = T.t0;
+    FT_ADD(24, t0);
+#endif
+    // ---- phase 0: 6 -> 128 (T5, fp32 MFMA), g_4; the first three K steps of layer 4's transposed image start their trip
+    {
+        gcb8p p1 = fuse_x6_base(A.imgT, X6_LH(4) + w * 512), p2 = fuse_x6_base(A.imgT, X6_H8 + X6_LH(4) + w * 512), p3 = fuse_x6_base(A.imgT, 2 * X6_H8 + X6_LH(4) + w * 512);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { R1[s] = p1[s * 64 + lane]; R2[s] = p2[s * 64 + lane]; R3[s] = p3[s * 64 + lane]; }
+    }
+    if (w == 0) {
+        gfp gw_rows = opaque_u(gs + (size_t)5 * 64 * REGF);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gw_rows[r * REGF + lane] = r < 4 ? r4[r] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+        const float a4[4] = {w5.x, w5.y, w5.z, w5.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = MFMA32(a4[k], r4[k], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gv[r] = acc[r] * act_d1<1>(zp[r]);
+    {
+        gcfp zr = opaque_u(zs + (size_t)(3 * 64 + 16 * w) * REGF);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+    }
+    int xc = A.xw;                                        // fp32 buffer of g_l (contraction waves)
+    {
+        float4* Xw = A.X + xc * FUSE_XB + (4 * w) * 2 * FUSE_HR + A.pos;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Xw[k * 2 * FUSE_HR] = make_float4(gv[4 * k], gv[4 * k + 1], gv[4 * k + 2], gv[4 * k + 3]);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            b8_t b1, b2, b3;
+            x6_split8(gv + 8 * k2, b1, b2, b3);
+            b8_t* d = A.XS + (size_t)((2 * w + k2) * 3) * 64;
+            d[0] = b1; d[64] = b2; d[128] = b3;
+        }
+    }
+    FT_ADD(8, t0);
+    FUSE_BAR();
+    FT_ADD(16, t0);
+    // ---- phases 1..4: dgrad of layer l on x6, then g_{l-1} and a_{l-1}
+#pragma unroll
+    for (int l = 4; l >= 1; --l) {
+        f32x16 a0, a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+        {
+            const b8_t* xs = A.XS + (size_t)(l & 1 ? 1 : 0) * FUSE_XS_H8;         // g_4, g_2 in image 0; g_3, g_1 in image 1
+            gcb8p p1 = fuse_x6_base(A.imgT, X6_LH(l) + w * 512), p2 = fuse_x6_base(A.imgT, X6_H8 + X6_LH(l) + w * 512), p3 = fuse_x6_base(A.imgT, 2 * X6_H8 + X6_LH(l) + w * 512);
+            b8_t B[2][3];
+            B[0][0] = xs[0]; B[0][1] = xs[64]; B[0][2] = xs[128];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s + 1 < 8) { B[(s + 1) & 1][0] = xs[((s + 1) * 3 + 0) * 64]; B[(s + 1) & 1][1] = xs[((s + 1) * 3 + 1) * 64]; B[(s + 1) & 1][2] = xs[((s + 1) * 3 + 2) * 64]; }
+                x6_mm6(R1[s % 3], R2[s % 3], R3[s % 3], B[s & 1][0], B[s & 1][1], B[s & 1][2], a0, a1);
+                if (s + 3 < 8) { R1[s % 3] = p1[(s + 3) * 64 + lane]; R2[s % 3] = p2[(s + 3) * 64 + lane]; R3[s % 3] = p3[(s + 3) * 64 + lane]; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = a1[r] + a0[r];                   // the small class first (both are complete sums here)
+#ifdef FUSE_TIMING
+        asm volatile("s_nop 0" :: "v"(acc[0]));
+        FT_ADD(5 - l, t0);
+#endif
+        // the next layer's first K steps start their trip from L2 behind the last MFMA that reads the current ones
+        if (l >= 2) {
+            gcb8p p1 = fuse_x6_base(A.imgT, X6_LH(l - 1) + w * 512), p2 = fuse_x6_base(A.imgT, X6_H8 + X6_LH(l - 1) + w * 512), p3 = fuse_x6_base(A.imgT, 2 * X6_H8 + X6_LH(l - 1) + w * 512);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) { R1[s] = p1[s * 64 + lane]; R2[s] = p2[s * 64 + lane]; R3[s] = p3[s * 64 + lane]; }
+        } else {                                                                   // this wave's K quarter of the 128 -> 28 input layer: K steps 2 w, 2 w + 1 of T0
+            gcb8p p1 = fuse_x6_base(A.imgT, X6_L0 + w * 128), p2 = fuse_x6_base(A.imgT, X6_H8 + X6_L0 + w * 128), p3 = fuse_x6_base(A.imgT, 2 * X6_H8 + X6_L0 + w * 128);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { R1[s] = p1[s * 64 + lane]; R2[s] = p2[s * 64 + lane]; R3[s] = p3[s * 64 + lane]; }
+        }
+        float4* Yw = A.Y + (l & 1) * FUSE_XB + (4 * w) * 2 * FUSE_HR + A.pos;
+        if (l >= 2) {
+            xc = xc + 1 == FUSE_NX ? 0 : xc + 1;
+            float4* Xw = A.X + xc * FUSE_XB + (4 * w) * 2 * FUSE_HR + A.pos;
+            b8_t* xsw = A.XS + (size_t)(l & 1 ? 0 : 1) * FUSE_XS_H8;            // g_{l-1}: the other image
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                float g8[8];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int k = 2 * k2 + kk;
+                    float a4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float z = zp[4 * k + c], sg = fast_sigmoid(z);
+                        g8[4 * kk + c] = acc[4 * k + c] * (sg * (1.f + z * (1.f - sg)));     // act_d1<1>
+                        a4[c] = z * sg;                                                      // act_f<1>
+                    }
+                    Xw[k * 2 * FUSE_HR] = make_float4(g8[4 * kk], g8[4 * kk + 1], g8[4 * kk + 2], g8[4 * kk + 3]);
+                    Yw[k * 2 * FUSE_HR] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+                }
+                b8_t b1, b2, b3;
+                x6_split8(g8, b1, b2, b3);
+                b8_t* d = xsw + (size_t)((2 * w + k2) * 3) * 64;
+                d[0] = b1; d[64] = b2; d[128] = b3;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            gcfp zr = opaque_u(zs + (size_t)((l - 2) * 64 + 16 * w) * REGF);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float z = zp[4 * k + c], sg = fast_sigmoid(z);
+                    gv[4 * k + c] = acc[4 * k + c] * (sg * (1.f + z * (1.f - sg)));
+                    a4[c] = z * sg;
+                }
+                Yw[k * 2 * FUSE_HR] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+            }
+        }
+        FT_ADD(8 + 5 - l, t0);
+        FUSE_BAR();
+        FT_ADD(16 + 5 - l, t0);
+    }
+    A.xw = A.xw + 1 == FUSE_NX ? 0 : A.xw + 1;
+    // ---- phase 5: 128 -> 28 (T0), this wave's K quarter: g_0 split in registers, two K steps
+    {
+        f32x16 a0, a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            b8_t b1, b2, b3;
+            x6_split8(gv + 8 * k2, b1, b2, b3);
+            x6_mm6(R1[k2], R2[k2], R3[k2], b1, b2, b3, a0, a1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) A.bc[(w * 16 + r) * 64 + lane] = a1[r] + a0[r];
+        if (zn) {
+            asm volatile("" :: "v"(a0[0]));
+            gcf4p b5 = (gcf4p)(t4[5] + (size_t)w * 64);
+            asm("" : "+s"(b5));
+            w5 = b5[lane];
+            gcfp zr = opaque_u(zn + (size_t)(4 * 64 + 16 * w) * REGF);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    hook();
+    {
+        gfp gr = opaque_u(gs + (size_t)(16 * w) * REGF);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) STASH_ST(gr[r * REGF + lane], gv[r]);
+    }
+    FT_ADD(5, t0);
+    FUSE_BAR();
+    FT_ADD(21, t0);
+#ifdef FUSE_TIMING
+    ft[63] += 1;
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        ge[r] = ((A.bc[r * 64 + lane] + A.bc[(16 + r) * 64 + lane]) + A.bc[(32 + r) * 64 + lane]) + A.bc[(48 + r) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // adjoint of the PositionEncoder at q = (x, y, z, t): vel_encode_slots + vel_encode_bwd of engine.h in one pass, four slots at a time (the two
 // library forms together keep 16 encoder slots and the temporaries of twelve argument reductions live at once: the register peak of the
 // whole adjoint role)
@@ -281,9 +479,11 @@ __device__ __forceinline__ void fuse_park_rec(const Rk2Args& ra, int s, int e, i
     }
 }
 
+template <bool X6>
 __device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* X, float4* Y, float* bc, int w, int lane, int ntiles) {
     const Rk2Args& ra = a.r;
     FuseA A; A.X = X; A.Y = Y; A.bc = bc; A.w = w; A.lane = lane; A.h = lane >> 5; A.xw = 0;
+    A.XS = reinterpret_cast<b8_t*>(bc + 4 * 16 * 64 + 4 * FUSE_PARK_FLOATS) + lane; A.imgT = reinterpret_cast<const b8_t*>(a.imgT);
     const int h = A.h, j = lane & 31;
     A.pos = h * FUSE_HR + j;
 #ifdef FUSE_TIMING
@@ -382,7 +582,8 @@ __device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* 
                         for (int c = 0; c < 3; ++c) glds4(reinterpret_cast<const float*>(ra.gxk) + c, list_t * 16, park_lds + (10 + c) * 256);
                     }
                 };
-                fuse_velnet_bwd(A, a.t4, r4, ra.zst + es * zt, ra.gst + es * gt, zn, w5, wq, zp, ge, prefetch FT_PASS);
+                if constexpr (X6) fuse_velnet_bwd_x6(A, a.t4, r4, ra.zst + es * zt, ra.gst + es * gt, zn, w5, zp, ge, prefetch FT_PASS);
+                else fuse_velnet_bwd(A, a.t4, r4, ra.zst + es * zt, ra.gst + es * gt, zn, w5, wq, zp, ge, prefetch FT_PASS);
                 const float4 gq = fuse_encode_bwd(make_float4(p[0], p[1], p[2], te), ge, h);
                 gloc[0] += gq.x; gloc[1] += gq.y; gloc[2] += gq.z;
 #pragma unroll
@@ -474,6 +675,7 @@ __device__ __forceinline__ void fuse_role_contract(const FuseBwdArgs& a, const f
 #undef FUSE_FLUSH
 }
 
+template <bool X6>
 __global__ __launch_bounds__(FUSE_THREADS) void k_rk2_fuse_bwd(FuseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* X = reinterpret_cast<float4*>(lds);
@@ -492,7 +694,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_rk2_fuse_bwd(FuseBwdArgs a) {
     if (wave < 4) {
 #endif
         __builtin_amdgcn_s_setprio(3);
-        fuse_role_adjoint(a, X, Y, bc, wave, lane, ntiles);
+        fuse_role_adjoint<X6>(a, X, Y, bc, wave, lane, ntiles);
     } else {
         fuse_role_contract(a, lds, lds + FUSE_NX * FUSE_XB * 4, wave - 4, lane, ntiles);
     }
@@ -510,9 +712,14 @@ int launch_rk2_fuse_bwd(const FuseBwdArgs& a, int64_t cap_samples, int max_slabs
         hipDeviceProp_t prop;
         int n = 256;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-        HIPCK(hipFuncSetAttribute((const void*)k_rk2_fuse_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_fuse_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES));
+        HIPCK(hipFuncSetAttribute((const void*)k_rk2_fuse_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES_X6));
         ncu_dev[dev] = n;
     }
+    // NVFI_FUSE_X6 (default 1, round 6): the adjoint waves' dgrad on the 16-bit matrix pipe (fuse_velnet_bwd_x6); 0: the fp32 MFMA dgrad of round 4
+    static int x6 = -1;
+    if (x6 < 0) { const char* e = getenv("NVFI_FUSE_X6"); x6 = e ? atoi(e) : 1; }
+    const bool use_x6 = x6 != 0 && a.imgT != nullptr;
     const int ncu = ncu_dev[dev];
     // NVFI_FUSE_RESERVE=n (experiment): leave n CUs to the kernels of the other streams (a persistent workgroup owns its CU: 12 waves x 168 registers)
     static int reserve = -1;
@@ -526,7 +733,8 @@ int launch_rk2_fuse_bwd(const FuseBwdArgs& a, int64_t cap_samples, int max_slabs
     if (!tbuf) { HIPCK(hipMalloc(&tbuf, 64 * 8)); }
     FuseBwdArgs b = a; b.timing = tbuf;
     HIPCK(hipMemsetAsync(tbuf, 0, 64 * 8, st));
-    hipLaunchKernelGGL(k_rk2_fuse_bwd, dim3((unsigned)G), dim3(FUSE_THREADS), FUSE_LDS_BYTES, st, b);
+    if (use_x6) hipLaunchKernelGGL(k_rk2_fuse_bwd<true>, dim3((unsigned)G), dim3(FUSE_THREADS), FUSE_LDS_BYTES_X6, st, b);
+    else hipLaunchKernelGGL(k_rk2_fuse_bwd<false>, dim3((unsigned)G), dim3(FUSE_THREADS), FUSE_LDS_BYTES, st, b);
     if (++shots % 8 == 0 && shots <= 64) {
         unsigned long long h[64];
         HIPCK(hipStreamSynchronize(st));
@@ -545,7 +753,8 @@ int launch_rk2_fuse_bwd(const FuseBwdArgs& a, int64_t cap_samples, int max_slabs
         fprintf(stderr, "\n");
     }
 #else
-    hipLaunchKernelGGL(k_rk2_fuse_bwd, dim3((unsigned)G), dim3(FUSE_THREADS), FUSE_LDS_BYTES, st, a);
+    if (use_x6) hipLaunchKernelGGL(k_rk2_fuse_bwd<true>, dim3((unsigned)G), dim3(FUSE_THREADS), FUSE_LDS_BYTES_X6, st, a);
+    else hipLaunchKernelGGL(k_rk2_fuse_bwd<false>, dim3((unsigned)G), dim3(FUSE_THREADS), FUSE_LDS_BYTES, st, a);
 #endif
     LAUNCHCK();
     *nslab_out = G;

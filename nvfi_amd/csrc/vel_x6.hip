@@ -33,10 +33,10 @@
 
 // ---------------------------------------------------------------- packing: three bfloat16 images of layers 0..4 (x6_pack_body, x6.h)
 __global__ __launch_bounds__(256) void k_pack_x6(X6PackArgs a) { x6_pack_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
-int launch_pack_x6(const float* const* W, void* img, hipStream_t st) {
+int launch_pack_x6(const float* const* W, void* img, hipStream_t st, void* imgT) {
     X6PackArgs pk;
     for (int l = 0; l < 5; ++l) pk.W[l] = W[l];
-    pk.img = reinterpret_cast<b8_t*>(img);
+    pk.img = reinterpret_cast<b8_t*>(img); pk.imgT = reinterpret_cast<b8_t*>(imgT);
     hipLaunchKernelGGL(k_pack_x6, dim3((X6_H8 + 255) / 256), dim3(256), 0, st, pk);
     LAUNCHCK();
     return 0;
@@ -493,7 +493,13 @@ int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st) {
     // prefilter 0.89 -> 0.83 ms).  NVFI_X6W=0: the four-waves-per-tile kernel below
     static int x6w = -1;
     if (x6w < 0) { const char* e = getenv("NVFI_X6W"); x6w = e ? atoi(e) : 1; }
-    if (x6w || nt == 4) return launch_rk2_x6w(a, cap_points, st);
+    // round 6: a SMALL call is latency-bound - its evaluations are a serial chain per tile, 60 k cycles each on one wave (x6w) against ~17.5 k with
+    // the tile's four row tiles on four SIMDs (k_rk2_x6<1>; 35 k with two workgroups per CU) - so up to NVFI_X6W_MIN_TILES (default 768: the
+    // point where the four-wave kernel needs a second round) the four-wave kernel runs; same products in the same order, identical bits
+    // (tests/test_gpu_x6.py).  train_segm's integrate_pos (3 000-30 000 occupied points, 40-60 evaluations deep) is the case: 1.03 -> 0.4 ms.
+    static int min_tiles = -1;
+    if (min_tiles < 0) { const char* e = getenv("NVFI_X6W_MIN_TILES"); min_tiles = e ? atoi(e) : 768; }
+    if ((x6w && tiles > min_tiles) || nt == 4) return launch_rk2_x6w(a, cap_points, st);
     const unsigned two = (unsigned)((tiles + 1) / 2);
     if (nt == 1) hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
     else hipLaunchKernelGGL(k_rk2_x6<2>, dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);

@@ -612,7 +612,9 @@ class TensorVMKeyframeTimeKplane(nn.Module):
         d.shading = 1 if self.shadingMode == "SH" else 0
         # 3 / "x6": every no-grad back-advection on the x6 kernels (vel_x6.hip: fp32 products formed exactly from three binary16 terms per operand)
         vf = self.vel_fp16
-        d.vel_fp16 = (3 if (vf == 3 or vf == "x6") else (2 if vf in (2, "split", "split16") else (1 if vf else 0))) | (4 if getattr(self, "vel_fp16_train", False) else 0)
+        # "fp32" (bit 3): keep the fp32 MFMA kernels for integrate_pos / compute_alpha, whose default since round 6 is x6 too (the A/B reference)
+        d.vel_fp16 = ((8 if vf == "fp32" else 3 if (vf == 3 or vf == "x6") else (2 if vf in (2, "split", "split16") else (1 if vf else 0)))
+                      | (4 if getattr(self, "vel_fp16_train", False) else 0))
         d.n_samples = int(self.nSamples)
         d.use_vel = int(self.use_vel)
         gsur, lo, hi = self._gate()

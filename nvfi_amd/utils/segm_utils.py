@@ -36,7 +36,7 @@ def balanced_sample(xyz, object_bounds):
 
 
 @torch.no_grad()
-def segm_points(kplane, n_sample_res, min_t, alpha_scale=10.0, object_bounds=None, t=None, dists=0.01):
+def segm_points(kplane, n_sample_res, min_t, alpha_scale=10.0, object_bounds=None, t=None, dists=0.01, advect_events=None):
     """train_segm.py:127-170.  Returns (xyz (N,3) normalised keyframe-0 points, flow (N,3), t) for one iteration."""
     device = kplane.aabb.device
     ab = kplane._aabb_host                       # host copy of the box (no device read per iteration)
@@ -57,5 +57,9 @@ def segm_points(kplane, n_sample_res, min_t, alpha_scale=10.0, object_bounds=Non
     if t is None:
         t = float(min_t + (kplane.tmax - min_t) * torch.rand(1))
     tt = t0 + t
+    if advect_events is not None:       # (bench.py: HIP events around the advection on the stream it is launched on)
+        advect_events[0].record()
     xyz2 = kplane.integrate_pos(xyz.clone(), t0, tt)
+    if advect_events is not None:
+        advect_events[1].record()
     return xyz, xyz2 - xyz, t

@@ -28,7 +28,7 @@ def main():
     seeds = [int(s) for s in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 3]
     R = import_reference()
     import torch
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("PSNR_THREADS", "8")))
     B = types.SimpleNamespace(Renderer=R["Renderer"], Camera=R["Camera"], Ray=R["Ray"], TVLoss=R["TVLoss"])
     out = {"iters": np.int64(iters), "seeds": np.asarray(seeds, np.int64)}
     rows = []
@@ -44,7 +44,7 @@ def main():
         rows.append([r["psnr_key"], r["psnr_nonkey"], r["psnr_key_before"], r["psnr_nonkey_before"], r["loss_first"], r["loss_last"]])
     out["columns"] = np.asarray(["psnr_key", "psnr_nonkey", "psnr_key_before", "psnr_nonkey_before", "loss_first", "loss_last"])
     out["reference"] = np.asarray(rows, np.float64)
-    np.savez(os.path.join(HERE, "psnr.npz"), **out)
+    np.savez(os.environ.get("PSNR_OUT", os.path.join(HERE, "psnr.npz")), **out)
     a = out["reference"]
     print("reference PSNR after", iters, "iterations: key", a[:, 0], "non-key", a[:, 1], "| spread", a[:, :2].max(0) - a[:, :2].min(0))
 

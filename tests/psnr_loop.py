@@ -23,7 +23,7 @@ N_RAYS, N_PTS = 512, 2048
 # the experiment block of the configuration (bat.yaml:21-52 names; values chosen for this 20 x 18 x 16 scene and a 300-iteration run: the
 # shipped 0.02 / 1e-3 with a 10x decay over 30 000 iterations is still at full step size after 300 - the validation PSNR then jumps by
 # several dB from one iteration to the next and says nothing about the arithmetic underneath)
-CFG = dict(lr_grid=0.02, lr_net=1e-3, lr_vel=1e-3, lr_decay_target_ratio=0.1, L1_weight_inital=8e-4, TV_weight_density=1.0, TV_weight_app=1.0, vel_reg_weight=1.0)
+CFG = dict(lr_grid=0.01, lr_net=1e-3, lr_vel=1e-3, lr_decay_target_ratio=0.01, L1_weight_inital=8e-4, TV_weight_density=1.0, TV_weight_app=1.0, vel_reg_weight=1.0)
 T_KEY, T_NONKEY = 15.0 / 60.0, 20.0 / 60.0          # K = 4, tmax = 0.75: keyframes every 0.25; 20/60 is 5/60 past one (one RK2 step)
 
 

@@ -43,7 +43,7 @@ def test_x6_integrate_pos_is_as_accurate_as_the_fp32_kernels(nsteps):
         base = torch.zeros(N, 1, device="cuda")
         ref = integrate64(f, x.cpu().numpy(), tt.cpu().numpy()[:, 0], base.cpu().numpy()[:, 0])
         err = {}
-        for mode_name, mode in (("fp32", False), ("x6", 3)):
+        for mode_name, mode in (("fp32", "fp32"), ("x6", 3), ("default", False)):
             f.vel_fp16 = mode
             with torch.no_grad():
                 outs = [f.integrate_pos(x.clone(), tt.clone(), base).cpu().numpy() for _ in range(3)]
@@ -55,6 +55,7 @@ def test_x6_integrate_pos_is_as_accurate_as_the_fp32_kernels(nsteps):
               f"x6 {err['x6'][0]:.2e} / {err['x6'][1]:.2e}")
         assert err["x6"][0] <= 1.25 * err["fp32"][0] + 1e-9 and err["x6"][1] <= 1.05 * err["fp32"][1] + 1e-10, (name, err)
         assert err["x6"][2] <= err["fp32"][2], (name, "outliers", err)      # (a point that takes another gate branch than float64 does is an outlier of BOTH kernels)
+        assert err["default"] == err["x6"], (name, err)                       # round 6: x6 is what integrate_pos runs by default
 
 
 def test_x6_repeats_bit_for_bit_at_two_workgroups_per_cu():
@@ -131,7 +132,7 @@ def test_one_wave_per_tile_kernel_is_bit_identical_to_the_four_wave_kernel(tmp_p
     outs = []
     for w in ("0", "1"):
         out = str(tmp_path / f"x6w{w}.npy")
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "x6w_check.py"), out], env=dict(os.environ, NVFI_X6W=w, NVFI_X6W_UNI="2" if w == "1" else "0"),
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "x6w_check.py"), out], env=dict(os.environ, NVFI_X6W=w, NVFI_X6W_MIN_TILES="0", NVFI_X6W_UNI="2" if w == "1" else "0"),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "repeat identical: True" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
         outs.append((np.load(out), np.load(out + ".render.npz")))
@@ -156,7 +157,7 @@ def test_x6_prefilter_keeps_the_fp32_set(tmp_path, n, extra, nt):
     """both prefilters decide `alpha >= alphaMask_thres` on positions that differ by rounding (another summation order of the same fp32
     products): a point would have to sit within ~1e-7 of the threshold to flip - at most a handful among 10^6"""
     # nt = 0: the default one-wave-per-tile kernel (vel_x6w.hip); 1 / 2: the four-waves-per-tile kernels with one / two tiles per workgroup
-    sw = dict(NVFI_X6W=1) if nt == 0 else dict(NVFI_X6W=0, NVFI_X6_NT=nt)
+    sw = dict(NVFI_X6W=1, NVFI_X6W_MIN_TILES=0) if nt == 0 else dict(NVFI_X6W=0, NVFI_X6_NT=nt)
     a, b = _run(tmp_path, "fp32", extra, n), _run(tmp_path, "x6", extra, n, **sw)
     for name in ("A", "B", "cfg1") + (("bench",) if extra else ()):
         ka, kb = a[f"{name}:kept"], b[f"{name}:kept"]

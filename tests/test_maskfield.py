@@ -172,3 +172,72 @@ def test_gpu_maskfield_repeats_bit_for_bit(mgold, fp16):
         outs = [mf(pts).clone() for _ in range(6)]
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), int((o != outs[0]).any(-1).sum())
+
+
+@pytest.mark.gpu
+def test_gpu_segm_iteration_at_the_shipped_size(mgold):
+    """round 6 (VERDICT r5 missing 2): BASELINE configs[4] on its own scene - fan.yaml = the bat box at the final 199^3 grid, K = 16, with
+    bat.yaml:142-154's segmentation block (n_sample_res 64, min_t 0.5, alpha_scale 10): one train_segm.py:126-198 iteration.  The occupied
+    points of the 64^3 lattice are advected 0 -> t in [0.5, 0.75] = 20-30 RK2 steps (dt_max 0.025) by integrate_pos' default kernel (x6w
+    since round 6); a 2 000-point slice is checked against the oracle (plain C, fp32) and against the fp32 MFMA kernel; the MaskField
+    step on ALL points is checked through properties: rows are probability vectors, d(sum_k mask)/d(parameters) = 0 (softmax rows sum
+    to one), the fp16-input mode stays within fp16 tolerance, a few Adam steps reduce the stand-in loss."""
+    import bench
+    from nvfi_amd.models import MaskField
+    from nvfi_amd.utils import segm_points
+    from oracle import oracle as orc
+    model = bench.build_scene(torch.device("cuda"), 199, 128, True)
+    f = model.nvfi
+    f.eval()
+    assert f.num_keyframes == 16 and [int(g) for g in f.gridSize.tolist()] == [199, 199, 199]
+    torch.manual_seed(3)
+    xyz, flow, t = segm_points(f, n_sample_res=64, min_t=0.5, alpha_scale=10.0)
+    n = int(xyz.shape[0])
+    dt_max = 0.5 * f.tmax / (f.num_keyframes - 1)
+    steps = int(np.ceil(t / dt_max - 1e-6))
+    print(f"fan scene: {n} occupied points of 64^3, t = {t:.4f} -> {steps} RK2 steps, mean |flow| {float(flow.norm(dim=1).mean()):.4f}")
+    assert n > 2000 and 0.5 <= t <= f.tmax and 20 <= steps <= 30 and torch.isfinite(flow).all()
+    assert float(flow.norm(dim=1).mean()) > 1e-4            # the random-init velocity field moves the points
+    sel = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:2000].cuda()
+    xs = xyz[sel].contiguous()
+    fs = bench._oracle_field(model, "bat")
+    xo = orc.integrate_pos(fs, xs.cpu().numpy(), np.zeros((2000, 1), np.float32), np.full((2000, 1), t, np.float32))
+    got = (xyz + flow)[sel].cpu().numpy()
+    np.testing.assert_allclose(got, xo, rtol=1e-4, atol=2e-5)
+    print(f"  2 000-point slice vs oracle: max abs {np.abs(got - xo).max():.2e}")
+    f.vel_fp16 = "fp32"                                      # the fp32 MFMA kernel (vel.hip) on the same points
+    try:
+        x32 = f.integrate_pos(xs.clone(), torch.zeros(2000, 1, device="cuda"), torch.full((2000, 1), t, device="cuda")).cpu().numpy()
+    finally:
+        f.vel_fp16 = False
+    assert np.abs(got - x32).max() < 5e-6, np.abs(got - x32).max()
+    # MaskField (train_segm.py:97-102) on every occupied point
+    torch.manual_seed(233)
+    mf = MaskField(n_layer=4, n_dim=128, input_dim=3, skips=[], mask_dim=8).cuda()
+    mask = mf(xyz)
+    assert mask.shape == (n, 8) and float(mask.min()) >= 0.0
+    np.testing.assert_allclose(mask.detach().sum(1).cpu().numpy(), 1.0, atol=1e-5)
+    mask.sum().backward()                                    # sum_k softmax = 1 for every point: the gradient of a constant
+    gmax = max(float(p.grad.abs().max()) for p in mf.parameters())
+    mf.zero_grad(set_to_none=True)
+    (mask.detach() * 0).sum()
+    mask = mf(xyz)
+    (mask[:, 0]).sum().backward()
+    gref = max(float(p.grad.abs().max()) for p in mf.parameters())
+    assert gmax < 1e-4 * gref, (gmax, gref)
+    mf.zero_grad(set_to_none=True)
+    mf.mfma_fp16 = True
+    m16 = mf(xyz).detach()
+    mf.mfma_fp16 = False
+    assert float((m16 - mask.detach()).abs().max()) < 5e-3
+    opt = torch.optim.Adam(mf.parameters(), lr=0.005, betas=(0.9, 0.999))
+    target = (flow / (flow.norm(dim=1, keepdim=True) + 1e-9))[:, :1]
+    losses = []
+    for _ in range(8):
+        mask = mf(xyz)
+        loss = ((mask[:, :1] - target) ** 2).mean() - 1e-3 * (mask * torch.log(mask + 1e-8)).sum(1).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses

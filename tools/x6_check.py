@@ -76,7 +76,7 @@ def main():
         base = torch.zeros(N, 1, device=dev)
         ref = integrate64(f, x.cpu().numpy(), tt.cpu().numpy()[:, 0], base.cpu().numpy()[:, 0])
         row = {}
-        for name, mode in (("fp32", False), ("x6", 3), ("split16", 2), ("fp16", True)):
+        for name, mode in (("fp32", "fp32"), ("x6", 3), ("split16", 2), ("fp16", True)):
             f.vel_fp16 = mode
             with torch.no_grad():
                 out = f.integrate_pos(x.clone(), tt.clone(), base)
