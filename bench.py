@@ -1203,6 +1203,12 @@ def main():
     if psteps > 0:
         step.counters.clear(); step.pde_counters.clear()
         streams, step.streams = getattr(step, "streams", None), None     # serial: an event interval then brackets one kernel class only
+        # ... which also means no LIBRARY-side fork (the backward's side streams of the one-stream / drop-in modes: an interval on one stream would
+        # include the contention of the kernels on the other - round 5's `wgrad 0.31 ms x 4` in those lines)
+        _fld = getattr(getattr(step, "m", None), "nvfi", None)
+        _forks = (_fld.fork_backward, _fld.auto_overlap) if _fld is not None else None
+        if _fld is not None:
+            _fld.fork_backward, _fld.auto_overlap = False, False
         torch.cuda.synchronize()
         L.nvfi_prof_enable(1)
         step()                      # one unrecorded profiled step: the event pool is created here (~0.1 s of hipEventCreate in a fresh process)
@@ -1219,6 +1225,8 @@ def main():
         _lib.check(L.nvfi_prof_collect(tot, cnt))
         L.nvfi_prof_enable(0)
         step.streams = streams
+        if _fld is not None:
+            _fld.fork_backward, _fld.auto_overlap = _forks
         c = torch.stack(step.counters).sum(0).cpu().numpy() if step.counters else np.zeros(8)
         pc = torch.stack(step.pde_counters).sum(0).cpu().numpy() if step.pde_counters else np.zeros(8)
         V, Nw, M, E = float(c[0]), float(c[1]), float(c[2]), float(c[3])
@@ -1317,6 +1325,7 @@ def main():
                    "rays_per_step_per_gpu": n_rays * renders, "pde_points_per_gpu": n_pts if args.workload == "cfg3" else 0,
                    "grid": [int(g) for g in model.nvfi.gridSize.tolist()], "samples_per_ray": int(model.nvfi.nSamples), "parallelism": f"ray-sharded x{world}",
                    "driver": args.mode,
+                   "pde_kept_fraction": (work["P_kept"] / n_pts if (work and args.workload == "cfg3" and n_pts) else None),      # P' / P of the profiled steps
                    "launch": (("three hipGraph replays per iteration (draw + fragment repack | PDE term on its stream | both renders + regularisers) around the eager gradient "
                                "exchange and the one-launch Adam; frame times, loss weights, learning rates and jitter read from a device record uploaded per iteration")
                               if (use_graph and world > 1) else

@@ -38,10 +38,17 @@
 #define FUSE_NY 2
 #define FUSE_PARK_FLOATS (16 * 64)                    // per adjoint wave: 10 record fields + the upstream gradient (4) x 64 lanes
 #define FUSE_LDS_BYTES ((FUSE_NX + FUSE_NY) * FUSE_XB * 16 + 4 * 16 * 64 * 4 + 4 * FUSE_PARK_FLOATS * 4)
-// round 6, the dgrad on x6: the adjoint waves exchange g_l ALSO as the split B operands of the 16-bit MFMAs - two images [K step][term][lane]
-// of 16-byte operands behind the parking areas (vel_x6.hip's exchange layout) - while the fp32 images above keep feeding the contraction waves
+// round 6, the x6 variant (k_rk2_fuse_bwd<true>): BOTH roles on the 16-bit matrix pipe.  LDS holds six images of 24 KB - 16-byte MFMA operands
+// [tile / K step][term][lane] - and the parking areas:
+//   XS0 | XS1   the dgrad exchange: g_l split into three bfloat16 terms, [K step 0..7][term][lane] (vel_x6.hip's layout; g_4, g_2 in image 0,
+//               g_3, g_1 in image 1); the 16 KB exchange of the input layer's partial sums `bc` ALIASES XS1 (written in phase 5 - XS1's last
+//               readers left before the barrier of phase 1 - and read behind phase 5's barrier, one barrier ahead of XS1's next writer)
+//   GT0 | GT1   g_l TRANSPOSED (a lane = a feature row, its registers = samples): the A operands of the weight gradient, [row tile][K step 0..1][term][lane]
+//   AT0 | AT1   a_{l-1} = SiLU(z_{l-1}) transposed: its B operands, [column tile][K step][term][lane]
+// The transposition is done by the matrix pipe: with B = a 16 x 32 selection matrix, D = A B moves the 8 K values a lane holds of its sample
+// (the B-operand format the split produces) to the lanes of the 32 feature rows (exact: a bfloat16 term times 1.0 into an fp32 zero).
 #define FUSE_XS_H8 (8 * 3 * 64)
-#define FUSE_LDS_BYTES_X6 (FUSE_LDS_BYTES + 2 * FUSE_XS_H8 * 16)
+#define FUSE_LDS_BYTES_X6 (6 * FUSE_XS_H8 * 16 + 4 * FUSE_PARK_FLOATS * 4)
 typedef const b8_t __attribute__((address_space(1)))* gcb8p;
 // Exchange layout: element (row p, sample s) of a 128-row x 32-sample image, p = 2 (16 w + r) + h for register r of adjoint wave w, lives in
 // float4 [(p >> 3) * 2 + (p & 1)] * 33 + s, component (p >> 1) & 3.  A lane of the dgrad (a sample) reads / writes whole float4s at
@@ -63,8 +70,9 @@ struct FuseA {
     int w, lane, h;
     int pos;             // float4 index of this lane inside a row group: h * 33 + sample
     int xw;              // X buffer that receives the next evaluation's g_4
-    b8_t* XS;            // x6: the two split-operand exchange images (+ lane)
+    b8_t* XS;            // x6: the two split-operand exchange images (+ lane); GT at + 2 images, AT at + 4 images
     const b8_t* imgT;    // x6: transposed images (term stride X6_H8)
+    b8_t I0, I1;         // x6: the selection matrices of the transposing MFMAs (K step 0 / 1 of a row tile -> columns p' = 2 r + h)
 };
 #ifdef FUSE_TIMING
 struct FuseT { unsigned long long ft[64]; unsigned long long t0; };
@@ -254,17 +262,30 @@ __device__ __forceinline__ void fuse_velnet_bwd(FuseA& A, const float4* const* t
 }
 
 
-// ---------------------------------------------------------------- round 6: the same evaluation with the dgrad on the 16-bit matrix pipe (x6)
-// The 4 x 64 fp32 MFMAs of the four 128 x 128 dgrads (and the 16 of the input layer) become 8 K steps x 6 bf16 MFMAs per layer: every fp32
-// product formed exactly from three bfloat16 terms per operand, the six largest term products kept, two fp32 accumulators by magnitude class
-// (x6.h, vel_x6.hip) - 192 cycles per K = 16 instead of 512.  A operands: the TRANSPOSED weight images (X6PackArgs::imgT: split at pack time),
-// streamed from L2 through a three-slot register ring, three K steps ahead; B operands: g_l, split by the wave that formed it (x6_split8: 11
-// VALU instructions per pair) and exchanged through LDS as in vel_x6.hip - XS image 0 receives g_4 and g_2, image 1 g_3 and g_1 (every image's
-// last reader is at least one barrier older than its next writer: the barriers of phases 2, 1 and 5 separate g_2's readers from the next
-// evaluation's g_4).  Everything else - the 6 -> 128 output layer (fp32 MFMA, K = 6), SiLU', the fp32 images of g_l / a_l for the contraction
-// waves, stash traffic, barriers, LDS-DMA prefetches - is fuse_velnet_bwd's.  Each g_l differs from the fp32 kernel's by the rounding of another
-// summation order (the x6 products are exact; tests/test_gpu_x6_bwd.py bounds both against float64).
+// ---------------------------------------------------------------- round 6: the same evaluation on the 16-bit matrix pipe (x6)
+// dgrad: the 4 x 64 fp32 MFMAs of the four 128 x 128 dgrads (and the 16 of the input layer) become 8 K steps x 6 bf16 MFMAs per layer: every
+// fp32 product formed exactly from three bfloat16 terms per operand, the six largest term products kept, two fp32 accumulators by magnitude
+// class (x6.h, vel_x6.hip) - 192 cycles per K = 16 instead of 512.  A operands: the TRANSPOSED weight images (X6PackArgs::imgT: split at pack
+// time), streamed from L2 through a three-slot register ring; B operands: g_l, split by the wave that formed it (x6_split8) and exchanged
+// through LDS (XS).  Weight gradient: in the epilogue of layer l the wave also hands the contraction waves THEIR operands - a_{l-1} (just
+// formed) and g_l (its own two K steps, read back from XS) transposed by two MFMAs per term against the selection matrices I0 / I1 and packed
+// back to bfloat16 (the fp32 result of a transposing MFMA is the term itself: its upper 16 bits) - GT / AT image l & 1.  The contraction of
+// layer l runs one phase later, like the fp32 kernel's.  Everything else - the 6 -> 128 output layer (fp32 MFMA, K = 6), SiLU', stash traffic,
+// barriers, LDS-DMA prefetches - is fuse_velnet_bwd's.  Each g_l differs from the fp32 kernel's by the rounding of another summation order.
 __device__ __forceinline__ gcb8p fuse_x6_base(const b8_t* img, int off) { gcb8p q = (gcb8p)(img + off); asm("" : "+s"(q)); return q; }
+// one 32-row x 32-sample term image (two K steps in the sample-per-lane format) -> the feature-per-lane format, to LDS at dst[0], dst[3 * 64]
+__device__ __forceinline__ void fuse_x6_transpose(const FuseA& A, const b8_t& p0, const b8_t& p1, b8_t* dst) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 D = MFMA16B(p0, A.I0, zero);
+    D = MFMA16B(p1, A.I1, D);
+    typedef unsigned fx_u32x4 __attribute__((ext_vector_type(4)));
+    unsigned q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = __builtin_amdgcn_perm(__float_as_uint(D[2 * i + 1]), __float_as_uint(D[2 * i]), 0x07060302u);
+    const fx_u32x4 lo = {q[0], q[1], q[2], q[3]}, hi = {q[4], q[5], q[6], q[7]};
+    dst[0] = __builtin_bit_cast(b8_t, lo);
+    dst[3 * 64] = __builtin_bit_cast(b8_t, hi);
+}
 template <class Hook>
 __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const* t4, const float (&r4)[4], const float* zs, float* gs,
                                                    const float* zn, f32x4v& w5, float (&zp)[16], float (&ge)[16], Hook hook FT_ARG) {
@@ -301,30 +322,24 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
 #pragma unroll
         for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
     }
-    int xc = A.xw;                                        // fp32 buffer of g_l (contraction waves)
-    {
-        float4* Xw = A.X + xc * FUSE_XB + (4 * w) * 2 * FUSE_HR + A.pos;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Xw[k * 2 * FUSE_HR] = make_float4(gv[4 * k], gv[4 * k + 1], gv[4 * k + 2], gv[4 * k + 3]);
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            b8_t b1, b2, b3;
-            x6_split8(gv + 8 * k2, b1, b2, b3);
-            b8_t* d = A.XS + (size_t)((2 * w + k2) * 3) * 64;
-            d[0] = b1; d[64] = b2; d[128] = b3;
-        }
+    for (int k2 = 0; k2 < 2; ++k2) {
+        b8_t b1, b2, b3;
+        x6_split8(gv + 8 * k2, b1, b2, b3);
+        b8_t* d = A.XS + (size_t)((2 * w + k2) * 3) * 64;
+        d[0] = b1; d[64] = b2; d[128] = b3;
     }
     FT_ADD(8, t0);
     FUSE_BAR();
     FT_ADD(16, t0);
-    // ---- phases 1..4: dgrad of layer l on x6, then g_{l-1} and a_{l-1}
+    // ---- phases 1..4: dgrad of layer l on x6, then g_{l-1}, a_{l-1} and the contraction waves' operands of layer l
 #pragma unroll
     for (int l = 4; l >= 1; --l) {
         f32x16 a0, a1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+        const b8_t* xs = A.XS + (size_t)(l & 1 ? 1 : 0) * FUSE_XS_H8;         // g_4, g_2 in image 0; g_3, g_1 in image 1
         {
-            const b8_t* xs = A.XS + (size_t)(l & 1 ? 1 : 0) * FUSE_XS_H8;         // g_4, g_2 in image 0; g_3, g_1 in image 1
             gcb8p p1 = fuse_x6_base(A.imgT, X6_LH(l) + w * 512), p2 = fuse_x6_base(A.imgT, X6_H8 + X6_LH(l) + w * 512), p3 = fuse_x6_base(A.imgT, 2 * X6_H8 + X6_LH(l) + w * 512);
             b8_t B[2][3];
             B[0][0] = xs[0]; B[0][1] = xs[64]; B[0][2] = xs[128];
@@ -336,7 +351,7 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = a1[r] + a0[r];                   // the small class first (both are complete sums here)
+        for (int r = 0; r < 16; ++r) acc[r] = a1[r] + a0[r];
 #ifdef FUSE_TIMING
         asm volatile("s_nop 0" :: "v"(acc[0]));
         FT_ADD(5 - l, t0);
@@ -351,54 +366,52 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
 #pragma unroll
             for (int s = 0; s < 2; ++s) { R1[s] = p1[s * 64 + lane]; R2[s] = p2[s * 64 + lane]; R3[s] = p3[s * 64 + lane]; }
         }
-        float4* Yw = A.Y + (l & 1) * FUSE_XB + (4 * w) * 2 * FUSE_HR + A.pos;
-        if (l >= 2) {
-            xc = xc + 1 == FUSE_NX ? 0 : xc + 1;
-            float4* Xw = A.X + xc * FUSE_XB + (4 * w) * 2 * FUSE_HR + A.pos;
-            b8_t* xsw = A.XS + (size_t)(l & 1 ? 0 : 1) * FUSE_XS_H8;            // g_{l-1}: the other image
+        b8_t* xsw = A.XS + (size_t)(l & 1 ? 0 : 1) * FUSE_XS_H8;                // g_{l-1}: the other exchange image
+        b8_t* gt = A.XS + (size_t)(2 + (l & 1)) * FUSE_XS_H8 + (size_t)(w * 2 * 3) * 64;     // GT / AT image l & 1, this wave's tile
+        b8_t* at = A.XS + (size_t)(4 + (l & 1)) * FUSE_XS_H8 + (size_t)(w * 2 * 3) * 64;
+        b8_t pa[2][3];
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                float g8[8];
+        for (int k2 = 0; k2 < 2; ++k2) {
+            float g8[8], a8[8];
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int k = 2 * k2 + kk;
-                    float a4[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float z = zp[4 * k + c], sg = fast_sigmoid(z);
-                        g8[4 * kk + c] = acc[4 * k + c] * (sg * (1.f + z * (1.f - sg)));     // act_d1<1>
-                        a4[c] = z * sg;                                                      // act_f<1>
-                    }
-                    Xw[k * 2 * FUSE_HR] = make_float4(g8[4 * kk], g8[4 * kk + 1], g8[4 * kk + 2], g8[4 * kk + 3]);
-                    Yw[k * 2 * FUSE_HR] = make_float4(a4[0], a4[1], a4[2], a4[3]);
-                }
+            for (int c = 0; c < 8; ++c) {
+                const float z = zp[8 * k2 + c], sg = fast_sigmoid(z);
+                g8[c] = acc[8 * k2 + c] * (sg * (1.f + z * (1.f - sg)));     // act_d1<1>
+                a8[c] = z * sg;                                               // act_f<1>
+            }
+            if (l >= 2) {
                 b8_t b1, b2, b3;
                 x6_split8(g8, b1, b2, b3);
                 b8_t* d = xsw + (size_t)((2 * w + k2) * 3) * 64;
                 d[0] = b1; d[64] = b2; d[128] = b3;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) gv[8 * k2 + c] = g8[c];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            x6_split8(a8, pa[k2][0], pa[k2][1], pa[k2][2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (l >= 2) {
             gcfp zr = opaque_u(zs + (size_t)((l - 2) * 64 + 16 * w) * REGF);
 #pragma unroll
             for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
-        } else {
+        }
+        // the contraction waves' operands of layer l: a_{l-1} (this wave's 32 columns) and g_l (this wave's 32 rows, read back from the exchange)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float a4[4];
+        for (int t = 0; t < 3; ++t) fuse_x6_transpose(A, pa[0][t], pa[1][t], at + (size_t)t * 64);
+        {
+            b8_t pg[2][3];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float z = zp[4 * k + c], sg = fast_sigmoid(z);
-                    gv[4 * k + c] = acc[4 * k + c] * (sg * (1.f + z * (1.f - sg)));
-                    a4[c] = z * sg;
-                }
-                Yw[k * 2 * FUSE_HR] = make_float4(a4[0], a4[1], a4[2], a4[3]);
-            }
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) pg[k2][t] = xs[((2 * w + k2) * 3 + t) * 64];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) fuse_x6_transpose(A, pg[0][t], pg[1][t], gt + (size_t)t * 64);
         }
         FT_ADD(8 + 5 - l, t0);
         FUSE_BAR();
         FT_ADD(16 + 5 - l, t0);
     }
-    A.xw = A.xw + 1 == FUSE_NX ? 0 : A.xw + 1;
     // ---- phase 5: 128 -> 28 (T0), this wave's K quarter: g_0 split in registers, two K steps
     {
         f32x16 a0, a1;
@@ -480,10 +493,26 @@ __device__ __forceinline__ void fuse_park_rec(const Rk2Args& ra, int s, int e, i
 }
 
 template <bool X6>
-__device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* X, float4* Y, float* bc, int w, int lane, int ntiles) {
+__device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* X, float4* Y, float* bc0, int w, int lane, int ntiles) {
     const Rk2Args& ra = a.r;
+    // fp32 variant: X | Y | bc | parking areas.  x6 variant (X is the start of LDS): XS0 | XS1 = bc | GT0 | GT1 | AT0 | AT1 | parking areas
+    b8_t* const xs0 = reinterpret_cast<b8_t*>(X);
+    float* const park0 = X6 ? reinterpret_cast<float*>(xs0 + 6 * FUSE_XS_H8) : bc0 + 4 * 16 * 64;
+    float* const bc = X6 ? reinterpret_cast<float*>(xs0 + FUSE_XS_H8) : bc0;
     FuseA A; A.X = X; A.Y = Y; A.bc = bc; A.w = w; A.lane = lane; A.h = lane >> 5; A.xw = 0;
-    A.XS = reinterpret_cast<b8_t*>(bc + 4 * 16 * 64 + 4 * FUSE_PARK_FLOATS) + lane; A.imgT = reinterpret_cast<const b8_t*>(a.imgT);
+    A.XS = xs0 + lane; A.imgT = reinterpret_cast<const b8_t*>(a.imgT);
+    if (X6) {       // selection matrices: element j of lane (n, kg) of K step ks is 1.0 where n = p' = 16 ks + 2 j + kg (row r = 8 ks + j of half kg)
+        typedef unsigned fi_u32x4 __attribute__((ext_vector_type(4)));
+        const int n = lane & 31, kg = lane >> 5;
+        unsigned d[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                d[ks][jj] = (n == 16 * ks + 4 * jj + kg ? 0x3F80u : 0u) | (n == 16 * ks + 4 * jj + 2 + kg ? 0x3F800000u : 0u);
+        const fi_u32x4 i0 = {d[0][0], d[0][1], d[0][2], d[0][3]}, i1 = {d[1][0], d[1][1], d[1][2], d[1][3]};
+        A.I0 = __builtin_bit_cast(b8_t, i0); A.I1 = __builtin_bit_cast(b8_t, i1);
+    }
     const int h = A.h, j = lane & 31;
     A.pos = h * FUSE_HR + j;
 #ifdef FUSE_TIMING
@@ -501,7 +530,7 @@ __device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* 
     float zp[16];
     f32x4v w5, wq[16];
     // record of the next evaluation / upstream gradient of the next tile: parked in this wave's LDS area by LDS-DMA ([field][lane])
-    float* park = bc + 4 * 16 * 64 + w * FUSE_PARK_FLOATS;
+    float* park = park0 + w * FUSE_PARK_FLOATS;
     const unsigned park_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(park));
     int idx = tile * TILE + j;
     bool active = idx < count;
@@ -675,6 +704,103 @@ __device__ __forceinline__ void fuse_role_contract(const FuseBwdArgs& a, const f
 #undef FUSE_FLUSH
 }
 
+// ---------------------------------------------------------------- contraction waves, x6 (round 6)
+// G[L][t] += sum over the tile's 32 samples of g[32 ob + row][s] * a[32 (ib0 + t) + col][s], every fp32 product from the six largest bfloat16 term
+// products (x6.h) - 2 K steps x 6 MFMAs of 32 cycles per 32 x 32 output tile instead of 16 fp32 MFMAs of 64.  Operands: GT / AT image `buf`,
+// written by the adjoint waves one phase earlier in exactly the register format of the MFMA (16-byte LDS reads, conflict-free).  One fp32
+// accumulator per output tile, like the fp32 kernel (the slab sums over ~40 tiles per workgroup dominate its rounding either way); the bias
+// sums are the row sums of g: the three term operands unpacked and added (fuse_x6_rowsum).
+typedef __bf16 fuse_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fuse_x6_rowsum(const b8_t& v, float acc) {
+    typedef unsigned fr_u32x4 __attribute__((ext_vector_type(4)));
+    const fr_u32x4 u = __builtin_bit_cast(fr_u32x4, v);
+    const fuse_bf2 one = {(__bf16)1.0f, (__bf16)1.0f};
+#ifndef FUSE_ROWSUM_DOT2C
+    // plain unpack + add.  The obvious form - v_dot2c_f32_bf16 against (1, 1), -DFUSE_ROWSUM_DOT2C - is exact in isolation
+    // (tools/probes/dot2_bf16_probe.hip: 3.6e-7 against float64) but came out ~30 % too LARGE here, between the bf16 MFMAs that read the same
+    // registers (every hidden-layer bias gradient wrong, every weight gradient - same operands through the MFMA - right to 5e-7): a second
+    // specimen of "VALU dot / packed arithmetic beside 16-bit MFMAs" after the v_pk_*_f32 glitch of round 5
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc += __uint_as_float(u[i] << 16); acc += __uint_as_float(u[i] & 0xffff0000u); }
+    (void)one;
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fuse_bf2, u[i]), one, acc, false);
+#endif
+    return acc;
+}
+#define FUSE6_CONTRACT(L, BUF)                                                                                       \
+    do {                                                                                                             \
+        const b8_t* ga_ = img + (size_t)(2 + (BUF)) * FUSE_XS_H8 + (size_t)(ob * 2 * 3) * 64;                        \
+        const b8_t* ab_ = img + (size_t)(4 + (BUF)) * FUSE_XS_H8 + (size_t)(ib0 * 2 * 3) * 64;                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
+            const b8_t A1_ = ga_[(ks * 3 + 0) * 64], A2_ = ga_[(ks * 3 + 1) * 64], A3_ = ga_[(ks * 3 + 2) * 64];     \
+            {                                                                                                        \
+                const b8_t B1_ = ab_[(ks * 3 + 0) * 64], B2_ = ab_[(ks * 3 + 1) * 64], B3_ = ab_[(ks * 3 + 2) * 64]; \
+                G##L##a = MFMA16B(A3_, B1_, G##L##a); G##L##a = MFMA16B(A1_, B3_, G##L##a); G##L##a = MFMA16B(A2_, B2_, G##L##a); \
+                G##L##a = MFMA16B(A2_, B1_, G##L##a); G##L##a = MFMA16B(A1_, B2_, G##L##a); G##L##a = MFMA16B(A1_, B1_, G##L##a); \
+            }                                                                                                        \
+            {                                                                                                        \
+                const b8_t B1_ = ab_[((2 + ks) * 3 + 0) * 64], B2_ = ab_[((2 + ks) * 3 + 1) * 64], B3_ = ab_[((2 + ks) * 3 + 2) * 64]; \
+                G##L##b = MFMA16B(A3_, B1_, G##L##b); G##L##b = MFMA16B(A1_, B3_, G##L##b); G##L##b = MFMA16B(A2_, B2_, G##L##b); \
+                G##L##b = MFMA16B(A2_, B1_, G##L##b); G##L##b = MFMA16B(A1_, B2_, G##L##b); G##L##b = MFMA16B(A1_, B1_, G##L##b); \
+            }                                                                                                        \
+            if (do_bias) { bs##L = fuse_x6_rowsum(A3_, bs##L); bs##L = fuse_x6_rowsum(A2_, bs##L); bs##L = fuse_x6_rowsum(A1_, bs##L); } \
+        }                                                                                                            \
+    } while (0)
+
+__device__ __forceinline__ void fuse_role_contract_x6(const FuseBwdArgs& a, const b8_t* img0, int v, int lane, int ntiles) {
+    const int i = lane & 31, kk = lane >> 5;
+    const int ob = v >> 1, ib0 = 2 * (v & 1);
+    const bool do_bias = (v & 1) == 0;
+    const b8_t* img = img0 + lane;
+    f32x16 G0a, G0b, G1a, G1b, G2a, G2b, G3a, G3b;
+    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { G0a[r] = 0.f; G0b[r] = 0.f; G1a[r] = 0.f; G1b[r] = 0.f; G2a[r] = 0.f; G2b[r] = 0.f; G3a[r] = 0.f; G3b[r] = 0.f; }
+    const int G = gridDim.x;
+    const int nsteps = a.r.nsteps;
+#ifdef FUSE_TIMING
+    unsigned long long ft[64]; for (int k = 0; k < 64; ++k) ft[k] = 0;
+    unsigned long long t0 = FT_NOW();
+#endif
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+#pragma unroll 1
+        for (int ev = 0; ev < 2 * nsteps; ++ev) {
+            FT_ADD(32, t0); FUSE_BAR_G(); FT_ADD(40, t0);                   // g_4 exchanged
+            FUSE_BAR_G(); FT_ADD(41, t0);                                   // operands of layer 4 (image 0)
+            FUSE6_CONTRACT(3, 0);
+            FT_ADD(34, t0); FUSE_BAR_G(); FT_ADD(42, t0);                   // layer 3 (image 1)
+            FUSE6_CONTRACT(2, 1);
+            FT_ADD(35, t0); FUSE_BAR_G(); FT_ADD(43, t0);                   // layer 2 (image 0)
+            FUSE6_CONTRACT(1, 0);
+            FT_ADD(36, t0); FUSE_BAR_G(); FT_ADD(44, t0);                   // layer 1 (image 1)
+            FUSE6_CONTRACT(0, 1);
+            FT_ADD(37, t0); FUSE_BAR_G(); FT_ADD(45, t0);
+        }
+    }
+#ifdef FUSE_TIMING
+    if (a.timing && blockIdx.x == 0 && v == 0 && lane == 0)
+        for (int k = 32; k < 48; ++k) a.timing[k] = ft[k];
+#endif
+#define FUSE_FLUSH(L)                                                                                                \
+    do {                                                                                                             \
+        float* S = a.slabs + (size_t)((L) + 1) * a.layer_stride + (size_t)blockIdx.x * a.slab_floats;                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                             \
+            const int row = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * kk;                                               \
+            S[(size_t)row * 128 + 32 * ib0 + i] = G##L##a[r];                                                        \
+            S[(size_t)row * 128 + 32 * (ib0 + 1) + i] = G##L##b[r];                                                  \
+        }                                                                                                            \
+        if ((v & 1) == 0) {                                                                                          \
+            float bsum = bs##L; bsum += __shfl_xor(bsum, 32);                                                        \
+            if (kk == 0) S[(size_t)128 * 128 + 32 * ob + i] = bsum;                                                  \
+        }                                                                                                            \
+    } while (0)
+    FUSE_FLUSH(0); FUSE_FLUSH(1); FUSE_FLUSH(2); FUSE_FLUSH(3);
+#undef FUSE_FLUSH
+}
+
 template <bool X6>
 __global__ __launch_bounds__(FUSE_THREADS) void k_rk2_fuse_bwd(FuseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -696,7 +822,8 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_rk2_fuse_bwd(FuseBwdArgs a) {
         __builtin_amdgcn_s_setprio(3);
         fuse_role_adjoint<X6>(a, X, Y, bc, wave, lane, ntiles);
     } else {
-        fuse_role_contract(a, lds, lds + FUSE_NX * FUSE_XB * 4, wave - 4, lane, ntiles);
+        if constexpr (X6) fuse_role_contract_x6(a, reinterpret_cast<const b8_t*>(lds), wave - 4, lane, ntiles);
+        else fuse_role_contract(a, lds, lds + FUSE_NX * FUSE_XB * 4, wave - 4, lane, ntiles);
     }
 }
 
