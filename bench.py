@@ -1263,7 +1263,10 @@ def main():
                 e["frac"] = e["tflops"] / PEAK_FP32_MFMA
             x6_warp = (k == "rk2_fwd" and os.environ.get("NVFI_RK2_X6", "1") != "0" and os.environ.get("NVFI_RK2_SPLIT", "1") != "0"
                        and os.environ.get("NVFI_VEL_FP16_TRAIN", "0") != "1")
-            if ((k == "pde_prefilter" and pre_mode == "x6") or x6_warp) and "tflops" in e:
+            x6_bwd = (k == "rk2_bwd" and os.environ.get("NVFI_FUSE_X6", "1") != "0" and os.environ.get("NVFI_RK2_FUSE", "1") != "0"
+                      and os.environ.get("NVFI_RK2_SPLIT_BWD", "1") != "0")                 # round 6: vel_fuse.hip, both roles on x6
+            x6_jet = (k == "pde_fwd" and os.environ.get("NVFI_PDE_JET_X6", "1") != "0" and os.environ.get("NVFI_PDE_JET", "1") != "0")      # round 6: pde_jet6.hip
+            if ((k == "pde_prefilter" and pre_mode == "x6") or x6_warp or x6_bwd or x6_jet) and "tflops" in e:
                 # the x6 kernels run on the 16-bit matrix pipe, six MFMAs per fp32 product: their speed of light in ALGORITHMIC fp32 FLOPs is the dense
                 # bfloat16 peak / 6 (416.7 TFLOP/s) - NOT the fp32 MFMA peak, which they may (and do) exceed
                 e["peak"] = PEAK_BF16_MFMA / 6.0

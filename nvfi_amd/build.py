@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["engine.hip", "wgrad_ring.hip", "vel.hip", "render.hip", "scatter.hip", "mask.hip", "pde.hip", "pde_jet.hip", "pre16.hip", "vel_split.hip", "vel_fuse.hip", "pde_fuse.hip", "regs.hip", "optim.hip", "abi.hip", "comm.hip", "frags.hip", "vel_x6.hip", "vel_x6w.hip"]
+SOURCES = ["engine.hip", "wgrad_ring.hip", "vel.hip", "render.hip", "scatter.hip", "mask.hip", "pde.hip", "pde_jet.hip", "pre16.hip", "vel_split.hip", "vel_fuse.hip", "pde_fuse.hip", "regs.hip", "optim.hip", "abi.hip", "comm.hip", "frags.hip", "vel_x6.hip", "vel_x6w.hip", "pde_jet6.hip"]
 # every header under csrc/ (engine16.h, ... - a header that is not listed here would leave stale objects behind) + the public ABI
 HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith(".h")) + [os.path.join("..", "..", "include", "nvfi_hip.h")]
 SO = os.environ.get("NVFI_BUILD_SO", os.path.join(CSRC, "libnvfi_hip.so"))   # experiments build a second library elsewhere
@@ -21,8 +21,8 @@ FILE_FLAGS = {"vel_x6.hip": ["-fno-slp-vectorize"], "vel_x6w.hip": ["-fno-slp-ve
               # beside 16-bit MFMAs) is kept out of every such unit, and check_no_packed_f32() below fails the build if it comes back
               "pre16.hip": ["-fno-slp-vectorize"], "mask.hip": ["-fno-slp-vectorize"],
               # round 6: the fused RK2 adjoint runs its dgrad on bf16 MFMAs (x6) with three waves per SIMD
-              "vel_fuse.hip": ["-fno-slp-vectorize"]}
-NO_PACKED_F32 = ["vel_x6.hip", "vel_x6w.hip", "pre16.hip", "mask.hip", "vel_fuse.hip"]
+              "vel_fuse.hip": ["-fno-slp-vectorize"], "pde_jet6.hip": ["-fno-slp-vectorize"]}
+NO_PACKED_F32 = ["vel_x6.hip", "vel_x6w.hip", "pre16.hip", "mask.hip", "vel_fuse.hip", "pde_jet6.hip"]
 OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
 
 

@@ -117,6 +117,8 @@ int launch_pde_band_map(int64_t P, const int* bcount, const int* perm, int* blis
 // tiles: capacity in 32-point tiles (five weight_net columns each); anet_wgs: capacity in 128-point workgroups of the acceleration net
 int launch_pde_jet_fwd(const PdeJetArgs& a, unsigned tiles, unsigned anet_wgs, hipStream_t st);
 int launch_pde_jet_bwd(const PdeJetArgs& a, unsigned tiles, unsigned anet_wgs, hipStream_t st);
+// pde_jet6.hip (round 6): the forward with the hidden layers on the 16-bit matrix pipe (x6img: the three bfloat16 weight images of x6.h)
+int launch_pde_jet6_fwd(const PdeJetArgs& a, const void* x6img, unsigned tiles, unsigned anet_wgs, hipStream_t st);
 
 // value adjoint with the correction term; no input gradient needed
 template <int ACT, bool CORR>

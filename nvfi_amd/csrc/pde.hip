@@ -892,7 +892,13 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
             if (use_jet) {
                 // all five weight_net columns of a tile in one workgroup; the ReLU acceleration net keeps its column kernel
                 // (the launch carries the acceleration net's value column as trailing workgroups: they fill the tail of the jet tiles)
-                if (launch_pde_jet_fwd(ja, (unsigned)(cap / TILE), wgs, st)) return 1;
+                // NVFI_PDE_JET_X6 (default 1, round 6): pde_jet6.hip - the same program with the hidden layers' products on the 16-bit matrix pipe
+                static int jet_x6 = -1;
+                if (jet_x6 < 0) { const char* e = getenv("NVFI_PDE_JET_X6"); jet_x6 = e ? atoi(e) : 1; }
+                if (jet_x6) {
+                    if (!cached && pre16 != 4 && first == 0 && launch_pack_x6(f->vW, L.x6img, st)) return 1;      // (the x6 prefilter has packed it already)
+                    if (launch_pde_jet6_fwd(ja, cached ? FC.vel_x6 : L.x6img, (unsigned)(cap / TILE), wgs, st)) return 1;
+                } else if (launch_pde_jet_fwd(ja, (unsigned)(cap / TILE), wgs, st)) return 1;
             } else {
                 hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
                 hipLaunchKernelGGL(k_pde_tangent_fwd, PDE_GRID(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);

@@ -48,6 +48,9 @@
 // The transposition is done by the matrix pipe: with B = a 16 x 32 selection matrix, D = A B moves the 8 K values a lane holds of its sample
 // (the B-operand format the split produces) to the lanes of the 32 feature rows (exact: a bfloat16 term times 1.0 into an fp32 zero).
 #define FUSE_XS_H8 (8 * 3 * 64)
+#ifndef FUSE_RING
+#define FUSE_RING 4                                   // register ring of the transposed weight stream (K steps in flight)
+#endif
 #define FUSE_LDS_BYTES_X6 (6 * FUSE_XS_H8 * 16 + 4 * FUSE_PARK_FLOATS * 4)
 typedef const b8_t __attribute__((address_space(1)))* gcb8p;
 // Exchange layout: element (row p, sample s) of a 128-row x 32-sample image, p = 2 (16 w + r) + h for register r of adjoint wave w, lives in
@@ -292,16 +295,16 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
     const int w = A.w, lane = A.lane;
     f32x16 acc;
     float gv[16];
-    b8_t R1[3], R2[3], R3[3];                             // weight ring: K step s of the layer in slot s % 3
+    b8_t R1[FUSE_RING], R2[FUSE_RING], R3[FUSE_RING];    // weight ring: K step s of the layer in slot s % FUSE_RING
 #ifdef FUSE_TIMING
     unsigned long long* ft = T.ft; unsigned long long& t0 = T.t0;
     FT_ADD(24, t0);
 #endif
-    // ---- phase 0: 6 -> 128 (T5, fp32 MFMA), g_4; the first three K steps of layer 4's transposed image start their trip
+    // ---- phase 0: 6 -> 128 (T5, fp32 MFMA), g_4; the first K steps of layer 4's transposed image start their trip
     {
         gcb8p p1 = fuse_x6_base(A.imgT, X6_LH(4) + w * 512), p2 = fuse_x6_base(A.imgT, X6_H8 + X6_LH(4) + w * 512), p3 = fuse_x6_base(A.imgT, 2 * X6_H8 + X6_LH(4) + w * 512);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) { R1[s] = p1[s * 64 + lane]; R2[s] = p2[s * 64 + lane]; R3[s] = p3[s * 64 + lane]; }
+        for (int s = 0; s < FUSE_RING; ++s) { R1[s] = p1[s * 64 + lane]; R2[s] = p2[s * 64 + lane]; R3[s] = p3[s * 64 + lane]; }
     }
     if (w == 0) {
         gfp gw_rows = opaque_u(gs + (size_t)5 * 64 * REGF);
@@ -339,15 +342,21 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
 #pragma unroll
         for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
         const b8_t* xs = A.XS + (size_t)(l & 1 ? 1 : 0) * FUSE_XS_H8;         // g_4, g_2 in image 0; g_3, g_1 in image 1
+        b8_t* gt = A.XS + (size_t)(2 + (l & 1)) * FUSE_XS_H8 + (size_t)(w * 2 * 3) * 64;     // GT / AT image l & 1, this wave's tile
+        b8_t* at = A.XS + (size_t)(4 + (l & 1)) * FUSE_XS_H8 + (size_t)(w * 2 * 3) * 64;
         {
             gcb8p p1 = fuse_x6_base(A.imgT, X6_LH(l) + w * 512), p2 = fuse_x6_base(A.imgT, X6_H8 + X6_LH(l) + w * 512), p3 = fuse_x6_base(A.imgT, 2 * X6_H8 + X6_LH(l) + w * 512);
-            b8_t B[2][3];
-            B[0][0] = xs[0]; B[0][1] = xs[64]; B[0][2] = xs[128];
+            // the contraction waves' A operands of layer l: g_l (this wave's 32 rows = K steps 2 w, 2 w + 1 of the exchange) transposed.  At the HEAD of the
+            // phase: it depends on nothing this phase computes, and its perms / LDS traffic ride in the shadow of the dgrad's MFMAs
+#pragma unroll
+            for (int t = 0; t < 3; ++t) fuse_x6_transpose(A, xs[((2 * w) * 3 + t) * 64], xs[((2 * w + 1) * 3 + t) * 64], gt + (size_t)t * 64);
+            // B operands single-buffered (an LDS round trip is ~100 cycles, covered by the other waves' MFMAs): the registers go to a fourth ring slot
+            // instead - K step s + 4 leaves for L2 behind K step s, ~1 200 cycles ahead of its use on the shared pipe (three slots stalled every K step)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                if (s + 1 < 8) { B[(s + 1) & 1][0] = xs[((s + 1) * 3 + 0) * 64]; B[(s + 1) & 1][1] = xs[((s + 1) * 3 + 1) * 64]; B[(s + 1) & 1][2] = xs[((s + 1) * 3 + 2) * 64]; }
-                x6_mm6(R1[s % 3], R2[s % 3], R3[s % 3], B[s & 1][0], B[s & 1][1], B[s & 1][2], a0, a1);
-                if (s + 3 < 8) { R1[s % 3] = p1[(s + 3) * 64 + lane]; R2[s % 3] = p2[(s + 3) * 64 + lane]; R3[s % 3] = p3[(s + 3) * 64 + lane]; }
+                const b8_t B1 = xs[(s * 3 + 0) * 64], B2 = xs[(s * 3 + 1) * 64], B3 = xs[(s * 3 + 2) * 64];
+                x6_mm6(R1[s % FUSE_RING], R2[s % FUSE_RING], R3[s % FUSE_RING], B1, B2, B3, a0, a1);
+                if (s + FUSE_RING < 8) { R1[s % FUSE_RING] = p1[(s + FUSE_RING) * 64 + lane]; R2[s % FUSE_RING] = p2[(s + FUSE_RING) * 64 + lane]; R3[s % FUSE_RING] = p3[(s + FUSE_RING) * 64 + lane]; }
             }
         }
 #pragma unroll
@@ -360,15 +369,13 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
         if (l >= 2) {
             gcb8p p1 = fuse_x6_base(A.imgT, X6_LH(l - 1) + w * 512), p2 = fuse_x6_base(A.imgT, X6_H8 + X6_LH(l - 1) + w * 512), p3 = fuse_x6_base(A.imgT, 2 * X6_H8 + X6_LH(l - 1) + w * 512);
 #pragma unroll
-            for (int s = 0; s < 3; ++s) { R1[s] = p1[s * 64 + lane]; R2[s] = p2[s * 64 + lane]; R3[s] = p3[s * 64 + lane]; }
+            for (int s = 0; s < FUSE_RING; ++s) { R1[s] = p1[s * 64 + lane]; R2[s] = p2[s * 64 + lane]; R3[s] = p3[s * 64 + lane]; }
         } else {                                                                   // this wave's K quarter of the 128 -> 28 input layer: K steps 2 w, 2 w + 1 of T0
             gcb8p p1 = fuse_x6_base(A.imgT, X6_L0 + w * 128), p2 = fuse_x6_base(A.imgT, X6_H8 + X6_L0 + w * 128), p3 = fuse_x6_base(A.imgT, 2 * X6_H8 + X6_L0 + w * 128);
 #pragma unroll
             for (int s = 0; s < 2; ++s) { R1[s] = p1[s * 64 + lane]; R2[s] = p2[s * 64 + lane]; R3[s] = p3[s * 64 + lane]; }
         }
         b8_t* xsw = A.XS + (size_t)(l & 1 ? 0 : 1) * FUSE_XS_H8;                // g_{l-1}: the other exchange image
-        b8_t* gt = A.XS + (size_t)(2 + (l & 1)) * FUSE_XS_H8 + (size_t)(w * 2 * 3) * 64;     // GT / AT image l & 1, this wave's tile
-        b8_t* at = A.XS + (size_t)(4 + (l & 1)) * FUSE_XS_H8 + (size_t)(w * 2 * 3) * 64;
         b8_t pa[2][3];
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
@@ -396,18 +403,9 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
 #pragma unroll
             for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
         }
-        // the contraction waves' operands of layer l: a_{l-1} (this wave's 32 columns) and g_l (this wave's 32 rows, read back from the exchange)
+        // the contraction waves' B operands of layer l: a_{l-1} (this wave's 32 columns) transposed
 #pragma unroll
         for (int t = 0; t < 3; ++t) fuse_x6_transpose(A, pa[0][t], pa[1][t], at + (size_t)t * 64);
-        {
-            b8_t pg[2][3];
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) pg[k2][t] = xs[((2 * w + k2) * 3 + t) * 64];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) fuse_x6_transpose(A, pg[0][t], pg[1][t], gt + (size_t)t * 64);
-        }
         FT_ADD(8 + 5 - l, t0);
         FUSE_BAR();
         FT_ADD(16 + 5 - l, t0);
