@@ -54,7 +54,7 @@ PEAK_FP32_MFMA = 157.3     # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f3
 PEAK_BF16_MFMA = 2500.0    # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0      # GB/s, MI355X_MICROARCH.md (HBM3E)
 CLASSES = ["rk2_fwd", "rk2_bwd", "app_fwd", "app_bwd", "wgrad", "pde_fwd", "pde_bwd", "density_fwd", "density_bwd", "pde_prefilter", "density_scatter", "app_scatter", "other"]
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 
 def bat_cfg(S=128, use_vel=True):

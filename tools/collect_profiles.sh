@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 passes of bench.py, summarised into gpurun_out/<tag>_*.
-# usage: tools/collect_profiles.sh <tag> [quick]      (e.g. r05; quick: the headline set only)
+# usage: tools/collect_profiles.sh <tag> [quick]      (e.g. r06; quick: the headline set only)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 QUICK=${2:-}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
@@ -39,8 +39,12 @@ python $REPO/tools/bench_extras.py eval_frame > $OUT/${TAG}_eval_frame.json 2>/d
 # the reference's chunk loop for the same frame (2048-ray calls on the current stream), and the frame with the fp32 warp
 NVFI_EVAL_CHUNK=2048 NVFI_EVAL_STREAMS=1 python $REPO/tools/bench_extras.py eval_frame > $OUT/${TAG}_eval_frame_chunk2048.json 2>/dev/null
 NVFI_RK2_X6=0 python $REPO/tools/bench_extras.py eval_frame > $OUT/${TAG}_eval_frame_fp32_warp.json 2>/dev/null
-# the x6 kernels off (fp32 MFMA kernels of round 4 for the render warp and the PDE prefilter), and at one workgroup per CU
-NVFI_RK2_X6=0 NVFI_PDE_PREFILTER=fp32 $B0 --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_fp32_mfma_only.json 2>/dev/null
+# every x6 kernel off (the fp32 MFMA kernels of round 4 for the render warp, its adjoint, the PDE prefilter and the Jacobian forward), and at one workgroup per CU
+NVFI_RK2_X6=0 NVFI_PDE_PREFILTER=fp32 NVFI_FUSE_X6=0 NVFI_PDE_JET_X6=0 NVFI_INTEGRATE_X6=0 $B0 --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_fp32_mfma_only.json 2>/dev/null
+# round 6 A/B: the fused RK2 adjoint / the Jacobian forward back on their fp32 MFMA kernels, one at a time
+NVFI_FUSE_X6=0 $B0 --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_fuse_fp32.json 2>/dev/null
+NVFI_PDE_JET_X6=0 $B0 --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_jet_fp32.json 2>/dev/null
+$B0 --no-extras --graph on --no-cpu-baseline --rays 256 --pts 32768 > $OUT/${TAG}_bench_line_strong_shard_1of8_hipgraph.json 2>/dev/null
 NVFI_X6_ONE_WG=1 $B0 --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_x6_one_wg.json 2>/dev/null
 fi
 # 1. kernel trace of the default bench command: per-kernel statistics of the whole run and of the profiled pass (after the marker)
