@@ -1116,6 +1116,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # round 6: several ranks under STRONG scaling run a launch-bound shard (~22 class launches for ~1 ms of device time): `auto` takes the captured
+    # three-graph iteration there (GraphedStep._multi_iteration; weak scaling - the SCALE run's default - stays on eager launches)
+    if (args.graph == "auto" and world > 1 and args.scaling == "strong" and args.mode == "fused" and args.workload == "cfg3"
+            and os.environ.get("NVFI_ALLREDUCE", "torch") != "abi" and not os.environ.get("NVFI_TORCH_ADAM")):
+        args.graph = "on"
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
     if world > 1 and backend == "nccl" and ndev < world:

@@ -279,6 +279,10 @@ struct RenderFrags {
 int pack_vel_frags(const float* const* W, const float* const* b, float* buf, VelFrags* out, PackJobs* jobs);
 int pack_render_frags(const nvfi_field_desc* f, float* buf, RenderFrags* out, PackJobs* jobs);
 int launch_pack(const PackJobs& jobs, hipStream_t st);
+// zero `bytes` (a multiple of 4) at p with a KERNEL.  Round 6: hipMemsetAsync is not used on any path that can be captured - as the root node of a
+// captured hipGraph (the PDE term's own graph of the multi-rank step) its replay left the workspace's histogram words uncleared / wrote elsewhere:
+// k_pde_bucket then scattered through stale offsets ("Write access to a read-only page", two ranks on one GPU; tools/run_cap_debug2.py).
+int launch_zero(void* p, int64_t bytes, hipStream_t st);
 int launch_scan_fill(const int* cnt, int* off, int64_t ngroups, int* total, const uint8_t* flags, int* list, hipStream_t st);
 int launch_wgrad(const WgradJobs& wj, const ReduceJobs& rj, hipStream_t st);
 int launch_wgrad_ring(WgradJobs& bj, ReduceJobs& br, hipStream_t st);   // wgrad_ring.hip

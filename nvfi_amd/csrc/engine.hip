@@ -39,6 +39,18 @@ __global__ void k_pack_all(PackJobsAll jobs, X6PackArgs x6) {
     if ((int)blockIdx.x < jobs.n) pack_job(jobs.j[blockIdx.x], blockIdx.y, gridDim.y);
     else x6_pack_body(x6, (((int)blockIdx.x - jobs.n) * 8 + (int)blockIdx.y) * 256 + (int)threadIdx.x);
 }
+__global__ void k_zero_words(unsigned* p, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+int launch_zero(void* p, int64_t bytes, hipStream_t st) {
+    if (bytes <= 0) return 0;
+    if (bytes & 3) return nvfi_fail(2, "launch_zero: %lld bytes is not a multiple of 4", (long long)bytes);
+    const int64_t n = bytes / 4;
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(p), n);
+    LAUNCHCK();
+    return 0;
+}
 int launch_pack_all(const PackJobsAll& jobs, const X6PackArgs* x6, hipStream_t st) {
     if (jobs.n == 0 && !x6) return 0;
     X6PackArgs xa; memset(&xa, 0, sizeof(xa));

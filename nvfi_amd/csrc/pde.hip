@@ -730,7 +730,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     if (ensure_pde_attrs() || ensure_lds_attrs()) return 1;
     PdePlan L; plan_pde(P, workspace, &L);
     if (L.total > workspace_bytes) return nvfi_fail(4, "workspace too small: need %lld bytes, got %lld", (long long)L.total, (long long)workspace_bytes);
-    HIPCK(hipMemsetAsync(L.cls_count, 0, (size_t)L.zero_bytes, st));     // histogram / counts, loss sums, look-back words: one fill
+    if (launch_zero(L.cls_count, L.zero_bytes, st)) return 1;     // histogram / counts, loss sums, look-back words: one fill (a kernel, not hipMemsetAsync: common.h)
     const bool fl = fused_launch();
     PackJobs jobs; jobs.n = 0;
     VelFrags VW, AW;

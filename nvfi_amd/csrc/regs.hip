@@ -104,7 +104,7 @@ static int plane_regs(const nvfi_field_desc* f, float w_l1, float w_tv_density, 
                       const nvfi_grads* grads, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     RegJobs jobs; jobs.n = 0; jobs.out = out3; jobs.wdev = wdev;
-    HIPCK(hipMemsetAsync(out3, 0, 3 * sizeof(float), st));
+    if (launch_zero(out3, 3 * sizeof(float), st)) return 1;
     const int A[3] = {0, 0, 1}, Bx[3] = {1, 2, 2}, Cc[3] = {2, 1, 0};
     auto add = [&](const float* p, float* g, int H, int W, int C, int l1_mode, int tv_slot, float hmul, float tvw) {
         RegJob& J = jobs.j[jobs.n++];

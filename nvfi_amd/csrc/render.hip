@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_sample_fill(SampleArgs a) {
 
 // scan + ordered fill for n_groups groups of 64 flags (used by the PDE prefilter)
 int launch_scan_fill(const int* cnt, int* off, int64_t ngroups, int* total, const uint8_t* flags, int* list, hipStream_t st) {
-    if (ngroups <= 0) { HIPCK(hipMemsetAsync(total, 0, sizeof(int), st)); return 0; }
+    if (ngroups <= 0) return launch_zero(total, sizeof(int), st);
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, st, ngroups, 64, flags, cnt, off, list, total);
     LAUNCHCK();
     return 0;
@@ -1488,7 +1488,7 @@ static int render_fwd_impl(const nvfi_field_desc* f, int64_t R, const float* ray
         }
         hipLaunchKernelGGL(k_prologue, dim3(1), dim3(256), 0, st, pa);
     } else {
-        HIPCK(hipMemsetAsync(P.counters, 0, (size_t)P.zero_bytes, st));
+        if (launch_zero(P.counters, P.zero_bytes, st)) return 1;
         if (t_dev) {
             SchedArgs sc; memset(&sc, 0, sizeof(sc));
             sc.f = *f; sc.t_dev = t_dev; sc.flags = flags; sc.nsteps_plan = nsteps; sc.tn_plan = tn; sc.sched = P.sched;
@@ -1659,7 +1659,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     int64_t det_off[12]; int64_t det_n = 0;
     if (det_mode()) {
         det_n = plane_elems(f, det_off);
-        HIPCK(hipMemsetAsync(P.shadow, 0, (size_t)det_n * sizeof(long long), st));
+        if (launch_zero(P.shadow, det_n * (int64_t)sizeof(long long), st)) return 1;
         for (int i = 0; i < 3; ++i) {
             if (gdet.dps[i]) gdet.dps[i] = reinterpret_cast<float*>(P.shadow + det_off[i]);
             if (gdet.dpt[i]) gdet.dpt[i] = reinterpret_cast<float*>(P.shadow + det_off[3 + i]);
