@@ -16,7 +16,7 @@ CLASSES = {
     "rk2_fwd": [r"k_rk2_fwd<true, true>", r"k_rk2_split_uni<", r"k_rk2_x6_uni<"],
     "rk2_bwd": [r"k_rk2_bwd", r"k_rk2_split_bwd<", r"k_rk2_fuse_bwd"],
     "pde_bwd": [r"k_pde_jet_bwd", r"k_pde_tangent_bwd", r"k_pde_value_bwd", r"k_pde_fuse_bwd"],
-    "pde_fwd": [r"k_pde_jet_fwd", r"k_pde_value_fwd", r"k_pde_tangent_fwd"],
+    "pde_fwd": [r"k_pde_jet6_fwd", r"k_pde_jet_fwd", r"k_pde_value_fwd", r"k_pde_tangent_fwd"],
     "app_fwd": [r"k_app_fwd<true>", r"k_app_feat$"],
     "app_bwd": [r"k_app_bwd"],
     "density_fwd": [r"k_density_q"],
