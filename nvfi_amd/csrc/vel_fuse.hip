@@ -707,23 +707,23 @@ __device__ __forceinline__ void fuse_role_contract(const FuseBwdArgs& a, const f
 // products (x6.h) - 2 K steps x 6 MFMAs of 32 cycles per 32 x 32 output tile instead of 16 fp32 MFMAs of 64.  Operands: GT / AT image `buf`,
 // written by the adjoint waves one phase earlier in exactly the register format of the MFMA (16-byte LDS reads, conflict-free).  One fp32
 // accumulator per output tile, like the fp32 kernel (the slab sums over ~40 tiles per workgroup dominate its rounding either way); the bias
-// sums are the row sums of g: the three term operands unpacked and added (fuse_x6_rowsum).
+// sums are the row sums of g: v_dot2c_f32_bf16 of the three term operands against (1, 1) (fuse_x6_rowsum).
 typedef __bf16 fuse_bf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float fuse_x6_rowsum(const b8_t& v, float acc) {
+    // v_dot2c_f32_bf16 against (1, 1), the pairs formed ELEMENT-WISE.  The first build wrote `bit_cast<bf16x2>(bit_cast<u32x4>(v)[i])`: hipcc 7.2 folds
+    // that to element pair 0 for every i (four identical v_dot2c on ONE register - visible in a ten-line kernel without any MFMA,
+    // tools/probes/dot2_bf16_probe.hip, k_bitcast) and every hidden-layer bias gradient came out 10-60 % wrong while the weight gradients - same
+    // registers through the MFMA - were right.  A compiler bug, not a hazard: the instruction itself is exact (same probe, 3.6e-7 against float64).
+    // -DFUSE_ROWSUM_PLAIN: shift / mask / add instead.
+#ifdef FUSE_ROWSUM_PLAIN
     typedef unsigned fr_u32x4 __attribute__((ext_vector_type(4)));
     const fr_u32x4 u = __builtin_bit_cast(fr_u32x4, v);
-    const fuse_bf2 one = {(__bf16)1.0f, (__bf16)1.0f};
-#ifndef FUSE_ROWSUM_DOT2C
-    // plain unpack + add.  The obvious form - v_dot2c_f32_bf16 against (1, 1), -DFUSE_ROWSUM_DOT2C - is exact in isolation
-    // (tools/probes/dot2_bf16_probe.hip: 3.6e-7 against float64) but came out ~30 % too LARGE here, between the bf16 MFMAs that read the same
-    // registers (every hidden-layer bias gradient wrong, every weight gradient - same operands through the MFMA - right to 5e-7): a second
-    // specimen of "VALU dot / packed arithmetic beside 16-bit MFMAs" after the v_pk_*_f32 glitch of round 5
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc += __uint_as_float(u[i] << 16); acc += __uint_as_float(u[i] & 0xffff0000u); }
-    (void)one;
 #else
+    const fuse_bf2 one = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fuse_bf2, u[i]), one, acc, false);
+    for (int i = 0; i < 4; ++i) { const fuse_bf2 p = {v[2 * i], v[2 * i + 1]}; acc = __builtin_amdgcn_fdot2_f32_bf16(p, one, acc, false); }
 #endif
     return acc;
 }
