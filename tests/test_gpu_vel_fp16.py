@@ -225,6 +225,7 @@ def test_gpu_training_render_with_fp16_forward_warp_matches_the_fp16_oracle(gold
     print(f"[{kind}] fp16-forward training warp: {n} gradients within 1e-3 of the fp16 oracle; velocity-net gradient differs from the fp32 path by {dv:.2e} (max-norm)")
 
 
+@pytest.mark.gpu
 def test_fp16_input_kernels_repeat_bit_for_bit():
     """round 6: pre16.hip carries 16-bit MFMAs for eight waves per workgroup - two per SIMD, the occupancy at which the
     x6 kernels once glitched with packed-fp32 VALU code beside them.  The unit is compiled with the same fence now
