@@ -494,11 +494,12 @@ int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st) {
     static int x6w = -1;
     if (x6w < 0) { const char* e = getenv("NVFI_X6W"); x6w = e ? atoi(e) : 1; }
     // round 6: a SMALL call is latency-bound - its evaluations are a serial chain per tile, 60 k cycles each on one wave (x6w) against ~17.5 k with
-    // the tile's four row tiles on four SIMDs (k_rk2_x6<1>; 35 k with two workgroups per CU) - so up to NVFI_X6W_MIN_TILES (default 768: the
-    // point where the four-wave kernel needs a second round) the four-wave kernel runs; same products in the same order, identical bits
-    // (tests/test_gpu_x6.py).  train_segm's integrate_pos (3 000-30 000 occupied points, 40-60 evaluations deep) is the case: 1.03 -> 0.4 ms.
+    // the tile's four row tiles on four SIMDs (k_rk2_x6<1>; 35 k with two workgroups per CU) - so up to NVFI_X6W_MIN_TILES the four-wave kernel
+    // runs; same products in the same order, identical bits (tests/test_gpu_x6.py).  Default 4096, measured on the PDE prefilter (trajectories of up
+    // to 20 evaluations): 1024 tiles (the strong-scaling shard) 0.41 -> 0.19 ms, 4096 tiles 0.45 -> 0.44 ms, 8192 tiles (the full batch) one wave per
+    // tile wins (0.80 against 0.89 ms).  train_segm's integrate_pos (3 000-30 000 occupied points, 40-60 evaluations deep): 1.03 -> 0.46 ms.
     static int min_tiles = -1;
-    if (min_tiles < 0) { const char* e = getenv("NVFI_X6W_MIN_TILES"); min_tiles = e ? atoi(e) : 768; }
+    if (min_tiles < 0) { const char* e = getenv("NVFI_X6W_MIN_TILES"); min_tiles = e ? atoi(e) : 4096; }
     if ((x6w && tiles > min_tiles) || nt == 4) return launch_rk2_x6w(a, cap_points, st);
     const unsigned two = (unsigned)((tiles + 1) / 2);
     if (nt == 1) hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
