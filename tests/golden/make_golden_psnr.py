@@ -42,7 +42,7 @@ def main():
         r = psnr_loop.run(B, teacher, student, "cpu", seed, iters=iters, log=lambda s: print(s, f"({time.time() - t0:.0f} s)", flush=True))
         print(seed, r, flush=True)
         rows.append([r["psnr_key"], r["psnr_nonkey"], r["psnr_key_before"], r["psnr_nonkey_before"], r["loss_first"], r["loss_last"]])
-    out["columns"] = np.asarray(["psnr_key", "psnr_nonkey", "psnr_key_before", "psnr_nonkey_before", "loss_first", "loss_last"])
+    # columns of `reference` (one row per seed): psnr_key, psnr_nonkey, psnr_key_before, psnr_nonkey_before, loss_first, loss_last
     out["reference"] = np.asarray(rows, np.float64)
     np.savez(os.environ.get("PSNR_OUT", os.path.join(HERE, "psnr.npz")), **out)
     a = out["reference"]
