@@ -1240,12 +1240,12 @@ def main():
         flops = {"rk2_fwd": E * VEL_FLOP, "rk2_bwd": E * VEL_FLOP, "app_fwd": M * APP_FLOP, "app_bwd": M * APP_FLOP,
                  "wgrad": E * VEL_FLOP + M * APP_FLOP + kept * 6 * VEL_FLOP, "pde_fwd": kept * 6 * VEL_FLOP,
                  "pde_bwd": kept * 6 * VEL_FLOP, "pde_prefilter": pre_evals * VEL_FLOP}
-        if os.environ.get("NVFI_RK2_FUSE", "1") != "0" and os.environ.get("NVFI_RK2_SPLIT_BWD", "1") != "0":
+        if os.environ.get("NVFI_RK2_FUSE", "1") != "0":
             # vel_fuse.hip: the RK2 adjoint also forms the four 128 x 128 weight gradients of the render warp (2 * 4 * 128^2 FLOP per evaluation);
             # the wgrad class keeps the two edge layers of that launch
             flops["rk2_bwd"] += E * 131072.0
             flops["wgrad"] -= E * 131072.0
-        if os.environ.get("NVFI_PDE_FUSE", "1") != "0" and os.environ.get("NVFI_PDE_JET", "1") != "0":
+        if os.environ.get("NVFI_PDE_FUSE", "1") != "0":
             # pde_fuse.hip: the Jacobian adjoint also forms weight_net's four 128 x 128 weight gradients for the five columns of every kept point
             flops["pde_bwd"] += kept * 5 * 131072.0
             flops["wgrad"] -= kept * 5 * 131072.0
@@ -1266,11 +1266,10 @@ def main():
             if k in flops and ms > 0:
                 e["tflops"] = flops[k] / (ms * 1e-3) / 1e12
                 e["frac"] = e["tflops"] / PEAK_FP32_MFMA
-            x6_warp = (k == "rk2_fwd" and os.environ.get("NVFI_RK2_X6", "1") != "0" and os.environ.get("NVFI_RK2_SPLIT", "1") != "0"
+            x6_warp = (k == "rk2_fwd" and os.environ.get("NVFI_RK2_X6", "1") != "0"
                        and os.environ.get("NVFI_VEL_FP16_TRAIN", "0") != "1")
-            x6_bwd = (k == "rk2_bwd" and os.environ.get("NVFI_FUSE_X6", "1") != "0" and os.environ.get("NVFI_RK2_FUSE", "1") != "0"
-                      and os.environ.get("NVFI_RK2_SPLIT_BWD", "1") != "0")                 # round 6: vel_fuse.hip, both roles on x6
-            x6_jet = (k == "pde_fwd" and os.environ.get("NVFI_PDE_JET_X6", "1") != "0" and os.environ.get("NVFI_PDE_JET", "1") != "0")      # round 6: pde_jet6.hip
+            x6_bwd = (k == "rk2_bwd" and os.environ.get("NVFI_FUSE_X6", "1") != "0" and os.environ.get("NVFI_RK2_FUSE", "1") != "0")                 # round 6: vel_fuse.hip, both roles on x6
+            x6_jet = (k == "pde_fwd" and os.environ.get("NVFI_PDE_JET_X6", "1") != "0")      # round 6: pde_jet6.hip
             if ((k == "pde_prefilter" and pre_mode == "x6") or x6_warp or x6_bwd or x6_jet) and "tflops" in e:
                 # the x6 kernels run on the 16-bit matrix pipe, six MFMAs per fp32 product: their speed of light in ALGORITHMIC fp32 FLOPs is the dense
                 # bfloat16 peak / 6 (416.7 TFLOP/s) - NOT the fp32 MFMA peak, which they may (and do) exceed

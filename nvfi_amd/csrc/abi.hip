@@ -100,7 +100,7 @@ extern "C" int nvfi_integrate_pos(const nvfi_field_desc* f, int64_t N, const flo
     }
     a.f = *f; a.count = nullptr; a.n_direct = N; a.list = nullptr; a.xw = xw; a.xout = xk;
     a.pt_t = t; a.pt_base = base; a.dt_max = dt_max_of(*f); a.max_steps = 4096;
-    return launch_rk2_fwd(a, N, false, false, st);
+    return launch_rk2_fwd(a, N, false, st);
 }
 
 // ---------------------------------------------------------------- compute_alpha / device-side rays (next rows f-3, f-2)
@@ -182,7 +182,7 @@ extern "C" int nvfi_compute_alpha(const nvfi_field_desc* f, int64_t N, const flo
         if (pack_vel_frags(f->vW, f->vb, fv, &a.Wv, &jobs)) return 3;
         if (launch_pack(jobs, st)) return 1;
         a.f = *f; a.count = nullptr; a.n_direct = N; a.list = nullptr; a.xw = xw; a.xout = nullptr; a.nsteps = n;
-        if (launch_rk2_fwd(a, N, true, false, st)) return 1;
+        if (launch_rk2_fwd(a, N, true, st)) return 1;
         }
     }
     {   // density at the (warped) points with the quad-lane gather kernel (scatter.hip), then alpha = 1 - exp(-sigma * length)

@@ -439,157 +439,8 @@ __device__ __forceinline__ void acc_from_w(const float* aw, float x, float y, fl
     a[2] = aw[2] - aw[3] * z - aw[4] * z;
 }
 
-// Backward (dgrad) of one evaluation.  gw4: adjoint of the 6 outputs in D-layout regs 0..3 of this lane.
-// zst: z stash of the forward; gst: adjoint stash to fill (5*64 rows gz + 16 rows gw) for k_wgrad, or NULL.
-// Returns ge (16 regs, input-slot layout) in ge[].
-// (step-major accumulation: 4 live accumulator tiles, one 64-register adjoint array - the tile-major ping-pong form
-// of the forward pass spills here because the RK2 adjoint keeps more state live around the MLP pass)
-template <int ACT>
-__device__ __forceinline__ void velnet_backward(const VelFrags& W, float* lds_w, float* lds_b, int lane,
-                                                const float* gw4, const float* zst, float* gst, float* ge) {
-    float g[64];
-    f32x16 acc[4];
-    g[0] = gw4[0]; g[1] = gw4[1]; g[2] = gw4[2]; g[3] = gw4[3];
-    if (gst) {
-        float* gw_rows = gst + (size_t)5 * 64 * REGF;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
-    }
-    __syncthreads();
-    stage_frag(lds_w, lds_b, W.t[5], VEL_T5, nullptr, 0);
-    __syncthreads();
-    acc_init<4>(acc, lds_b, 0, false);
-    layer_mfma<4, 4>(lds_w, lane, g, acc);
-#pragma unroll 1
-    for (int l = 4; l >= 1; --l) {
-        const float* zl = zst + (size_t)l * 64 * REGF;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[16 * m + r] = acc[m][r] * act_d1<ACT>(zl[(16 * m + r) * REGF + lane]);
-        if (gst) stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
-        __syncthreads();
-        stage_frag(lds_w, lds_b, W.t[l], VEL_FH, nullptr, 0);
-        __syncthreads();
-        acc_init<4>(acc, lds_b, 0, false);
-        layer_mfma<4, 64>(lds_w, lane, g, acc);
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g[16 * m + r] = acc[m][r] * act_d1<ACT>(zst[(16 * m + r) * REGF + lane]);
-    if (gst) stash_store<64>(gst, lane, g);
-    __syncthreads();
-    stage_frag(lds_w, lds_b, W.t[0], VEL_T0, nullptr, 0);
-    __syncthreads();
-    f32x16 o[1];
-    acc_init<1>(o, lds_b, 0, false);
-    layer_mfma<1, 64>(lds_w, lane, g, o);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ge[r] = o[0][r];
-}
-
-// ---------------------------------------------------------------- pipelined backward (one workgroup per CU)
-// The adjoint passes were dominated by exposed latency (PMC: 40-66 % of the wave cycles in s_waitcnt): every layer
-// waited for its weight fragment (global -> LDS between two barriers) and then for the z stash in the epilogue.
-// Here the workgroup owns the CU (one wave per SIMD, 512 registers, 2 x 64 KB fragment buffers):
-//   issue   : the NEXT layer's fragment is loaded into 64 registers and the NEXT epilogue's z rows into 64 more,
-//   compute : 256 MFMAs read the current fragment from LDS buffer `cur`,
-//   commit  : the in-flight fragment is written to the other buffer, ONE barrier, buffers flip.
-// A buffer is only overwritten after every wave has passed the barrier that followed its last read of it.
-#define ENGINE2_LDS_BYTES ((2 * LDS_W_FLOATS + 2 * LDS_B_FLOATS) * 4)
-struct FragPipe {
-    float* base; int cur; float4 r[16]; int n4; float rb; int nb;
-    __device__ __forceinline__ void init(float* lds) { base = lds; cur = 0; n4 = 0; nb = 0; rb = 0.f; }
-    __device__ __forceinline__ const float* w() const { return base + cur * LDS_W_FLOATS; }
-    __device__ __forceinline__ const float* b() const { return base + 2 * LDS_W_FLOATS + cur * LDS_B_FLOATS; }
-    __device__ __forceinline__ void issue(const float* __restrict__ frag, int nfloats, const float* __restrict__ bfrag = nullptr, int nbias = 0) {
-        const float4* src = reinterpret_cast<const float4*>(frag);
-        n4 = frag ? nfloats >> 2 : 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int idx = threadIdx.x + k * WG_THREADS;
-            if (idx < n4) r[k] = src[idx];
-        }
-        nb = bfrag ? nbias : 0;
-        if ((int)threadIdx.x < nb) rb = bfrag[threadIdx.x];
-    }
-    __device__ __forceinline__ void commit() {
-        float4* dst = reinterpret_cast<float4*>(base + (cur ^ 1) * LDS_W_FLOATS);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int idx = threadIdx.x + k * WG_THREADS;
-            if (idx < n4) dst[idx] = r[k];
-        }
-        if ((int)threadIdx.x < nb) base[2 * LDS_W_FLOATS + (cur ^ 1) * LDS_B_FLOATS + threadIdx.x] = rb;
-        __syncthreads();
-        cur ^= 1;
-    }
-};
-
-template <int NR>
-__device__ __forceinline__ void stash_load(const float* base, int lane, float* v) {
-#pragma unroll
-    for (int s = 0; s < NR; ++s) v[s] = STASH_LD(base[s * REGF + lane]);
-}
-
-// (A pipelined FORWARD was built the same way and measured: rk2_fwd unchanged, the PDE prefilter 12 % slower - the forward
-// has no stash reads to hide, its staging is already covered by the second workgroup of the CU, and at one wave per SIMD
-// the SiLU epilogue is no longer hidden at all.  The forward kernels therefore keep two workgroups per CU.)
-// Backward (dgrad) of one evaluation, pipelined form.  On entry the pipe's current buffer holds W.t[5]; on exit it holds
-// `next_frag` (next_n floats: the first fragment of whatever pass follows - usually W.t[5] again), so consecutive
-// evaluations chain without an exposed staging step.  Same results as velnet_backward.
-template <int ACT>
-__device__ __forceinline__ void velnet_backward_p(const VelFrags& W, FragPipe& P, int lane, const float* gw4, const float* zst,
-                                                  float* gst, float* ge, const float* next_frag, int next_n) {
-    float g[64], zp[64];
-    f32x16 acc[4];
-    g[0] = gw4[0]; g[1] = gw4[1]; g[2] = gw4[2]; g[3] = gw4[3];
-    if (gst) {
-        float* gw_rows = gst + (size_t)5 * 64 * REGF;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
-    }
-    P.issue(W.t[4], VEL_FH);
-    stash_load<64>(zst + (size_t)4 * 64 * REGF, lane, zp);
-    __builtin_amdgcn_sched_barrier(0);
-    acc_init<4>(acc, nullptr, 0, false);
-    layer_mfma<4, 4>(P.w(), lane, g, acc);
-    P.commit();
-#pragma unroll 1
-    for (int l = 4; l >= 1; --l) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 v2 = (f32x2){acc[m][r], acc[m][r + 1]} * act_d1_2<ACT>((f32x2){zp[16 * m + r], zp[16 * m + r + 1]});
-                g[16 * m + r] = v2.x; g[16 * m + r + 1] = v2.y;
-            }
-        if (gst) stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
-        if (l > 1) P.issue(W.t[l - 1], VEL_FH); else P.issue(W.t[0], VEL_T0);
-        stash_load<64>(zst + (size_t)(l - 1) * 64 * REGF, lane, zp);
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetches ahead of the MFMAs (the scheduler would sink them to save registers)
-        acc_init<4>(acc, nullptr, 0, false);
-        layer_mfma<4, 64>(P.w(), lane, g, acc);
-        P.commit();
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const f32x2 v2 = (f32x2){acc[m][r], acc[m][r + 1]} * act_d1_2<ACT>((f32x2){zp[16 * m + r], zp[16 * m + r + 1]});
-            g[16 * m + r] = v2.x; g[16 * m + r + 1] = v2.y;
-        }
-    if (gst) stash_store<64>(gst, lane, g);
-    P.issue(next_frag, next_n);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 o[1];
-    acc_init<1>(o, nullptr, 0, false);
-    layer_mfma<1, 64>(P.w(), lane, g, o);
-    P.commit();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ge[r] = o[0][r];
-}
+// (The adjoint of one evaluation lives with its kernels: vel_split.hip - feature-split, unfused - and vel_fuse.hip - the persistent kernel with the weight
+// gradients; the one-tile-per-wave forms of rounds 1-2, velnet_backward / velnet_backward_p on a double-buffered fragment pipe, were retired in round 6.)
 
 // adjoint of the PositionEncoder slots: ge (16 regs of this lane) + the forward slots x0 -> (gx,gy,gz,gt) summed over both halves
 __device__ __forceinline__ float4 vel_encode_bwd(const float* ge, const float* x0, int h) {
@@ -625,7 +476,6 @@ struct WgradJob {
 };
 #define MAX_WGRAD_JOBS 24
 struct WgradJobs { WgradJob j[MAX_WGRAD_JOBS]; int n; };
-__global__ void k_wgrad(WgradJobs jobs);
 
 // slab reduce + un-permute into the logical gradient tensors
 struct ReduceJob {

@@ -4,7 +4,7 @@
 #include "vel.h"
 
 #define PDE_MAX_CLASS 64           // RK2 step-count buckets
-#define PDE_CHUNK 262144           // kept points processed per pass (bounds the stash: 42 KB per point -> 11 GB of address space, touched only up to the kept count; sized for 288 GB of HBM)
+#define PDE_CHUNK 262144           // kept points processed per pass (bounds the stash: 32 KB per point -> 8.4 GB of address space, touched only up to the kept count; sized for 288 GB of HBM)
 #ifndef PDE_NSLAB
 #define PDE_NSLAB 256
 #endif
@@ -15,8 +15,7 @@
 #define PDE_X0    (PDE_ZD + 4 * 320)         // encoder slots                      16
 #define PDE_X0D   (PDE_X0 + 16)              // encoder tangents               4 x 16
 #define PDE_GA    (PDE_X0D + 64)             // adjoints: value, 4 tangents   5 x 336
-#define PDE_CORR  (PDE_GA + 5 * 336)         // second-derivative corrections 4 x 320 (one per tangent column)
-#define PDE_ZA    (PDE_CORR + 4 * 320)           // a_weight_net pre-activations      320
+#define PDE_ZA    (PDE_GA + 5 * 336)         // a_weight_net pre-activations      320   (the 4 x 320 second-derivative correction rows of the round-1 column kernels went with them in round 6)
 #define PDE_GAA   (PDE_ZA + 320)             // a_weight_net adjoints             336
 #define PDE_TILE_ROWS (PDE_GAA + 336)
 
@@ -47,7 +46,6 @@ struct PdeJetArgs {
     VelFrags Wv, Wa;
     const float4* f4[6]; const float4* t4[6]; const float* bv[6];   // x4 fragments / bias fragments of weight_net (fused jet kernels)
     int jet_tiles;             // fused jet launches: workgroups [0, jet_tiles) are jet tiles, the rest the acceleration net's column
-    int only_col;              // column kernels of pde.hip: >= 0 runs that single column (the acceleration net beside the fused kernels)
     const float4* qorig; const int* klist;
     int64_t first; const int* kcount; int64_t cap; int wgs;     // kcount: DEVICE count of kept points; this pass handles [first, first + cap)
     float* stash; float* seeds; float* wout; double* sums;

@@ -118,319 +118,9 @@ __global__ __launch_bounds__(256) void k_pde_keep_fill(nvfi_field_desc f, int64_
     if (keep) klist[base + __popcll(b & ((1ull << lane) - 1ull))] = (int)i;
 }
 
-// ---------------------------------------------------------------- forward-mode passes
-// tangent of the PositionEncoder slots wrt q_j
-__device__ __forceinline__ void encode_tangent(const float* x0, int h, int j, float* xd) {
-#pragma unroll
-    for (int s = 0; s < 16; ++s) xd[s] = 0.f;
-    // raw slots: s=0 -> (x|y), s=1 -> (z|t)
-    if (j == 0 && h == 0) xd[0] = 1.f;
-    if (j == 1 && h == 1) xd[0] = 1.f;
-    if (j == 2 && h == 0) xd[1] = 1.f;
-    if (j == 3 && h == 1) xd[1] = 1.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float mine = x0[2 + 4 * k + c];
-            const float other = __shfl_xor(mine, 32);
-            const float fr = (float)(1 << k);
-            if (c == j) xd[2 + 4 * k + c] = h ? -fr * other : fr * other;   // d sin = fr cos ; d cos = -fr sin
-        }
-}
-
-// The tangent forward pass uses the tile-major form (engine.h: layer_tiles): while the MFMAs of output tile m run, the
-// epilogue of tile m-1 - its stash loads (z, zd), derivative math and stash stores - is independent work.
-
-template <int ACT>
-__device__ __forceinline__ void velnet_tangent_forward(const VelFrags& W, float* lds_w, float* lds_b, int lane, const float* xd16,
-                                                       const float* zst, float* zdst, float* out4) {
-    float xa[64], xb[64];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) xb[s] = xd16[s];
-#define TAN_FWD_EPI(L, XOUT)                                                                  \
-    [&](int m, const f32x16& acc) {                                                           \
-        const float* zl = zst + (size_t)(L) * 64 * REGF; float* zd = zdst + (size_t)(L) * 64 * REGF; \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
-            zd[(16 * m + r) * REGF + lane] = acc[r];                                          \
-            XOUT[16 * m + r] = act_d1<ACT>(zl[(16 * m + r) * REGF + lane]) * acc[r];          \
-        }                                                                                     \
-    }
-    __syncthreads();
-    stage_frag(lds_w, lds_b, W.f[0], VEL_F0, nullptr, 0);
-    __syncthreads();
-    layer_tiles<4, 14>(lds_w, lds_b, false, lane, 0, xb, TAN_FWD_EPI(0, xa));
-#pragma unroll 1
-    for (int it = 0; it < 2; ++it) {
-        const int l = 1 + 2 * it;
-        __syncthreads();
-        stage_frag(lds_w, lds_b, W.f[l], VEL_FH, nullptr, 0);
-        __syncthreads();
-        layer_tiles<4, 64>(lds_w, lds_b, false, lane, 0, xa, TAN_FWD_EPI(l, xb));
-        __syncthreads();
-        stage_frag(lds_w, lds_b, W.f[l + 1], VEL_FH, nullptr, 0);
-        __syncthreads();
-        layer_tiles<4, 64>(lds_w, lds_b, false, lane, 0, xb, TAN_FWD_EPI(l + 1, xa));
-    }
-#undef TAN_FWD_EPI
-    __syncthreads();
-    stage_frag(lds_w, lds_b, W.f[5], VEL_F5, nullptr, 0);
-    __syncthreads();
-    layer_tiles<1, 64>(lds_w, lds_b, false, lane, 0, xa, [&](int, const f32x16& acc) {
-        out4[0] = acc[0]; out4[1] = acc[1]; out4[2] = acc[2]; out4[3] = acc[3];
-    });
-}
-
-// (the two adjoint passes keep the step-major form: measured faster here - the tile-major epilogue with its three
-// stash streams spills)
-// adjoint of one tangent column: seeds gwd (D-layout regs) -> gzd stash (A operand of k_wgrad) and the
-// second-derivative correction corr_l (+)= act''(z_l) * zd_l * ghd_l for the value-adjoint pass
-template <int ACT>
-__device__ __forceinline__ void velnet_tangent_backward(const VelFrags& W, float* lds_w, float* lds_b, int lane, const float* seed4,
-                                                        const float* zst, const float* zdst, float* corr, bool first, float* gst) {
-    float g[64];
-    f32x16 acc[4];
-    g[0] = seed4[0]; g[1] = seed4[1]; g[2] = seed4[2]; g[3] = seed4[3];
-    {
-        float* gw_rows = gst + (size_t)5 * 64 * REGF;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
-    }
-    __syncthreads();
-    stage_frag(lds_w, lds_b, W.t[5], VEL_T5, nullptr, 0);
-    __syncthreads();
-    acc_init<4>(acc, lds_b, 0, false);
-    layer_mfma<4, 4>(lds_w, lane, g, acc);
-#pragma unroll 1
-    for (int l = 4; l >= 0; --l) {
-        const float* zl = zst + (size_t)l * 64 * REGF;
-        const float* zdl = zdst + (size_t)l * 64 * REGF;
-        float* cl = corr + (size_t)l * 64 * REGF;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int s = 16 * m + r;
-                const float z = zl[s * REGF + lane];
-                float d1, d2;
-                act_d12<ACT>(z, d1, d2);
-                const float c = d2 * zdl[s * REGF + lane] * acc[m][r];
-                cl[s * REGF + lane] = first ? c : cl[s * REGF + lane] + c;
-                g[s] = d1 * acc[m][r];
-            }
-        stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
-        if (l >= 1) {
-            __syncthreads();
-            stage_frag(lds_w, lds_b, W.t[l], VEL_FH, nullptr, 0);
-            __syncthreads();
-            acc_init<4>(acc, lds_b, 0, false);
-            layer_mfma<4, 64>(lds_w, lane, g, acc);
-        }
-    }
-}
-// Pipelined forms (engine.h: FragPipe - one workgroup per CU, next fragment and next epilogue's stash rows in flight behind
-// the MFMAs).  On entry the pipe's current buffer holds W.t[5].
-template <int ACT>
-__device__ __forceinline__ void velnet_tangent_backward_p(const VelFrags& W, FragPipe& P, int lane, const float* seed4,
-                                                          const float* zst, const float* zdst, float* corr, float* gst) {
-    float g[64], zp[64], zdp[64];
-    f32x16 acc[4];
-    g[0] = seed4[0]; g[1] = seed4[1]; g[2] = seed4[2]; g[3] = seed4[3];
-    {
-        float* gw_rows = gst + (size_t)5 * 64 * REGF;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
-    }
-    P.issue(W.t[4], VEL_FH);
-    stash_load<64>(zst + (size_t)4 * 64 * REGF, lane, zp);
-    stash_load<64>(zdst + (size_t)4 * 64 * REGF, lane, zdp);
-    __builtin_amdgcn_sched_barrier(0);
-    acc_init<4>(acc, nullptr, 0, false);
-    layer_mfma<4, 4>(P.w(), lane, g, acc);
-    P.commit();
-#pragma unroll 1
-    for (int l = 4; l >= 0; --l) {
-        float* cl = corr + (size_t)l * 64 * REGF;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int s = 16 * m + r;
-                f32x2 d1, d2;
-                act_d12_2<ACT>((f32x2){zp[s], zp[s + 1]}, d1, d2);
-                const f32x2 a2 = {acc[m][r], acc[m][r + 1]};
-                const f32x2 c2 = d2 * (f32x2){zdp[s], zdp[s + 1]} * a2, g2 = d1 * a2;
-                cl[s * REGF + lane] = c2.x; cl[(s + 1) * REGF + lane] = c2.y;
-                g[s] = g2.x; g[s + 1] = g2.y;
-            }
-        stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
-        if (l >= 1) {
-            if (l > 1) P.issue(W.t[l - 1], VEL_FH); else P.issue(nullptr, 0);
-            stash_load<64>(zst + (size_t)(l - 1) * 64 * REGF, lane, zp);
-            stash_load<64>(zdst + (size_t)(l - 1) * 64 * REGF, lane, zdp);
-            __builtin_amdgcn_sched_barrier(0);
-            acc_init<4>(acc, nullptr, 0, false);
-            layer_mfma<4, 64>(P.w(), lane, g, acc);
-            P.commit();
-        }
-    }
-}
-// tangent forward of one column, pipelined.  On entry the pipe's current buffer holds W.f[0].
-template <int ACT>
-__device__ __forceinline__ void velnet_tangent_forward_p(const VelFrags& W, FragPipe& P, int lane, const float* xd16,
-                                                         const float* zst, float* zdst, float* out4) {
-    float x[64], zp[64];
-    f32x16 acc[4];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) x[s] = xd16[s];
-    P.issue(W.f[1], VEL_FH);
-    stash_load<64>(zst, lane, zp);
-    __builtin_amdgcn_sched_barrier(0);
-    acc_init<4>(acc, nullptr, 0, false);
-    layer_mfma<4, 14>(P.w(), lane, x, acc);
-    P.commit();
-#pragma unroll 1
-    for (int l = 0; l < 4; ++l) {
-        float* zd = zdst + (size_t)l * 64 * REGF;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                zd[(16 * m + r) * REGF + lane] = acc[m][r];
-                zd[(16 * m + r + 1) * REGF + lane] = acc[m][r + 1];
-                const f32x2 v2 = act_d1_2<ACT>((f32x2){zp[16 * m + r], zp[16 * m + r + 1]}) * (f32x2){acc[m][r], acc[m][r + 1]};
-                x[16 * m + r] = v2.x; x[16 * m + r + 1] = v2.y;
-            }
-        if (l < 3) P.issue(W.f[l + 2], VEL_FH); else P.issue(W.f[5], VEL_F5);
-        stash_load<64>(zst + (size_t)(l + 1) * 64 * REGF, lane, zp);
-        __builtin_amdgcn_sched_barrier(0);
-        acc_init<4>(acc, nullptr, 0, false);
-        layer_mfma<4, 64>(P.w(), lane, x, acc);
-        P.commit();
-    }
-    {
-        float* zd = zdst + (size_t)4 * 64 * REGF;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                zd[(16 * m + r) * REGF + lane] = acc[m][r];
-                zd[(16 * m + r + 1) * REGF + lane] = acc[m][r + 1];
-                const f32x2 v2 = act_d1_2<ACT>((f32x2){zp[16 * m + r], zp[16 * m + r + 1]}) * (f32x2){acc[m][r], acc[m][r + 1]};
-                x[16 * m + r] = v2.x; x[16 * m + r + 1] = v2.y;
-            }
-    }
-    f32x16 o[1];
-    acc_init<1>(o, nullptr, 0, false);
-    layer_mfma<1, 64>(P.w(), lane, x, o);
-    out4[0] = o[0][0]; out4[1] = o[0][1]; out4[2] = o[0][2]; out4[3] = o[0][3];
-}
-template <int ACT>
-__device__ __forceinline__ void velnet_value_backward_p(const VelFrags& W, FragPipe& P, int lane, const float* seed4,
-                                                        const float* zst, float* gst) {
-    float g[64], zp[64];
-    f32x16 acc[4];
-    g[0] = seed4[0]; g[1] = seed4[1]; g[2] = seed4[2]; g[3] = seed4[3];
-    {
-        float* gw_rows = gst + (size_t)5 * 64 * REGF;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) gw_rows[s * REGF + lane] = s < 4 ? g[s] : 0.f;
-    }
-    P.issue(W.t[4], VEL_FH);
-    stash_load<64>(zst + (size_t)4 * 64 * REGF, lane, zp);
-    __builtin_amdgcn_sched_barrier(0);
-    acc_init<4>(acc, nullptr, 0, false);
-    layer_mfma<4, 4>(P.w(), lane, g, acc);
-    P.commit();
-#pragma unroll 1
-    for (int l = 4; l >= 0; --l) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 v2 = act_d1_2<ACT>((f32x2){zp[16 * m + r], zp[16 * m + r + 1]}) * (f32x2){acc[m][r], acc[m][r + 1]};
-                g[16 * m + r] = v2.x; g[16 * m + r + 1] = v2.y;
-            }
-        stash_store<64>(gst + (size_t)l * 64 * REGF, lane, g);
-        if (l >= 1) {
-            if (l > 1) P.issue(W.t[l - 1], VEL_FH); else P.issue(nullptr, 0);
-            stash_load<64>(zst + (size_t)(l - 1) * 64 * REGF, lane, zp);
-            __builtin_amdgcn_sched_barrier(0);
-            acc_init<4>(acc, nullptr, 0, false);
-            layer_mfma<4, 64>(P.w(), lane, g, acc);
-            P.commit();
-        }
-    }
-}
-
-// ---- column-parallel jet kernels: the value column, the 4 tangent columns and the a_weight_net column of a
-// tile run in DIFFERENT workgroups (blockIdx.y = column) so that a few ten-thousand kept points still fill 256 CUs.
-
-// XCD-aware (tile, column) mapping of the column-parallel kernels.  Workgroups are dealt to the 8 XCDs round-robin by their
-// linear id, and each XCD has its own L2; the NCOL column workgroups of one tile all read that tile's z stash, so they are
-// given linear ids with the same residue mod 8: id = ((tile/8) * NCOL + col) * 8 + tile%8.  The grid is 1-D with
-// ceil(wgs/8) * 8 * NCOL workgroups; returns false for the padding ids.
-#define PDE_GRID(wgs, ncol) dim3((unsigned)((((wgs) + 7) / 8) * 8 * (ncol)))
-__device__ __forceinline__ bool pde_tile_col(int ncol, int wgs, int& wg, int& col) {
-    const int L = blockIdx.x;
-    const int xcd = L & 7, q = L >> 3;
-    col = q % ncol;
-    wg = (q / ncol) * 8 + xcd;
-    return wg < wgs;
-}
-
+// (The Jacobian passes - value + four tangent columns forward, their adjoints with the second-derivative corrections - live in pde_jet.hip,
+// pde_jet6.hip and pde_fuse.hip; the column-parallel forms that stood here in rounds 1-5 were retired in round 6.)
 #define pde_pass_count pde_pass_count_of
-// K1: value forward of weight_net (y=0) and a_weight_net (y=1)
-__global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_fwd(PdeJetArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    int wg, ycol;
-    if (a.only_col >= 0) { if (!pde_tile_col(1, a.wgs, wg, ycol)) return; ycol = a.only_col; }
-    else if (!pde_tile_col(2, a.wgs, wg, ycol)) return;
-    const int count = pde_pass_count(a);
-    if (wg * WG_SAMPLES >= count) return;
-    const int tile = wg * 4 + wave_id();
-    const int i = tile * TILE + (lane & 31);
-    const bool active = i < count;
-    float4 q = active ? a.qorig[a.klist[a.first + i]] : zero4();
-    float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
-    float o4[4], w[6];
-    if (ycol == 0) velnet_forward<1, true>(a.Wv, lds_w, lds_b, lane, q, T + PDE_Z * REGF, T + PDE_X0 * REGF, o4);
-    else velnet_forward<0, true>(a.Wa, lds_w, lds_b, lane, q, T + PDE_ZA * REGF, nullptr, o4);
-    gather6(o4, h, w);
-    if (h == 0 && i < a.cap) {
-        float* o = a.wout + (size_t)(ycol == 0 ? 0 : 30) * a.cap + i;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[(size_t)k * a.cap] = w[k];
-    }
-}
-// K2: tangent column j = blockIdx.y of weight_net
-__global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_fwd(PdeJetArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    int wg, j;
-    if (!pde_tile_col(4, a.wgs, wg, j)) return;
-    if (wg * WG_SAMPLES >= pde_pass_count(a)) return;
-    const int tile = wg * 4 + wave_id();
-    const int i = tile * TILE + (lane & 31);
-    float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
-    FragPipe pipe; pipe.init(lds);
-    pipe.issue(a.Wv.f[0], VEL_F0);
-    float x0[16], xd[16], o4[4], wd[6];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) x0[s] = T[(PDE_X0 + s) * REGF + lane];
-    pipe.cur = 1; pipe.commit();          // first fragment into buffer 0
-    encode_tangent(x0, h, j, xd);
-    stash_store<16>(T + (PDE_X0D + 16 * j) * REGF, lane, xd);
-    velnet_tangent_forward_p<1>(a.Wv, pipe, lane, xd, T + PDE_Z * REGF, T + (PDE_ZD + 320 * j) * REGF, o4);
-    gather6(o4, h, wd);
-    if (h == 0 && i < a.cap) {
-        float* o = a.wout + (size_t)(6 + 6 * j) * a.cap + i;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[(size_t)k * a.cap] = wd[k];
-    }
-}
 // Round 5: the call's tiny bookkeeping kernels ride in k_pde_seeds.  Every workgroup of the launch draws a ticket when it is done (its
 // partial sums are agent-scope atomics that have completed - s_waitcnt vmcnt(0) - before the ticket, as in k_tile_hist); the LAST one does the
 // work of k_pde_pass_count (the sample count of this pass for the weight-gradient kernels, the fused adjoint's queue word), and - in the last
@@ -550,50 +240,6 @@ __global__ __launch_bounds__(256) void k_pde_seeds(PdeJetArgs a) {
     }
     if (a.tail.ticket) pde_tail(a, count);
 }
-// K4: tangent-adjoint column j = blockIdx.y (0..3) or the a_weight_net adjoint (y = 4)
-__global__ __launch_bounds__(WG_THREADS, 1) void k_pde_tangent_bwd(PdeJetArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    int wg, j;
-    if (a.only_col >= 0) { if (!pde_tile_col(1, a.wgs, wg, j)) return; j = a.only_col; }
-    else if (!pde_tile_col(5, a.wgs, wg, j)) return;
-    if (wg * WG_SAMPLES >= pde_pass_count(a)) return;
-    const int tile = wg * 4 + wave_id();
-    const int i = tile * TILE + (lane & 31);
-    float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
-    const size_t cs = a.cap;
-    const bool ok = i < a.cap;
-    FragPipe pipe; pipe.init(lds);
-    pipe.issue(j < 4 ? a.Wv.t[5] : a.Wa.t[5], VEL_T5);
-    pipe.cur = 1; pipe.commit();          // first fragment into buffer 0
-    float r4[4], s6[6];
-    const int sbase = j < 4 ? 6 + 6 * j : 30;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s6[k] = ok ? a.seeds[(size_t)(sbase + k) * cs + i] : 0.f;
-    scatter6(s6, h, r4);
-    if (j < 4)
-        velnet_tangent_backward_p<1>(a.Wv, pipe, lane, r4, T + PDE_Z * REGF, T + (PDE_ZD + 320 * j) * REGF,
-                                     T + (PDE_CORR + 320 * j) * REGF, T + (PDE_GA + 336 * (1 + j)) * REGF);
-    else
-        velnet_value_backward_p<0>(a.Wa, pipe, lane, r4, T + PDE_ZA * REGF, T + PDE_GAA * REGF);
-}
-// K5: value adjoint of weight_net with the summed second-derivative corrections
-__global__ __launch_bounds__(WG_THREADS, 2) void k_pde_value_bwd(PdeJetArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    if ((int)(blockIdx.x * WG_SAMPLES) >= pde_pass_count(a)) return;
-    const int tile = blockIdx.x * 4 + wave_id();
-    const int i = tile * TILE + (lane & 31);
-    float* T = a.stash + (size_t)tile * PDE_TILE_ROWS * REGF;
-    const size_t cs = a.cap;
-    const bool ok = i < a.cap;
-    float r4[4], s6[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s6[k] = ok ? a.seeds[(size_t)k * cs + i] : 0.f;
-    scatter6(s6, h, r4);
-    velnet_value_backward<1, true>(a.Wv, lds_w, lds_b, lane, r4, T + PDE_Z * REGF, T + PDE_CORR * REGF, T + PDE_GA * REGF);
-}
 
 // tiny helpers that keep the bookkeeping on the device (no synchronisation on the launch stream)
 // per-pass sample count for k_wgrad (whole 128-point groups: the ragged rows of the last group are zero)
@@ -678,10 +324,6 @@ extern "C" int nvfi_pde_workspace_bytes(const nvfi_field_desc* f, int64_t P, int
 static int ensure_pde_attrs() {
     static bool done = false;
     if (done) return 0;
-    HIPCK(hipFuncSetAttribute((const void*)k_pde_value_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_pde_tangent_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE2_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_pde_tangent_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE2_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_pde_value_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     done = true;
     return 0;
 }
@@ -739,33 +381,30 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     if (pack_vel_frags(f->vW, f->vb, cached ? FC.vel : L.vel_frag, &VW, &jobs)) return 3;
     if (pack_vel_frags(f->aW, f->ab, cached ? FC.anet : L.a_frag, &AW, &jobs)) return 3;
     if (!cached && launch_pack(jobs, st)) return 1;
-    // fused jet kernels (pde_jet.hip; NVFI_PDE_JET=0 keeps the column kernels for every column): x4 copies of the v-net fragments
-    static int use_jet = -1;
-    if (use_jet < 0) { const char* e = getenv("NVFI_PDE_JET"); use_jet = e ? atoi(e) : 1; }
+    // fused jet kernels (pde_jet.hip / pde_jet6.hip): x4 copies of the v-net fragments.  (The column-parallel Jacobian kernels of round 1 - one workgroup
+    // per (tile, column), NVFI_PDE_JET=0 - were retired in round 6.)
     // NVFI_PDE_FUSE (default 1): pde_fuse.hip - weight_net's Jacobian adjoint and its four 128 x 128 weight gradients in one persistent kernel
     // (no gz_1..gz_4 stash, no second pass over the z / zd stash); 0: k_pde_jet_bwd + k_wgrad_ring8 over the full adjoint stash
     static int pde_fuse = -1;
     if (pde_fuse < 0) { const char* e = getenv("NVFI_PDE_FUSE"); pde_fuse = e ? atoi(e) : 1; }
     // prefilter mode: x6 (default, round 5: vel_x6.hip - the fp32 products of the hidden layers formed exactly on the 16-bit matrix pipe) | fp32 (the
-    // feature-split fp32 MFMA kernel of vel_split.hip, the default of rounds 2-4) | engine32 (k_rk2_fwd of vel.hip: the same numbers bit for
-    // bit, ~4 % slower) | fp16band (pre16.hip: fp16-input pass + fp32 re-evaluation of the unsafe points)
+    // feature-split fp32 MFMA kernel of vel_split.hip, the default of rounds 2-4; "engine32", k_rk2_fwd of vel.hip with the same numbers bit for
+    // bit and ~4 % slower, was retired in round 6) | fp16band (pre16.hip: fp16-input pass + fp32 re-evaluation of the unsafe points)
     // split16band (opt-in, pre16.hip): the pre-pass with fp32 products emulated by two binary16 terms per operand (three fp16 MFMAs), and a
     // band 100 x narrower than fp16band's in front of the same fp32 re-evaluation
     static int pre16 = -1; static float band16 = 0.1f, eps16 = 2e-3f;
     if (pre16 < 0) {
         const char* e = getenv("NVFI_PDE_PREFILTER");
-        if (e && strcmp(e, "fp16band") && strcmp(e, "split16band") && strcmp(e, "fp32") && strcmp(e, "split32") && strcmp(e, "engine32") && strcmp(e, "x6"))
-            return nvfi_fail(2, "NVFI_PDE_PREFILTER must be fp32, engine32, x6, fp16band or split16band");
+        if (e && strcmp(e, "fp16band") && strcmp(e, "split16band") && strcmp(e, "fp32") && strcmp(e, "split32") && strcmp(e, "x6"))
+            return nvfi_fail(2, "NVFI_PDE_PREFILTER must be fp32, x6, fp16band or split16band");
         // 2 = split kernel ("split32" = "fp32"); 4 = x6 (vel_x6.hip: fp32 products formed exactly from three binary16 terms per operand)
         // round 5: x6 is the default - its error against float64 is not larger than the fp32 MFMA kernel's (tests/test_gpu_x6.py) and it is 1.35x faster
-        pre16 = !e ? 4 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "split16band") ? 3 : (!strcmp(e, "engine32") ? 0 : (!strcmp(e, "x6") ? 4 : 2))));
+        pre16 = !e ? 4 : (!strcmp(e, "fp16band") ? 1 : (!strcmp(e, "split16band") ? 3 : (!strcmp(e, "x6") ? 4 : 2)));
         if (pre16 == 3) { band16 = 1e-3f; eps16 = 2e-5f; }
-        if ((e = getenv("NVFI_PDE_BAND"))) band16 = (float)atof(e);
-        if ((e = getenv("NVFI_PDE_GATE_EPS"))) eps16 = (float)atof(e);
     }
     const float4* f4[6] = {nullptr}; const float4* t4[6] = {nullptr};
     if (cached) { x4f_pointers(FC.vel_x4f, f4); x4b_pointers(FC.vel_x4b, t4); }
-    else if (use_jet || pre16) {
+    else {
         X4Jobs xj; xj.n = 0;
         float* p = L.vel_x4;
         auto add = [&](const float* src, int MT, int NS, const float4** slot) {
@@ -782,7 +421,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
     }
     const float4* ta4[6] = {nullptr};
     if (cached) a_x4b_pointers(FC.a_x4b, ta4);
-    else if (use_jet && pde_fuse && grads) {
+    else if (pde_fuse && grads) {
         X4Jobs xj; xj.n = 0;
         float* p = L.a_x4;
         for (int l = 1; l <= 5; ++l) {
@@ -819,11 +458,6 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         xa.dt_max = ra.dt_max; xa.max_steps = PDE_MAX_CLASS;
         if (!cached && launch_pack_x6(f->vW, L.x6img, st)) return 1;
         { ProfScope ps(PK_PDE_PREFILTER, st); if (launch_rk2_x6(xa, P, st)) return 1; }
-        da.n_direct = P; da.xw = L.xw;
-        if (launch_density_q(da, P, st)) return 1;
-    } else if (!pre16) {
-        ra.count = nullptr; ra.n_direct = P; ra.list = L.perm; ra.pt_t = L.pt_t_perm; ra.pt_base = L.pt_base_perm;
-        if (launch_rk2_fwd(ra, P, false, false, st)) return 1;
         da.n_direct = P; da.xw = L.xw;
         if (launch_density_q(da, P, st)) return 1;
     } else {
@@ -880,16 +514,13 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
         const unsigned wgs = (unsigned)(cap / WG_SAMPLES);
         ja.wgs = (int)wgs;
         ja.wout = L.wout;
-        ja.only_col = -1;
         for (int l = 0; l < 6; ++l) { ja.f4[l] = f4[l]; ja.t4[l] = t4[l]; ja.bv[l] = VW.b[l]; }
-        // the fused adjoint is the only reader of the hidden layers' pre-activations: they travel as x4 stash blocks (NVFI_PDE_X4=0: row-major)
-        static int want_x4 = -1;
-        if (want_x4 < 0) { const char* e = getenv("NVFI_PDE_X4"); want_x4 = e ? atoi(e) : 1; }
-        const bool fuse_ok = use_jet && pde_fuse && grads && grads->vW[1] && grads->vW[2] && grads->vW[3] && grads->vW[4];
-        ja.x4 = (fuse_ok && want_x4) ? 1 : 0;
+        // the fused adjoint is the only reader of the hidden layers' pre-activations: they travel as x4 stash blocks (row-major for the unfused adjoint)
+        const bool fuse_ok = pde_fuse && grads && grads->vW[1] && grads->vW[2] && grads->vW[3] && grads->vW[4];
+        ja.x4 = fuse_ok ? 1 : 0;
         {
             ProfScope ps(PK_PDE_FWD, st);
-            if (use_jet) {
+            {
                 // all five weight_net columns of a tile in one workgroup; the ReLU acceleration net keeps its column kernel
                 // (the launch carries the acceleration net's value column as trailing workgroups: they fill the tail of the jet tiles)
                 // NVFI_PDE_JET_X6 (default 1, round 6): pde_jet6.hip - the same program with the hidden layers' products on the 16-bit matrix pipe
@@ -899,9 +530,6 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
                     if (!cached && pre16 != 4 && first == 0 && launch_pack_x6(f->vW, L.x6img, st)) return 1;      // (the x6 prefilter has packed it already)
                     if (launch_pde_jet6_fwd(ja, cached ? FC.vel_x6 : L.x6img, (unsigned)(cap / TILE), wgs, st)) return 1;
                 } else if (launch_pde_jet_fwd(ja, (unsigned)(cap / TILE), wgs, st)) return 1;
-            } else {
-                hipLaunchKernelGGL(k_pde_value_fwd, PDE_GRID(wgs, 2), dim3(WG_THREADS), ENGINE_LDS_BYTES, st, ja);
-                hipLaunchKernelGGL(k_pde_tangent_fwd, PDE_GRID(wgs, 4), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, ja);
             }
             if (fl) {
                 // the last workgroup of k_pde_seeds does the bookkeeping launches' work (pde_tail); out / counters in the last pass of the call only
@@ -954,12 +582,7 @@ static int pde_loss_impl(const nvfi_field_desc* f, int64_t P, const float* point
                     const int max_wgs = sb != st ? PDE_NSLAB - 8 : PDE_NSLAB;
                     if (launch_pde_fuse_bwd(fa, cap, max_wgs, &fused_nslab, sb)) return 1;
                     fused_accel = fa.do_accel;
-                } else if (use_jet) {
-                    if (launch_pde_jet_bwd(ja, (unsigned)(cap / TILE), wgs, sb)) return 1;
-                } else {
-                    hipLaunchKernelGGL(k_pde_tangent_bwd, PDE_GRID(wgs, 5), dim3(WG_THREADS), ENGINE2_LDS_BYTES, sb, ja);
-                    hipLaunchKernelGGL(k_pde_value_bwd, dim3(wgs), dim3(WG_THREADS), ENGINE_LDS_BYTES, sb, ja);
-                }
+                } else if (launch_pde_jet_bwd(ja, (unsigned)(cap / TILE), wgs, sb)) return 1;
             }
             LAUNCHCK();
             if (launch_pde_wgrad(L.stash, (int)(cap / TILE), L.slabs, L.dcount, grads, sb, fused_nslab, fused_slabs, fused_accel ? fused_slabs_a : nullptr)) return 1;

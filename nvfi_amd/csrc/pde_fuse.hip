@@ -632,10 +632,7 @@ int launch_pde_fuse_bwd(const PdeFuseArgs& a, int64_t cap_points, int max_slabs,
         ncu_dev[dev] = n;
     }
     const int ncu = ncu_dev[dev];
-    static int reserve = -1;                              // NVFI_FUSE_RESERVE=n (experiment): see launch_rk2_fuse_bwd
-    if (reserve < 0) { const char* e = getenv("NVFI_FUSE_RESERVE"); reserve = e ? atoi(e) : 0; }
-    int G = ncu - reserve < max_slabs ? ncu - reserve : max_slabs;
-    if (G < 1) G = 1;
+    int G = ncu < max_slabs ? ncu : max_slabs;           // one persistent workgroup per CU (leaving 8-32 CUs to the other streams: no gain)
     if ((int64_t)G > tiles) G = (int)tiles;
 #ifdef PF_TIMING
     static unsigned long long* tbuf = nullptr; static int shots = 0;

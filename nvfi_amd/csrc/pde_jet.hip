@@ -367,12 +367,6 @@ int ensure_jet_attrs() {
     if (done) return 0;
     HIPCK(hipFuncSetAttribute((const void*)k_pde_jet_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, JET_LDS_BYTES));
     HIPCK(hipFuncSetAttribute((const void*)k_pde_jet_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, JET_LDS_BYTES));
-    if (getenv("NVFI_DEBUG_OCC")) {
-        int nf = -1, nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (const void*)k_pde_jet_fwd, WG_THREADS, JET_LDS_BYTES);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_pde_jet_bwd, WG_THREADS, JET_LDS_BYTES);
-        fprintf(stderr, "[nvfi] jet kernels: workgroups per CU fwd %d, bwd %d (LDS %d B each)\n", nf, nb, JET_LDS_BYTES);
-    }
     done = true;
     return 0;
 }

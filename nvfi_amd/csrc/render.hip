@@ -1133,8 +1133,6 @@ static ForkStream& fork_of_current_device() {
     return g_forks[dev];
 }
 #define g_fork (fork_of_current_device())
-static int scatter_mask() { static int m = -1; if (m < 0) { const char* e = getenv("NVFI_SCATTER_MASK"); m = e ? atoi(e) : 63; } return m; }
-
 
 // NVFI_DETERMINISTIC=1: bit-reproducible plane gradients for tests.  The sorted-tile path sums in an order that
 // depends on atomic cursors; this mode takes the plain atomic scatter instead and accumulates in fixed point (k_plane_scatter<C, true>).
@@ -1160,9 +1158,7 @@ static int launch_scatter(const nvfi_field_desc* f, ScatterArgs& sa, int C, int6
     int gmax = f->G[0] > f->G[1] ? f->G[0] : f->G[1];
     gmax = gmax > f->G[2] ? gmax : f->G[2];
     const size_t lds = (size_t)6 * gmax * 24 * sizeof(float);
-    static int use_lds = -1;
-    if (use_lds < 0) { const char* e = getenv("NVFI_SCATTER_LDS"); use_lds = e ? atoi(e) : 1; }
-    if (use_lds && lds <= 150 * 1024) {
+    if (lds <= 150 * 1024) {
         static bool attr = false;
         if (!attr) {
             HIPCK(hipFuncSetAttribute((const void*)k_plane_scatter_lds<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
@@ -1332,12 +1328,10 @@ struct RenderPlan {
     TileWork tw; bool tiles;   // sorted-tile plane scatter (scatter.hip); tiles = false: grid too large, atomic scatter instead
     int64_t total;
 };
-#define NSLAB_MAX 1024
-static int nslab_rt() { static int n = -1; if (n < 0) { const char* e = getenv("NVFI_NSLAB"); n = e ? atoi(e) : 256; if (n < 1) n = 1; if (n > NSLAB_MAX) n = NSLAB_MAX; } return n; }
-#define NSLAB (nslab_rt())
+#define NSLAB_MAX 256        // (1024 while NVFI_NSLAB could be swept: 0.6 GB of slab workspace nobody wrote)
+#define NSLAB 256            // slab capacity of a weight-gradient job (one per CU; the NVFI_NSLAB sweep of round 2 was retired in round 6)
 #define SLAB_FLOATS (128 * 128 + 128)
 
-static bool app_feat_split() { static int u = -1; if (u < 0) { const char* e = getenv("NVFI_APP_FEAT"); u = e ? atoi(e) : 1; } return u != 0; }
 static bool use_tiles() { static int u = -1; if (u < 0) { const char* e = getenv("NVFI_SCATTER_TILES"); u = e ? atoi(e) : 1; } return u != 0; }
 static void plan_render(const nvfi_field_desc* f, int64_t R, int flags, int nsteps, void* ws, RenderPlan* P) {
     Bump B{(char*)ws, 0, 0};
@@ -1530,15 +1524,14 @@ static int render_fwd_impl(const nvfi_field_desc* f, int64_t R, const float* ray
         ra.nsteps = nsteps; ra.sched = sched;
         for (int s = 0; s < nsteps; ++s) { ra.dt[s] = dts[s]; ra.tcur[s] = tcs[s]; }
         ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles;
-        // the feature-split layout of vel_split.hip (NVFI_RK2_SPLIT=0: k_rk2_fwd of vel.hip; same stash, same numbers bit for bit)
-        static int split = -1;
-        if (split < 0) { const char* e = getenv("NVFI_RK2_SPLIT"); split = e ? atoi(e) : 1; }
+        // fp32 form: the feature-split layout of vel_split.hip (the one-tile-per-wave k_rk2_fwd<uniform> of vel.hip, NVFI_RK2_SPLIT=0 - same stash, same
+        // numbers bit for bit - was retired in round 6)
         // round 5: the warp on the x6 evaluation (vel_x6.hip: the hidden layers' fp32 products formed exactly from three bfloat16 terms per operand
         // on the 16-bit matrix pipe; same stash / records for the fp32 adjoint) unless NVFI_RK2_X6=0 or an fp16-input mode is asked for
         static int x6 = -1;
         if (x6 < 0) { const char* e = getenv("NVFI_RK2_X6"); x6 = e ? atoi(e) : 1; }
         const int vf = f->vel_fp16 & 3;
-        if ((x6 && split && !(train && (f->vel_fp16 & 4)) && (train || vf == 0 || vf == 3)) || (!train && vf == 3)) {
+        if ((x6 && !(train && (f->vel_fp16 & 4)) && (train || vf == 0 || vf == 3)) || (!train && vf == 3)) {
             X6UniArgs xa; xa.r = ra; xa.img = cached ? FC.vel_x6 : P.x6img;
             if (!cached && launch_pack_x6(f->vW, P.x6img, st)) return 1;
             if (launch_rk2_x6_uni(xa, N, train, st)) return 1;
@@ -1550,13 +1543,13 @@ static int render_fwd_impl(const nvfi_field_desc* f, int64_t R, const float* ray
             h.zst = P.zst; h.x0st = P.x0st; h.rec = P.rec; h.cap = N; h.cap_tiles = P.cap_tiles;
             for (int s = 0; s < nsteps; ++s) { h.dt[s] = dts[s]; h.tcur[s] = tcs[s]; }
             if (launch_rk2_inf16(f, h, true, st, train)) return 1;
-        } else if (split) {
+        } else {
             SplitUniArgs ua; ua.r = ra;
             if (cached) x4f_pointers(FC.vel_x4f, ua.f4);
             else if (pack_vel_x4_fwd(VW, P.vel_x4, ua.f4, st)) return 1;
             for (int l = 0; l < 6; ++l) ua.bv[l] = VW.b[l];
             if (launch_rk2_split_uni(ua, N, train, st)) return 1;
-        } else if (launch_rk2_fwd(ra, N, true, train, st)) return 1;
+        }
     }
     // density
     DensityArgs da; memset(&da, 0, sizeof(da));
@@ -1582,7 +1575,7 @@ static int render_fwd_impl(const nvfi_field_desc* f, int64_t R, const float* ray
     {
         ProfScope ps(PK_APP_FWD, st);
         // train: the plane-product features of the masked samples from their own gather kernel (parked in gg, which only the backward writes)
-        if (train && f->Ca == 48 && app_feat_split()) {
+        if (train && f->Ca == 48) {
             OgArgs oa; memset(&oa, 0, sizeof(oa));
             oa.f = *f; oa.count = P.counters + 1; oa.list = P.mlist; oa.xw = P.xw; oa.tn = tn; oa.sched = sched; oa.og = P.gg;
             if (launch_app_feat(oa, N, st)) return 1;
@@ -1700,7 +1693,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         }
     } else if (want_aplanes) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
-        sa.f = *f; sa.count = P.counters + 1; sa.list = P.mlist; sa.xw = P.xw; sa.tn = tn; sa.sched = sched; sa.gg = P.gg; sa.g = det_mode() ? gdet : *grads; sa.plane_mask = scatter_mask();
+        sa.f = *f; sa.count = P.counters + 1; sa.list = P.mlist; sa.xw = P.xw; sa.tn = tn; sa.sched = sched; sa.gg = P.gg; sa.g = det_mode() ? gdet : *grads; sa.plane_mask = 63;
         hipStream_t ss = st;
         if (side) { HIPCK(hipEventRecord(g_side.fork[0], st)); HIPCK(hipStreamWaitEvent(g_side.s, g_side.fork[0], 0)); ss = g_side.s; forked = true; }
         ProfScope ps(PK_APP_SCATTER, ss);
@@ -1762,7 +1755,7 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
     } else if (nsteps > 0) { ProfScope ps(PK_DENSITY_BWD, st); hipLaunchKernelGGL(k_density_bwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, da); }
     if (!P.tiles && want_dplanes) {
         ScatterArgs sa; memset(&sa, 0, sizeof(sa));
-        sa.f = *f; sa.count = P.counters + 0; sa.list = P.vlist; sa.xw = P.xw; sa.tn = tn; sa.sched = sched; sa.gxpre = P.gxpre; sa.g = det_mode() ? gdet : *grads; sa.plane_mask = scatter_mask();
+        sa.f = *f; sa.count = P.counters + 0; sa.list = P.vlist; sa.xw = P.xw; sa.tn = tn; sa.sched = sched; sa.gxpre = P.gxpre; sa.g = det_mode() ? gdet : *grads; sa.plane_mask = 63;
         hipStream_t ss = st;
         if (side) { HIPCK(hipEventRecord(g_side.fork[1], st)); HIPCK(hipStreamWaitEvent(g_side.s, g_side.fork[1], 0)); ss = g_side.s; forked = true; }
         ProfScope ps(PK_DENSITY_SCATTER, ss);
@@ -1786,15 +1779,13 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         ra.nsteps = nsteps; ra.sched = sched;
         for (int s = 0; s < nsteps; ++s) { ra.dt[s] = dts[s]; ra.tcur[s] = tcs[s]; }
         ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles; ra.gxk = P.gxk;
-        static int split = -1;
-        if (split < 0) { const char* e = getenv("NVFI_RK2_SPLIT_BWD"); split = e ? atoi(e) : 1; }
         // NVFI_RK2_FUSE (default 1): vel_fuse.hip - the adjoint AND the four 128 x 128 weight gradients in one persistent kernel (no g_1..g_4
         // stash, no second pass over the z stash); 0: k_rk2_split_bwd + k_wgrad_ring8 over the full adjoint stash
         static int fuse = -1;
         if (fuse < 0) { const char* e = getenv("NVFI_RK2_FUSE"); fuse = e ? atoi(e) : 1; }
         float* vslabs = (fork2 || merge_wgrad) ? P.slabs2 : P.slabs;      // (merged launches: the render MLP's slabs in P.slabs are still live)
         int fused_nslab = 0;
-        if (split && fuse) {
+        if (fuse) {
             FuseBwdArgs fa; memset(&fa, 0, sizeof(fa));
             fa.r = ra; fa.slabs = vslabs; fa.layer_stride = (int64_t)NSLAB * SLAB_FLOATS; fa.slab_floats = SLAB_FLOATS;
             if (cached) { x4b_pointers(FC.vel_x4b, fa.t4); fa.imgT = FC.vel_x6t; }
@@ -1804,12 +1795,12 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
                 fa.imgT = P.x6imgT;
             }
             if (launch_rk2_fuse_bwd(fa, N, NSLAB, &fused_nslab, st)) return 1;
-        } else if (split) {   // vel_split.hip: same adjoint stash bit for bit
+        } else {              // vel_split.hip (k_rk2_bwd of vel.hip, NVFI_RK2_SPLIT_BWD=0 - the same adjoint stash bit for bit - was retired in round 6)
             SplitBwdArgs ba; ba.r = ra;
             if (cached) x4b_pointers(FC.vel_x4b, ba.t4);
             else if (pack_vel_x4_bwd(VW, P.vel_x4b, ba.t4, st)) return 1;
             if (launch_rk2_split_bwd(ba, N, st)) return 1;
-        } else if (launch_rk2_bwd(ra, N, st)) return 1;
+        }
         if (launch_vel_wgrad(P.zst, P.x0st, P.gst, P.counters + 3, (int)P.cap_tiles, 2 * nsteps, BM_SILU, vslabs, NSLAB,
                              grads->vW, grads->vb, 1.f, st, fused_nslab, merge_wgrad ? &mlp_wj : nullptr, merge_wgrad ? &mlp_rj : nullptr)) return 1;
     }

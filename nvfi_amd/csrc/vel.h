@@ -40,5 +40,4 @@ struct Rk2Args {
 };
 
 int launch_vel_eval(const VelEvalArgs& a, hipStream_t st);
-int launch_rk2_fwd(const Rk2Args& a, int64_t cap_samples, bool uniform, bool stash, hipStream_t st);
-int launch_rk2_bwd(const Rk2Args& a, int64_t cap_samples, hipStream_t st);
+int launch_rk2_fwd(const Rk2Args& a, int64_t cap_samples, bool uniform, hipStream_t st);

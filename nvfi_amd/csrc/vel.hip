@@ -39,7 +39,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_vel_eval(VelEvalArgs a) {
 // ---------------------------------------------------------------- RK2 forward
 // UNIFORM: every sample takes the same (dt_s, t_s) sequence (render path, t is a per-call scalar);
 // otherwise per-point t/base (integrate_pos API, PDE prefilter) with a workgroup-uniform loop.
-template <bool UNIFORM, bool STASH>
+// (the stash-writing form of the training warp and the adjoint k_rk2_bwd that stood here were retired in round 6: vel_split.hip / vel_x6.hip /
+// vel_fuse.hip own the training path; this kernel serves the fp32 escape of integrate_pos / compute_alpha and the band re-evaluation)
+template <bool UNIFORM>
 __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_fwd(Rk2Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lds_w = lds; float* lds_b = lds + LDS_W_FLOATS;
@@ -71,15 +73,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_fwd(Rk2Args a) {
             dt = off > 0.f ? m : (off < 0.f ? -m : 0.f);
         }
         const bool live = active && (UNIFORM || fabsf(off) > 0.f);
-        float* zst1 = nullptr; float* zst2 = nullptr; float* x0s1 = nullptr; float* x0s2 = nullptr;
-        if (STASH) {
-            size_t e1 = ((size_t)(2 * s) * a.cap_tiles + tile), e2 = ((size_t)(2 * s + 1) * a.cap_tiles + tile);
-            zst1 = a.zst + e1 * (VEL_Z_REGS * REGF); zst2 = a.zst + e2 * (VEL_Z_REGS * REGF);
-            x0s1 = a.x0st + e1 * (VEL_X0_REGS * REGF); x0s2 = a.x0st + e2 * (VEL_X0_REGS * REGF);
-        }
         float o4[4], w1[6], w2[6], v1[3], v2[3];
         // v1 = vel(x, t)
-        velnet_forward<1, STASH>(a.Wv, lds_w, lds_b, lane, make_float4(x, y, z, tcur), zst1, x0s1, o4);
+        velnet_forward<1>(a.Wv, lds_w, lds_b, lane, make_float4(x, y, z, tcur), nullptr, nullptr, o4);
         gather6(o4, h, w1);
         vel_from_w(w1, x, y, z, v1);
         const bool g1 = gated_out(a.f, x, y, z);
@@ -88,21 +84,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_fwd(Rk2Args a) {
         const float hdt = 0.5f * dt;
         const float px = x - hdt * v1[0], py = y - hdt * v1[1], pz = z - hdt * v1[2];
         const float tm = tcur - hdt;
-        velnet_forward<1, STASH>(a.Wv, lds_w, lds_b, lane, make_float4(px, py, pz, tm), zst2, x0s2, o4);
+        velnet_forward<1>(a.Wv, lds_w, lds_b, lane, make_float4(px, py, pz, tm), nullptr, nullptr, o4);
         gather6(o4, h, w2);
         vel_from_w(w2, px, py, pz, v2);
         const bool g2 = gated_out(a.f, px, py, pz);
         if (g2) { v2[0] = v2[1] = v2[2] = 0.f; }
         const float nx = x - dt * v2[0], ny = y - dt * v2[1], nz = z - dt * v2[2];
         const bool rej = a.f.gate_sur && gated_out(a.f, nx, ny, nz);   // tensorf_keyframe.py:603-605
-        if (STASH && active && h == 0) {
-            float* rc = a.rec + (size_t)s * RK_NF * a.cap + i;
-            rc[0 * a.cap] = x; rc[1 * a.cap] = y; rc[2 * a.cap] = z;
-            rc[3 * a.cap] = px; rc[4 * a.cap] = py; rc[5 * a.cap] = pz;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { rc[(6 + k) * a.cap] = w1[k]; rc[(12 + k) * a.cap] = w2[k]; }
-            rc[18 * a.cap] = __int_as_float((g1 ? 1 : 0) | (g2 ? 2 : 0) | (rej ? 4 : 0));
-        }
         if (live && !rej) { x = nx; y = ny; z = nz; }
         if (!UNIFORM) {
             if (live) { off = off - dt; tcur = tcur - dt; }
@@ -114,83 +102,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_rk2_fwd(Rk2Args a) {
     }
 }
 
-// ---------------------------------------------------------------- RK2 adjoint (render backward)
-__global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_bwd(Rk2Args a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int count = *a.count;
-    if ((int)(blockIdx.x * WG_SAMPLES) >= count) return;
-    FragPipe pipe; pipe.init(lds);
-    pipe.issue(a.Wv.t[5], VEL_T5);
-    pipe.cur = 1; pipe.commit();          // first fragment into buffer 0
-    const int tile = blockIdx.x * 4 + wave_id();
-    const int i = tile * TILE + (lane & 31);
-    const bool active = i < count;
-    float4 gin = active ? a.gxk[a.list[i]] : zero4();     // upstream gradient of the warped position, stored per sample
-    float g3[3] = {gin.x, gin.y, gin.z};
-#pragma unroll 1
-    for (int s = a.nsteps - 1; s >= 0; --s) {
-        const float dt = RK_DT(a, s), tcur = RK_TC(a, s);
-        const float* rc = a.rec + (size_t)s * RK_NF * a.cap + (active ? i : 0);
-        const int flags = active ? __float_as_int(rc[18 * a.cap]) : 7;
-        const bool g1 = flags & 1, g2 = flags & 2, rej = flags & 4;
-        const size_t e1 = ((size_t)(2 * s) * a.cap_tiles + tile), e2 = ((size_t)(2 * s + 1) * a.cap_tiles + tile);
-        // The two network evaluations of the step are walked in reverse by ONE loop body (e = 1: v2 = vel(pmid, tmid),
-        // x_new = x - dt*v2;  e = 0: v1 = vel(x, t), pmid = x - dt/2*v1); records are re-read around the MLP pass
-        // instead of being kept live - the two 64-register adjoint arrays need the room.
-        float gacc[3] = {0.f, 0.f, 0.f};        // gpm after e=1, then + gx1
-        float gup[3] = {g3[0], g3[1], g3[2]};   // upstream of the evaluation being processed
-#pragma unroll 1
-        for (int e = 1; e >= 0; --e) {
-            const int po = e ? 3 : 0, wo = e ? 12 : 6;
-            const float coef = e ? -dt : -0.5f * dt;
-            const float te = e ? tcur - 0.5f * dt : tcur;
-            const bool gate = e ? g2 : g1;
-            const size_t es = ((size_t)(2 * s + e) * a.cap_tiles + tile);
-            float p[3], w[6], gv[3], gw[6], r4[4], gloc[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) p[c] = active ? rc[(po + c) * a.cap] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) w[k] = active ? rc[(wo + k) * a.cap] : 0.f;
-            const bool on = active && !rej && !gate;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gv[c] = on ? coef * gup[c] : 0.f;
-            gw[0] = gv[0]; gw[1] = gv[1]; gw[2] = gv[2];
-            gw[3] = p[2] * gv[1] - p[1] * gv[2];
-            gw[4] = -p[2] * gv[0] + p[0] * gv[2];
-            gw[5] = p[1] * gv[0] - p[0] * gv[1];
-            gloc[0] = -w[5] * gv[1] + w[4] * gv[2];
-            gloc[1] = w[5] * gv[0] - w[3] * gv[2];
-            gloc[2] = -w[4] * gv[0] + w[3] * gv[1];
-            scatter6(gw, h, r4);
-            float ge[16];
-            velnet_backward_p<1>(a.Wv, pipe, lane, r4, a.zst + es * (VEL_Z_REGS * REGF), a.gst + es * (VEL_G_REGS * REGF), ge, a.Wv.t[5], VEL_T5);
-            float x0[16];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) p[c] = active ? rc[(po + c) * a.cap] : 0.f;
-            vel_encode_slots(make_float4(p[0], p[1], p[2], te), h, x0);
-            const float4 gq = vel_encode_bwd(ge, x0, h);
-            gloc[0] += gq.x; gloc[1] += gq.y; gloc[2] += gq.z;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { gacc[c] += gloc[c]; gup[c] = gloc[c]; }
-        }
-        float gpm[3] = {gacc[0], gacc[1], gacc[2]}, gx1[3] = {0.f, 0.f, 0.f};
-        if (active && !rej) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g3[c] = g3[c] + gpm[c] + gx1[c];
-        }
-    }
-}
-
 // ---------------------------------------------------------------- host-side helpers
 int ensure_lds_attrs() {
     static bool done = false;
     if (done) return 0;
     HIPCK(hipFuncSetAttribute((const void*)k_vel_eval, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_rk2_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_rk2_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_rk2_fwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
-    HIPCK(hipFuncSetAttribute((const void*)k_rk2_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE2_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_rk2_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
+    HIPCK(hipFuncSetAttribute((const void*)k_rk2_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ENGINE_LDS_BYTES));
     done = true;
     return 0;
 }
@@ -203,24 +121,14 @@ int launch_vel_eval(const VelEvalArgs& a, hipStream_t st) {
     LAUNCHCK();
     return 0;
 }
-int launch_rk2_fwd(const Rk2Args& a, int64_t cap_samples, bool uniform, bool stash, hipStream_t st) {
+int launch_rk2_fwd(const Rk2Args& a, int64_t cap_samples, bool uniform, hipStream_t st) {
     if (ensure_lds_attrs()) return 1;
     int64_t nwg = (cap_samples + WG_SAMPLES - 1) / WG_SAMPLES;
     if (nwg <= 0) return 0;
     dim3 g((unsigned)nwg), b(WG_THREADS);
     ProfScope ps(uniform ? PK_RK2_FWD : PK_PDE_PREFILTER, st);
-    if (uniform && stash) hipLaunchKernelGGL((k_rk2_fwd<true, true>), g, b, ENGINE_LDS_BYTES, st, a);
-    else if (uniform) hipLaunchKernelGGL((k_rk2_fwd<true, false>), g, b, ENGINE_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((k_rk2_fwd<false, false>), g, b, ENGINE_LDS_BYTES, st, a);
-    LAUNCHCK();
-    return 0;
-}
-int launch_rk2_bwd(const Rk2Args& a, int64_t cap_samples, hipStream_t st) {
-    if (ensure_lds_attrs()) return 1;
-    int64_t nwg = (cap_samples + WG_SAMPLES - 1) / WG_SAMPLES;
-    if (nwg <= 0) return 0;
-    ProfScope ps(PK_RK2_BWD, st);
-    hipLaunchKernelGGL(k_rk2_bwd, dim3((unsigned)nwg), dim3(WG_THREADS), ENGINE2_LDS_BYTES, st, a);
+    if (uniform) hipLaunchKernelGGL((k_rk2_fwd<true>), g, b, ENGINE_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_rk2_fwd<false>), g, b, ENGINE_LDS_BYTES, st, a);
     LAUNCHCK();
     return 0;
 }

@@ -846,11 +846,7 @@ int launch_rk2_fuse_bwd(const FuseBwdArgs& a, int64_t cap_samples, int max_slabs
     if (x6 < 0) { const char* e = getenv("NVFI_FUSE_X6"); x6 = e ? atoi(e) : 1; }
     const bool use_x6 = x6 != 0 && a.imgT != nullptr;
     const int ncu = ncu_dev[dev];
-    // NVFI_FUSE_RESERVE=n (experiment): leave n CUs to the kernels of the other streams (a persistent workgroup owns its CU: 12 waves x 168 registers)
-    static int reserve = -1;
-    if (reserve < 0) { const char* e = getenv("NVFI_FUSE_RESERVE"); reserve = e ? atoi(e) : 0; }
-    int G = ncu - reserve < max_slabs ? ncu - reserve : max_slabs;
-    if (G < 1) G = 1;
+    int G = ncu < max_slabs ? ncu : max_slabs;           // one persistent workgroup per CU: 12 waves x 168 registers (leaving CUs to the other streams: no gain)
     if ((int64_t)G > tiles) G = (int)tiles;
     ProfScope ps(PK_RK2_BWD, st);
 #ifdef FUSE_TIMING

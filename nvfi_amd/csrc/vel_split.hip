@@ -423,7 +423,7 @@ int launch_rk2_split_uni(const SplitUniArgs& a, int64_t cap_samples, bool stash,
     ProfScope ps(PK_RK2_FWD, st);
     // NVFI_SPLIT_UNI_NT=1 (experiment): one tile per workgroup, output layer on the vector pipe
     static int unt = -1;
-    if (unt < 0) { const char* e = getenv("NVFI_SPLIT_UNI_NT"); unt = e ? atoi(e) : 2; }
+    if (unt < 0) unt = 2;      // (the NVFI_SPLIT_UNI_NT / _VOUT / _BWD_NT / NVFI_SPLIT_NT / _VOUT sweep knobs of rounds 3-4 were retired in round 6: these are the swept optima)
     if (unt == 1) {
         const dim3 g1((unsigned)tiles), b1(WG_THREADS);
         if (stash) hipLaunchKernelGGL((k_rk2_split_uni<1, true, true>), g1, b1, SPLIT_VOUT_LDS_BYTES(1), st, a);
@@ -437,7 +437,7 @@ int launch_rk2_split_uni(const SplitUniArgs& a, int64_t cap_samples, bool stash,
     // gather / scatter kernels of the other chains no longer fit beside its two waves per SIMD, and the three-stream step gains nothing
     // (5.04 against 5.07 ms): off by default, where it is the numbers of k_rk2_fwd<true, STASH> bit for bit
     static int vout = -1;
-    if (vout < 0) { const char* e = getenv("NVFI_SPLIT_UNI_VOUT"); vout = e ? atoi(e) : 0; }
+    if (vout < 0) vout = 0;
     if (vout) {
         if (stash) hipLaunchKernelGGL((k_rk2_split_uni<2, true, true>), g, b, SPLIT_VOUT_LDS_BYTES(2), st, a);
         else hipLaunchKernelGGL((k_rk2_split_uni<2, false, true>), g, b, SPLIT_VOUT_LDS_BYTES(2), st, a);
@@ -623,7 +623,7 @@ int launch_rk2_split_bwd(const SplitBwdArgs& a, int64_t cap_samples, hipStream_t
     if (tiles <= 0) return 0;
     ProfScope ps(PK_RK2_BWD, st);
     static int nt = -1;
-    if (nt < 0) { const char* e = getenv("NVFI_SPLIT_BWD_NT"); nt = e ? atoi(e) : 2; }
+    if (nt < 0) nt = 2;
     if (nt == 1) hipLaunchKernelGGL(k_rk2_split_bwd<1>, dim3((unsigned)tiles), dim3(WG_THREADS), SPLIT_BWD_LDS_BYTES(1), st, a);
     else hipLaunchKernelGGL(k_rk2_split_bwd<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(WG_THREADS), SPLIT_BWD_LDS_BYTES(2), st, a);
     LAUNCHCK();
@@ -640,8 +640,7 @@ int launch_rk2_split(const SplitArgs& a, int64_t cap_points, int wide, hipStream
         // NVFI_SPLIT_NT: tiles per workgroup of the wide launch.  With the output layer on the vector pipe one tile is the default: alone it is
         // 1.5 % slower than two (1.32 against 1.30 ms; every weight load feeds one tile), but its 130-register workgroups leave the render
         // chains' kernels more room beside it - the three-stream step is 1 % faster (5.04 against 5.10 ms).  NVFI_SPLIT_VOUT=0: matrix pipe.
-        const char* e = getenv("NVFI_SPLIT_NT"); nt = e ? atoi(e) : 1;
-        e = getenv("NVFI_SPLIT_VOUT"); vout = e ? atoi(e) : 1;
+        nt = 1; vout = 1;
         HIPCK(hipFuncSetAttribute((const void*)k_rk2_split<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_VOUT_LDS_BYTES(4)));
         HIPCK(hipFuncSetAttribute((const void*)k_rk2_split<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_VOUT_LDS_BYTES(4)));
     }

@@ -439,8 +439,8 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6_uni(X6Un
 // repeats are bit-identical at two workgroups per CU (tests/test_gpu_x6.py: 8 x 524 288 points; the render-warp determinism tests), and
 // the speed is the same (the epilogues hide behind the other workgroup's MFMAs).  The mechanism is NOT understood: none of the pieces
 // reproduces in isolation (tools/probes/mfma_hazard_probe.hip, nine experiments incl. packed fp32 beside this MFMA pattern at 1, 2 and 4
-// waves per SIMD: all clean).  NVFI_X6_ONE_WG=1 asks for more than half of the CU's LDS and so keeps a second workgroup off the CU - the
-// other configuration known to be clean (about 7 % of the step slower).
+// waves per SIMD: all clean).  Asking for more than half of the CU's LDS keeps a second workgroup off the CU - the other
+// configuration known to be clean (about 7 % of the step slower; the switch for it, NVFI_X6_ONE_WG, was retired in round 6).
 #define X6_ONE_WG_LDS (84 * 1024)
 // (per device: hipFuncSetAttribute applies to the device that is current - one process per GPU never sees a second one, a host that drives
 // several devices from one process does)
@@ -449,36 +449,22 @@ static int x6_set_lds(K kernel) {
     HIPCK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6_ONE_WG_LDS));
     return 0;
 }
-static int x6_tiles_per_wg() {
-    static int nt = -1;
-    if (nt < 0) { const char* e = getenv("NVFI_X6_NT"); nt = e ? atoi(e) : 1; }      // 1 (default) | 2 | 4: one wave per tile (vel_x6w.hip, prefilter / integrate_pos only)
-    return nt;
-}
-static size_t x6_lds_nt1() {
-    static int one = -1;
-    if (one < 0) { const char* e = getenv("NVFI_X6_ONE_WG"); one = e ? atoi(e) : 0; }
-    return one ? (size_t)X6_ONE_WG_LDS : (size_t)X6_LDS_BYTES(1);
-}
+static size_t x6_lds_nt1() { return (size_t)X6_LDS_BYTES(1); }      // (NVFI_X6_ONE_WG=1 asked for X6_ONE_WG_LDS here: retired in round 6, the fence in build.py is the fix)
 
 int launch_rk2_x6_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipStream_t st) {
     const int64_t tiles = (cap_samples + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
     static DeviceOnce once;
-    if (once.run([] { return (x6_set_lds(k_rk2_x6_uni<1, true>) || x6_set_lds(k_rk2_x6_uni<1, false>) || x6_set_lds(k_rk2_x6_uni<2, true>) || x6_set_lds(k_rk2_x6_uni<2, false>)) ? 1 : 0; })) return 1;
+    if (once.run([] { return (x6_set_lds(k_rk2_x6_uni<1, true>) || x6_set_lds(k_rk2_x6_uni<1, false>)) ? 1 : 0; })) return 1;
     ProfScope ps(PK_RK2_FWD, st);
     // NVFI_X6W_UNI: 1 (default) eval renders on the one-wave-per-tile kernel of vel_x6w.hip (bit-identical; an 800 x 800 test frame 134 -> 120 ms),
     // 2 training renders too (same stash and records; no faster there: 0.35 against 0.37 ms, the stash stores are not hidden), 0 neither
     static int wuni = -1;
     if (wuni < 0) { const char* e = getenv("NVFI_X6W_UNI"); wuni = e ? atoi(e) : 1; }
     if ((wuni >= 1 && !stash) || wuni >= 2) return launch_rk2_x6w_uni(a, cap_samples, stash, st);
-    const unsigned two = (unsigned)((tiles + 1) / 2);
-    if (x6_tiles_per_wg() == 1) {
-        if (stash) hipLaunchKernelGGL((k_rk2_x6_uni<1, true>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
-        else hipLaunchKernelGGL((k_rk2_x6_uni<1, false>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
-    } else {
-        if (stash) hipLaunchKernelGGL((k_rk2_x6_uni<2, true>), dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);
-        else hipLaunchKernelGGL((k_rk2_x6_uni<2, false>), dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);
-    }
+    // (round 6: the two-tiles-per-workgroup variants - NVFI_X6_NT=2 - are retired: never a default, 8 % slower)
+    if (stash) hipLaunchKernelGGL((k_rk2_x6_uni<1, true>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
+    else hipLaunchKernelGGL((k_rk2_x6_uni<1, false>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
     LAUNCHCK();
     return 0;
 }
@@ -487,8 +473,7 @@ int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st) {
     const int64_t tiles = (cap_points + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
     static DeviceOnce once;
-    if (once.run([] { return (x6_set_lds(k_rk2_x6<1>) || x6_set_lds(k_rk2_x6<2>)) ? 1 : 0; })) return 1;
-    const int nt = x6_tiles_per_wg();
+    if (once.run([] { return x6_set_lds(k_rk2_x6<1>) ? 1 : 0; })) return 1;
     // default since round 5 (late): one wave per tile, the epilogue in the MFMAs' VALU slots (vel_x6w.hip; bit-identical results, the bench
     // prefilter 0.89 -> 0.83 ms).  NVFI_X6W=0: the four-waves-per-tile kernel below
     static int x6w = -1;
@@ -500,10 +485,8 @@ int launch_rk2_x6(const X6Args& a, int64_t cap_points, hipStream_t st) {
     // tile wins (0.80 against 0.89 ms).  train_segm's integrate_pos (3 000-30 000 occupied points, 40-60 evaluations deep): 1.03 -> 0.46 ms.
     static int min_tiles = -1;
     if (min_tiles < 0) { const char* e = getenv("NVFI_X6W_MIN_TILES"); min_tiles = e ? atoi(e) : 4096; }
-    if ((x6w && tiles > min_tiles) || nt == 4) return launch_rk2_x6w(a, cap_points, st);
-    const unsigned two = (unsigned)((tiles + 1) / 2);
-    if (nt == 1) hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
-    else hipLaunchKernelGGL(k_rk2_x6<2>, dim3(two), dim3(WG_THREADS), X6_ONE_WG_LDS, st, a);
+    if (x6w && tiles > min_tiles) return launch_rk2_x6w(a, cap_points, st);
+    hipLaunchKernelGGL(k_rk2_x6<1>, dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
     LAUNCHCK();
     return 0;
 }

@@ -2,7 +2,7 @@
 //
 //   G[pA][pB] = sum over sample tiles of A[pA][j] * B'[pB][j]        (p-space rows of the stash images, B' = bmode(B, B2))
 //
-// Same contraction, slab format and reduce kernel as k_wgrad (engine.hip, kept as NVFI_WGRAD=engine); what changes is how the operands
+// Same contraction, slab format and reduce kernel as the k_wgrad of rounds 1-2 (retired in round 6); what changes is how the operands
 // reach the MFMAs and how the work is shared.  k_wgrad loads both stash images of an item straight into the registers of ONE wave per
 // SIMD (two alternating operand sets, the A image read by both column-part workers) and gives every job its own workers.  Here:
 //   * ONE workgroup of EIGHT waves per CU (two per SIMD: one wave's activation / address / DMA-issue instructions run under the
@@ -273,15 +273,12 @@ static int ring_slot_bytes(const WgradJob& J) {
 // on return (bj / br are updated; the caller launches k_wgrad_reduce over br).
 int launch_wgrad_ring(WgradJobs& bj, ReduceJobs& br, hipStream_t st) {
     if (bj.n == 0) return 0;
-    static int ncu = 0, want = 0, chaining = 1;
+    static int ncu = 0, want = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t prop;
         ncu = 256;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        const char* b = getenv("NVFI_WGRAD_WGS");
-        want = (b && atoi(b) > 0) ? atoi(b) : ncu;              // workgroups of a launch: one per CU
-        const char* c = getenv("NVFI_WGRAD_CHAIN");
-        chaining = c ? atoi(c) : 1;
+        want = ncu;                                             // workgroups of a launch: one per CU (192 of 256 measured +1.5 % in round 3, within noise since)
         HIPCK(hipFuncSetAttribute((const void*)k_wgrad_ring8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     int G = want, lds_need = 68 * 1024;                         // (the end-of-job exchange of the two sample halves needs 66.5 KB)
@@ -305,20 +302,19 @@ int launch_wgrad_ring(WgradJobs& bj, ReduceJobs& br, hipStream_t st) {
         J.nslab = G;
     }
     // chain consecutive jobs of one shape whose slabs a reduce job adds into the same gradient (slabs + slabs2): one slab for both
-    if (chaining)
-        for (int i = 0; i + 1 < bj.n; ++i) {
-            const WgradJob &J0 = bj.j[i], &J1 = bj.j[i + 1];
-            if (J0.a_regs != J1.a_regs || J0.b_regs != J1.b_regs || (ch.c[i] & 1)) continue;
-            bool pair = false;
-            for (int k = 0; k < br.n; ++k) pair = pair || (br.j[k].slabs == J0.slabs && br.j[k].slabs2 == J1.slabs);
-            if (!pair) continue;
-            ch.c[i] |= 2; ch.c[i + 1] |= 1;
-            const float* first = J0.slabs;
-            for (int k = 0; k < br.n; ++k) {       // every reader of the first slab set (weights: slabs + slabs2; bias: slabs alone) reads the second
-                ReduceJob& Q = br.j[k];
-                if (Q.slabs == first) { Q.slabs = J1.slabs; Q.nslab = G; if (Q.slabs2 == J1.slabs) { Q.slabs2 = nullptr; Q.nslab2 = 0; } }
-            }
+    for (int i = 0; i + 1 < bj.n; ++i) {
+        const WgradJob &J0 = bj.j[i], &J1 = bj.j[i + 1];
+        if (J0.a_regs != J1.a_regs || J0.b_regs != J1.b_regs || (ch.c[i] & 1)) continue;
+        bool pair = false;
+        for (int k = 0; k < br.n; ++k) pair = pair || (br.j[k].slabs == J0.slabs && br.j[k].slabs2 == J1.slabs);
+        if (!pair) continue;
+        ch.c[i] |= 2; ch.c[i + 1] |= 1;
+        const float* first = J0.slabs;
+        for (int k = 0; k < br.n; ++k) {       // every reader of the first slab set (weights: slabs + slabs2; bias: slabs alone) reads the second
+            ReduceJob& Q = br.j[k];
+            if (Q.slabs == first) { Q.slabs = J1.slabs; Q.nslab = G; if (Q.slabs2 == J1.slabs) { Q.slabs2 = nullptr; Q.nslab2 = 0; } }
         }
+    }
     hipLaunchKernelGGL(k_wgrad_ring8, dim3(G), dim3(512), (size_t)lds_need, st, bj, ch);
     LAUNCHCK();
     return 0;

@@ -213,43 +213,14 @@ def test_deterministic_mode():
     assert res["worst_relerr_vs_reference"] < 5e-4, res["worst_relerr_vs_reference"]
 
 
-def test_pde_column_kernels_still_match_goldens():
-    """NVFI_PDE_JET=0 keeps the round-1 column-parallel Jacobian kernels of pde.hip (one workgroup per (tile, column)); they must keep
-    passing the functorch-Jacobian / loss / gradient goldens next to the fused five-column kernels of pde_jet.hip (the default)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, NVFI_PDE_JET="0")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_fullsize_chessboard.py"),
-                        "-q", "-x", "-m", "gpu", "-k", "pde"], env=env, cwd=root, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
-
-
-def test_engine_rk2_kernels_still_match_goldens():
-    """NVFI_RK2_SPLIT=0 / NVFI_RK2_SPLIT_BWD=0 / NVFI_PDE_PREFILTER=engine32 keep k_rk2_fwd / k_rk2_bwd of vel.hip (one tile per wave, weights
-    staged in LDS) for the render warp, its adjoint and the PDE prefilter instead of the feature-split kernels of vel_split.hip (the default): the same goldens must pass."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, NVFI_RK2_SPLIT="0", NVFI_RK2_SPLIT_BWD="0", NVFI_PDE_PREFILTER="engine32")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_fullsize_chessboard.py"),
-                        os.path.join(root, "tests", "test_gpu_training_loop.py"), "-q", "-x", "-m", "gpu"], env=env, cwd=root, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
-
-
-@pytest.mark.parametrize("env", [dict(NVFI_WGRAD="engine"), dict(NVFI_WGRAD_CHAIN="0"), dict(NVFI_BWD_FORK="0"), dict(NVFI_SCATTER="lds"),
-                                 dict(NVFI_APP_FEAT="0"), dict(NVFI_SPLIT_VOUT="0", NVFI_SPLIT_NT="2"), dict(NVFI_SPLIT_UNI_VOUT="1"), dict(NVFI_RK2_FUSE="0"), dict(NVFI_PDE_FUSE="0"), dict(NVFI_PDE_X4="0")],
-                         ids=["wgrad_engine", "wgrad_no_chain", "no_bwd_fork", "scatter_lds", "app_gather_in_kernel", "prefilter_output_layer_on_mfma",
-                              "render_warp_output_layer_on_valu", "rk2_adjoint_and_wgrad_unfused", "pde_adjoint_and_wgrad_unfused", "pde_stash_row_major"])
+@pytest.mark.parametrize("env", [dict(NVFI_BWD_FORK="0"), dict(NVFI_SCATTER="lds"), dict(NVFI_RK2_FUSE="0"), dict(NVFI_PDE_FUSE="0")],
+                         ids=["no_bwd_fork", "scatter_lds", "rk2_adjoint_and_wgrad_unfused", "pde_adjoint_and_wgrad_unfused"])
 def test_round3_switches_keep_the_goldens(env):
-    """the alternatives of the round-3 defaults - the register-operand weight-gradient kernel k_wgrad instead of k_wgrad_ring8, un-chained value /
-    tangent jobs in the ring kernel, the keyframe backward on one stream instead of the forked density half, the LDS read-add-write tile
-    scatter instead of the MFMA one, the appearance plane gather inside k_app_fwd instead of k_app_feat, the prefilter's 128 -> 6 output layer on the
-    matrix pipe (two-tile workgroups) instead of the vector pipe, and the opt-in vector-pipe output layer of the render warp - under the gradient goldens"""
+    """the alternatives that are still shipped beside the defaults - the keyframe backward on one stream instead of the forked density half, the LDS
+    read-add-write tile scatter instead of the MFMA one, and the unfused adjoints (k_rk2_split_bwd / k_pde_jet_bwd with k_wgrad_ring8 over the full
+    adjoint stash: the A/B references of the persistent kernels) - under the gradient goldens.  (Round 6 retired the other switches of rounds 1-4
+    with their kernels: the register-operand k_wgrad, the column-parallel Jacobian kernels, the one-tile-per-wave RK2 kernels with their adjoint,
+    and the sweep knobs of the split kernels - INTEGRATION.md section 4 keeps the list.)"""
     import os
     import subprocess
     import sys

@@ -32,7 +32,7 @@ def _fields():
 @pytest.mark.parametrize("nsteps", [1, 4, 10])
 def test_x6_integrate_pos_is_as_accurate_as_the_fp32_kernels(nsteps):
     from x6_check import integrate64
-    N = 1 << 16
+    N = (1 << 16) if nsteps == 1 else ((1 << 14) if nsteps == 4 else (1 << 13))      # (the float64 reference runs in numpy on the host: 2 * nsteps evaluations per point)
     g = torch.Generator(device="cuda").manual_seed(3)
     for name, model in _fields():
         f = model.nvfi
@@ -152,12 +152,12 @@ def _run(tmp_path, mode, extra=(), n=262144, **switches):
     return np.load(out)
 
 
-@pytest.mark.parametrize("n,extra,nt", [(1000000, (), 0), (1000000, (), 1), (262144, ("--bench",), 0), (262144, ("--bench",), 1), (262144, ("--bench",), 2), (37, (), 0), (1000, (), 2)])
+@pytest.mark.parametrize("n,extra,nt", [(1000000, (), 0), (1000000, (), 1), (262144, ("--bench",), 0), (262144, ("--bench",), 1), (37, (), 0), (1000, (), 1)])
 def test_x6_prefilter_keeps_the_fp32_set(tmp_path, n, extra, nt):
     """both prefilters decide `alpha >= alphaMask_thres` on positions that differ by rounding (another summation order of the same fp32
     products): a point would have to sit within ~1e-7 of the threshold to flip - at most a handful among 10^6"""
-    # nt = 0: the default one-wave-per-tile kernel (vel_x6w.hip); 1 / 2: the four-waves-per-tile kernels with one / two tiles per workgroup
-    sw = dict(NVFI_X6W=1, NVFI_X6W_MIN_TILES=0) if nt == 0 else dict(NVFI_X6W=0, NVFI_X6_NT=nt)
+    # nt = 0: the one-wave-per-tile kernel (vel_x6w.hip) at every size; 1: the four-waves-per-tile kernel (round 6: the default up to 4096 tiles)
+    sw = dict(NVFI_X6W=1, NVFI_X6W_MIN_TILES=0) if nt == 0 else dict(NVFI_X6W=0)
     a, b = _run(tmp_path, "fp32", extra, n), _run(tmp_path, "x6", extra, n, **sw)
     for name in ("A", "B", "cfg1") + (("bench",) if extra else ()):
         ka, kb = a[f"{name}:kept"], b[f"{name}:kept"]

@@ -34,7 +34,6 @@ NVFI_MASK_FP16=1 NVFI_VEL_FP16=1 $B0 --workload segm --no-cpu-baseline > $OUT/${
 $B0 --no-extras --graph off --no-cpu-baseline --rays 256 --pts 32768 > $OUT/${TAG}_bench_line_strong_shard_1of8.json 2>/dev/null
 NVFI_PDE_PREFILTER=fp16band $B0 --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_line_fp16band.json 2>/dev/null
 NVFI_PDE_PREFILTER=split16band $B0 --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_line_split16band.json 2>/dev/null
-NVFI_PDE_PREFILTER=engine32 NVFI_RK2_SPLIT=0 NVFI_RK2_SPLIT_BWD=0 $B0 --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_line_engine32.json 2>/dev/null
 python $REPO/tools/bench_extras.py eval_frame > $OUT/${TAG}_eval_frame.json 2>/dev/null
 # the reference's chunk loop for the same frame (2048-ray calls on the current stream), and the frame with the fp32 warp
 NVFI_EVAL_CHUNK=2048 NVFI_EVAL_STREAMS=1 python $REPO/tools/bench_extras.py eval_frame > $OUT/${TAG}_eval_frame_chunk2048.json 2>/dev/null
@@ -45,7 +44,6 @@ NVFI_RK2_X6=0 NVFI_PDE_PREFILTER=fp32 NVFI_FUSE_X6=0 NVFI_PDE_JET_X6=0 NVFI_INTE
 NVFI_FUSE_X6=0 $B0 --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_fuse_fp32.json 2>/dev/null
 NVFI_PDE_JET_X6=0 $B0 --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_jet_fp32.json 2>/dev/null
 $B0 --no-extras --graph on --no-cpu-baseline --rays 256 --pts 32768 > $OUT/${TAG}_bench_line_strong_shard_1of8_hipgraph.json 2>/dev/null
-NVFI_X6_ONE_WG=1 $B0 --no-extras --graph off --no-cpu-baseline > $OUT/${TAG}_bench_line_x6_one_wg.json 2>/dev/null
 fi
 # 1. kernel trace of the default bench command: per-kernel statistics of the whole run and of the profiled pass (after the marker)
 export NVFI_BENCH_CHILD=1
