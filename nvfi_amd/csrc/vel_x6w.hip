@@ -58,12 +58,14 @@ struct X6WEpi {                    // transient state of one pending epilogue
 // LAST (last hidden layer): no split - the activations go to LDS as floats (four float4 per tile, at u = 9, 17, 25, 33)
 template <int U, bool LAST>
 __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
+#ifndef X6W_PROBE_NO_SILU            // (timing probe: identity activation)
     if constexpr (U < 32) {
         constexpr int r = U >> 1;
         if constexpr ((U & 1) == 0) e.rr[r] = __builtin_amdgcn_exp2f(-1.44269504088896341f * v[r]);
         else e.rr[r] = __builtin_amdgcn_rcpf(1.f + e.rr[r]);
     }
     if constexpr (U >= 2 && U <= 32 && (U & 1) == 0) { constexpr int r = (U - 2) >> 1; v[r] = v[r] * e.rr[r]; }
+#endif
     if constexpr (LAST) {
         if constexpr (U >= 9 && U <= 33 && ((U - 9) & 7) == 0) {
             constexpr int k = (U - 9) >> 3;
@@ -73,6 +75,12 @@ __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& 
     } else {
         if constexpr (U >= 5 && U <= 36) {
             constexpr int p = (U - 5) >> 2, part = (U - 5) & 3;
+#ifdef X6W_PROBE_NO_SPLIT            // (timing probe: one instruction per pair instead of eleven)
+            if constexpr (part == 0) {
+                e.pk[0][p] = __builtin_amdgcn_perm(__float_as_uint(v[2 * p + 1]), __float_as_uint(v[2 * p]), 0x07060302u);
+                e.pk[1][p] = e.pk[0][p]; e.pk[2][p] = e.pk[0][p];
+            }
+#else
             if constexpr (part == 0) {
                 const unsigned ua = __float_as_uint(v[2 * p]), ub = __float_as_uint(v[2 * p + 1]);
                 e.pk[0][p] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
@@ -87,6 +95,7 @@ __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& 
                 const float sb = e.rr[2 * p + 1] - __uint_as_float(__float_as_uint(e.rr[2 * p + 1]) & 0xffff0000u);
                 e.pk[2][p] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(e.rr[2 * p]), 0x07060302u);
             }
+#endif
         }
         if constexpr (U == 22 || U == 37) {
             constexpr int k = U == 22 ? 0 : 1;
@@ -142,9 +151,15 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
 #endif
                 asm volatile("" : "+v"(c.W1), "+v"(c.W2), "+v"(c.W3));
             }
+#if defined(X6W_PROBE_QUARTER_LOADS)     // (timing probe: a quarter of the weight loads; the other ring slots keep what they hold)
+            if constexpr ((x & 3) == 0) { A1[x % X6W_RING] = c.W1[0]; A2[x % X6W_RING] = c.W2[0]; A3[x % X6W_RING] = c.W3[0]; }
+#elif defined(X6W_PROBE_LDS_A)           // (timing probe: the A operands from LDS - this wave's output buffer, garbage - instead of L1)
+            A1[x % X6W_RING] = c.ob[((x & 7) * 3 + 0) * 64]; A2[x % X6W_RING] = c.ob[((x & 7) * 3 + 1) * 64]; A3[x % X6W_RING] = c.ob[((x & 7) * 3 + 2) * 64];
+#else
             A1[x % X6W_RING] = c.W1[(x & 3) * 64]; A2[x % X6W_RING] = c.W2[(x & 3) * 64]; A3[x % X6W_RING] = c.W3[(x & 3) * 64];
+#endif
         }
-#ifndef X6W_PROBE_NO_EPILOGUE          // (timing probe: the MFMA stream alone)
+#ifndef X6W_PROBE_NO_EPILOGUE          // (timing probe; NOT the MFMA stream alone: without the epilogue the earlier tiles' MFMAs are dead code and go too)
         if constexpr (HAVE_PE) {
             if constexpr (KIND == 0) {                        // 12 slots: 4 micro-slots in the first two, 3 in the others
                 if constexpr (I < 2) x6w_micros<4 * I, 4, PE_LAST>(c, pv, e, pm2);
@@ -189,7 +204,12 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float
     float va[16], vb[16];
     {
         float x0[16];
+#ifdef X6W_PROBE_NO_ENC              // (timing probe: no sines / cosines)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x0[k] = q.x + (float)k * q.y;
+#else
         vel_encode_slots(q, c.h, x0);
+#endif
         if (STASH) stash_store<16>(x0st, c.lane, x0);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -245,6 +265,10 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float
     // ---- 128 -> 6: fp32 FMAs in velnet_x6's order (per row tile: a chain over its 16 activations, the two lane halves added, then the tiles in order)
 #pragma unroll
     for (int o = 0; o < 6; ++o) out6[o] = c.lb[128 * 5 + o];
+#ifdef X6W_PROBE_NO_OUT              // (timing probe: no output layer)
+    out6[0] += vb[0]; out6[1] += vb[5];
+    return;
+#endif
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         float zl[16];
