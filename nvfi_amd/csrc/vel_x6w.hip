@@ -143,9 +143,9 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
         constexpr int I = decltype(Ic)::value, s = I / 6, j = I % 6, en = E0 + s;
         if constexpr (KIND == 0) x6w_mfma<j, s == 0>(A1[en % X6W_RING], A2[en % X6W_RING], A3[en % X6W_RING], X0[s], a0, a1);
         else x6w_mfma<j, s == 0>(A1[en % X6W_RING], A2[en % X6W_RING], A3[en % X6W_RING], in[s], a0, a1);
-#ifdef X6W_PIN_MFMA                  // the MFMA first in its slot: without this the scheduler may put it last in one region and first in the next
+        // the MFMA first in its slot: left to itself the scheduler puts it last in one region and first in the next - two MFMAs back to back behind
+        // two epilogue slots in a row (round 6: -1.2 % per evaluation)
         __builtin_amdgcn_sched_barrier(0);
-#endif
         if constexpr (j == 5 && en + X6W_RING - 1 < X6W_ENTRIES) {
             constexpr int x = en + X6W_RING - 1;
             if constexpr ((x & 3) == 0) {
@@ -364,332 +364,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
 }
 
 
-// ================================================================ x6v: weight-stationary, four tiles per workgroup (round 6)
-// Probes (tools/x6w_probe.sh): in k_rk2_x6w every wave streams the whole 408 KB image per evaluation through the CU's vector-memory
-// path - four waves x 408 KB at 64 B per clock are as long as the evaluation's MFMAs, and the two only partly overlap.  Here the residency is
-// transposed: wave w keeps ITS 32 output rows of the current layer in 96 registers (a layer's image is exactly 4 waves x 96 registers) and the
-// workgroup's four point tiles pass under them, B operands from LDS (tile t's layer input, [K step][term][lane]; three ds_read_b128 per K step
-// through a four-deep register ring).  A slot = (layer, tile): 48 MFMAs (12 in layer 0); the epilogue of a slot - drain, SiLU, truncation split,
-// six 16-byte LDS writes: x6w's 38 micro-slots unchanged - rides under the MFMAs of the next slot and writes K steps 2w, 2w + 1 of ITS tile's
-// next-layer input in place (single buffer: one s_barrier at every slot end says "everybody has read tile t's input", after which the writes of
-// the next slot may land in it; the data a slot reads is at least one barrier old).  The next layer's weights replace the current ones K step
-// by K step during the layer's last slot.  Weight traffic through L1: 102 KB per wave and evaluation instead of 408.
-// Per output element the products and their order are x6_mm6's: results are bit-identical to k_rk2_x6 / k_rk2_x6w (tests/test_gpu_x6.py).
-// Wave w also owns tile w's points: encoder -> tile w's layer-0 input in LDS; the 128 -> 6 output layer from the four waves' layer-4
-// activations (floats in tile w's buffer); the RK2 glue.  All four tiles walk together: the RK2 loop runs as long as the workgroup's longest tile.
-#define X6V_BRING 4
-#define X6V_LA 3
-#if defined(X6V_PROBE_NO_BAR)          // (timing probes: races, garbage results)
-#define X6V_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif defined(X6V_PROBE_NO_BAR_NO_WAIT)
-#define X6V_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define X6V_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#endif
-
-#ifdef X6V_TIMING                     // shader-clock stamps at the slot boundaries of one evaluation of one wave (printed at the end of the kernel)
-__device__ unsigned long long x6v_ts[32];
-#define X6V_STAMP(c, k) do { if ((c).stamp) x6v_ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define X6V_STAMP(c, k) do { } while (0)
-#endif
-struct X6V {
-    int stamp;
-    x6w_gptr W[3];                 // per lane: term images + lane + this wave's row tile of layer 1 (entry 8 + 8 w)
-    const b8_t* tb;                // LDS: tile buffers + lane; tile t at [t * X6W_OB_H8]
-    b8_t* obw;                     // LDS: tb + this wave's two K steps (6 w * 64): epilogue target of tile t at [t * X6W_OB_H8]
-    b8_t* obf;                     // LDS: tb + this wave's four float4 rows (4 w * 64): layer-4 activations of tile t at [t * X6W_OB_H8]
-    const float* lb; const float4* w5l;
-    int lane, h, wv;
-};
-
-// global K step gk of an evaluation (0..135; x6w's entry numbering with the row tile taken out): which tile, which K step of its buffer
-__host__ __device__ constexpr int x6v_tile_of(int gk) { return gk < 8 ? gk / 2 : ((gk - 8) % 32) / 8; }
-__host__ __device__ constexpr int x6v_step_of(int gk) { return gk < 8 ? gk % 2 : (gk - 8) % 8; }
-template <int GK>
-__device__ __forceinline__ void x6v_bread(const X6V& c, b8_t (&B)[X6V_BRING][3]) {
-    constexpr int t = x6v_tile_of(GK), s = x6v_step_of(GK);
-    const b8_t* p = c.tb + t * X6W_OB_H8;
-    B[GK % X6V_BRING][0] = p[(s * 3 + 0) * 64]; B[GK % X6V_BRING][1] = p[(s * 3 + 1) * 64]; B[GK % X6V_BRING][2] = p[(s * 3 + 2) * 64];
-}
-
-// slot (layer L, tile T).  GK0: its first global K step.  pv / e / PT: the pending epilogue (previous slot's pre-activations, its tile);
-// nv: this slot's pre-activations.  A0: the wave's layer-0 rows (resident for the whole kernel); A: its rows of the current hidden layer.
-template <int L, int T, bool HAVE_PE, bool PE_LAST, int PT>
-__device__ __forceinline__ void x6v_slot(const X6V& c, const b8_t (&A0)[2][3], b8_t (&A)[8][3], b8_t (&B)[X6V_BRING][3], float (&pv)[16], X6WEpi& e,
-                                         float (&nv)[16], f32x16& bias) {
-    constexpr int NS = L == 0 ? 2 : 8;
-    constexpr int GK0 = L == 0 ? 2 * T : 8 + 32 * (L - 1) + 8 * T;
-    X6W ce;                                   // the view x6w's micro-slots write through: this wave's K steps / float rows of the pending slot's tile
-    ce.ob = (PE_LAST ? c.obf : c.obw) + PT * X6W_OB_H8;
-    f32x16 a0 = bias, a1;
-    x6w_for(std::make_integer_sequence<int, NS * 6>{}, [&](auto Ic) {
-        constexpr int I = decltype(Ic)::value, s = I / 6, j = I % 6, gk = GK0 + s;
-        if constexpr (L == 0) x6w_mfma<j, s == 0>(A0[s][0], A0[s][1], A0[s][2], B[gk % X6V_BRING], a0, a1);
-        else x6w_mfma<j, s == 0>(A[s][0], A[s][1], A[s][2], B[gk % X6V_BRING], a0, a1);
-#ifdef X6W_PIN_MFMA
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if constexpr (j == 5) {
-            if constexpr (gk + X6V_LA < X6W_ENTRIES) x6v_bread<gk + X6V_LA>(c, B);
-            // the layer's last slot hands its weight registers to the next layer (layer 4: to layer 1 of the next evaluation), K step by K step
-            if constexpr (L >= 1 && T == 3) {
-                constexpr int nl = L % 4 + 1;
-                const int off = ((nl - 1) * 32 + s) * 64;
-                A[s][0] = c.W[0][off]; A[s][1] = c.W[1][off]; A[s][2] = c.W[2][off];
-            }
-        }
-        if constexpr (HAVE_PE) {
-            if constexpr (L == 0) {                           // 12 slots: 4 micro-slots in the first two, 3 in the others
-                if constexpr (I < 2) x6w_micros<4 * I, 4, PE_LAST>(ce, pv, e, 0);
-                else x6w_micros<8 + 3 * (I - 2), 3, PE_LAST>(ce, pv, e, 0);
-            } else if constexpr (I < 38) x6w_micros<I, 1, PE_LAST>(ce, pv, e, 0);
-        }
-        if constexpr (I == 1 && T == 3 && L < 4) {            // the next layer's bias rows of this wave (behind the first MFMA, which has consumed this one's)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bias[r] = c.lb[(L + 1) * 128 + 32 * c.wv + (r & 3) + 8 * (r >> 2) + 4 * c.h];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    });
-#pragma unroll
-    for (int r = 0; r < 16; ++r) nv[r] = a1[r] + a0[r];
-    X6V_STAMP(c, 2 + (L == 0 ? T : 4 * L + T) * 1);
-    X6V_BAR();                                // every wave has read tile T's input; the pending epilogue's writes (another tile's buffer) have landed
-}
-
-// one evaluation for the workgroup's four tiles; this wave's tile is q, its six outputs come back in out6
-__device__ __forceinline__ void velnet_x6v(const X6V& c, const b8_t (&A0)[2][3], b8_t (&A)[8][3], const float4& q, float (&out6)[6]) {
-    b8_t B[X6V_BRING][3];
-    X6WEpi e;
-    float va[16], vb[16];
-    X6V_STAMP(c, 0);
-    {
-        float x0[16];
-        vel_encode_slots(q, c.h, x0);
-        b8_t* mine = const_cast<b8_t*>(c.tb) + c.wv * X6W_OB_H8;            // this wave's tile: K steps 0, 1 = the encoder slots
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            unsigned p1[4], p2[4], p3[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xa = x0[8 * k + 2 * j], xb = x0[8 * k + 2 * j + 1];
-                const unsigned ua = __float_as_uint(xa), ub = __float_as_uint(xb);
-                p1[j] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-                const float ra = xa - __uint_as_float(ua & 0xffff0000u), rb = xb - __uint_as_float(ub & 0xffff0000u);
-                const unsigned wa = __float_as_uint(ra), wb = __float_as_uint(rb);
-                p2[j] = __builtin_amdgcn_perm(wb, wa, 0x07060302u);
-                const float sa = ra - __uint_as_float(wa & 0xffff0000u), sb = rb - __uint_as_float(wb & 0xffff0000u);
-                p3[j] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-            }
-            const u32x4w q1 = {p1[0], p1[1], p1[2], p1[3]}, q2 = {p2[0], p2[1], p2[2], p2[3]}, q3 = {p3[0], p3[1], p3[2], p3[3]};
-            mine[(k * 3 + 0) * 64] = __builtin_bit_cast(b8_t, q1); mine[(k * 3 + 1) * 64] = __builtin_bit_cast(b8_t, q2); mine[(k * 3 + 2) * 64] = __builtin_bit_cast(b8_t, q3);
-        }
-    }
-    f32x16 bias;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bias[r] = c.lb[32 * c.wv + (r & 3) + 8 * (r >> 2) + 4 * c.h];
-    X6V_STAMP(c, 1);
-    X6V_BAR();                                // the four tiles' encoder slots are in LDS (and every wave is done with the previous evaluation's floats)
-    x6w_for(std::make_integer_sequence<int, X6V_LA>{}, [&](auto Gc) { x6v_bread<decltype(Gc)::value>(c, B); });
-    // layer 0
-    x6v_slot<0, 0, false, false, 0>(c, A0, A, B, va, e, va, bias);
-    x6v_slot<0, 1, true, false, 0>(c, A0, A, B, va, e, vb, bias);
-    x6v_slot<0, 2, true, false, 1>(c, A0, A, B, vb, e, va, bias);
-    x6v_slot<0, 3, true, false, 2>(c, A0, A, B, va, e, vb, bias);
-    // layers 1..4 (the bias rows of a layer arrive during the last slot of the layer before)
-    x6v_slot<1, 0, true, false, 3>(c, A0, A, B, vb, e, va, bias);
-    x6v_slot<1, 1, true, false, 0>(c, A0, A, B, va, e, vb, bias);
-    x6v_slot<1, 2, true, false, 1>(c, A0, A, B, vb, e, va, bias);
-    x6v_slot<1, 3, true, false, 2>(c, A0, A, B, va, e, vb, bias);
-    x6v_slot<2, 0, true, false, 3>(c, A0, A, B, vb, e, va, bias);
-    x6v_slot<2, 1, true, false, 0>(c, A0, A, B, va, e, vb, bias);
-    x6v_slot<2, 2, true, false, 1>(c, A0, A, B, vb, e, va, bias);
-    x6v_slot<2, 3, true, false, 2>(c, A0, A, B, va, e, vb, bias);
-    x6v_slot<3, 0, true, false, 3>(c, A0, A, B, vb, e, va, bias);
-    x6v_slot<3, 1, true, false, 0>(c, A0, A, B, va, e, vb, bias);
-    x6v_slot<3, 2, true, false, 1>(c, A0, A, B, vb, e, va, bias);
-    x6v_slot<3, 3, true, false, 2>(c, A0, A, B, va, e, vb, bias);
-    x6v_slot<4, 0, true, false, 3>(c, A0, A, B, vb, e, va, bias);
-    x6v_slot<4, 1, true, true, 0>(c, A0, A, B, va, e, vb, bias);
-    x6v_slot<4, 2, true, true, 1>(c, A0, A, B, vb, e, va, bias);
-    x6v_slot<4, 3, true, true, 2>(c, A0, A, B, va, e, vb, bias);
-    {   // the last slot's epilogue has no MFMAs to ride under
-        X6W ce; ce.ob = c.obf + 3 * X6W_OB_H8;
-        x6w_micros<0, 38, true>(ce, vb, e, 0);
-    }
-    X6V_STAMP(c, 22);
-    X6V_BAR();
-    X6V_STAMP(c, 23);
-    // ---- 128 -> 6: fp32 FMAs in velnet_x6's order (per row tile: a chain over its 16 activations, the two lane halves added, then the tiles in order)
-#pragma unroll
-    for (int o = 0; o < 6; ++o) out6[o] = c.lb[128 * 5 + o];
-    const float4* zt = reinterpret_cast<const float4*>(c.tb + c.wv * X6W_OB_H8);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        float zl[16];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const float4 t = zt[(m * 4 + k) * 64]; zl[4 * k] = t.x; zl[4 * k + 1] = t.y; zl[4 * k + 2] = t.z; zl[4 * k + 3] = t.w; }
-        float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float4* wl = c.w5l + (m * 2 + c.h) * 32;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float4 wa = wl[2 * r], wb = wl[2 * r + 1];
-            const float av = zl[r];
-            p[0] = __builtin_fmaf(av, wa.x, p[0]); p[1] = __builtin_fmaf(av, wa.y, p[1]); p[2] = __builtin_fmaf(av, wa.z, p[2]);
-            p[3] = __builtin_fmaf(av, wa.w, p[3]); p[4] = __builtin_fmaf(av, wb.x, p[4]); p[5] = __builtin_fmaf(av, wb.y, p[5]);
-        }
-#pragma unroll
-        for (int o = 0; o < 6; ++o) { p[o] += __shfl_xor(p[o], 32); out6[o] += p[o]; }
-    }
-    X6V_STAMP(c, 24);
-}
-
-// weights of this wave that stay: its layer-0 rows for the whole kernel, its layer-1 rows for the first evaluation (every later one inherits them
-// from the layer-4 slots of the one before)
-__device__ __forceinline__ void x6v_setup(X6V& c, const b8_t* img, float* lb, float* w5f, b8_t* tbase, int wv, int lane, b8_t (&A0)[2][3], b8_t (&A)[8][3]) {
-    c.stamp = 0;
-    c.lane = lane; c.h = lane >> 5; c.wv = wv; c.lb = lb; c.w5l = reinterpret_cast<const float4*>(w5f);
-    c.tb = tbase + lane; c.obw = tbase + lane + 6 * wv * 64; c.obf = tbase + lane + 4 * wv * 64;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const b8_t* g = img + (size_t)t * X6_H8 + lane;
-        c.W[t] = (x6w_gptr)(g + (8 + 8 * wv) * 64);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) A0[s][t] = ((x6w_gptr)g)[(2 * wv + s) * 64];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) A[s][t] = c.W[t][s * 64];
-    }
-}
-
-// the recurrence of k_rk2_x6w on the weight-stationary evaluation: four tiles per workgroup, in step
-__global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6v(X6Args a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lb = lds;
-    float* w5f = lb + 6 * 128;
-    b8_t* tbase = reinterpret_cast<b8_t*>(w5f + 4 * 2 * 16 * 8);
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int count = a.count ? *a.count : (int)a.n_direct;
-    if ((int)blockIdx.x * 4 * TILE >= count) return;
-    for (int k = threadIdx.x; k < 6 * 128; k += WG_THREADS) lb[k] = (k & 127) < (k < 640 ? 128 : 6) ? a.f.vb[k >> 7][k & 127] : 0.f;
-    for (int k = threadIdx.x; k < 4 * 2 * 16 * 8; k += WG_THREADS) {
-        const int o = k & 7, r = (k >> 3) & 15, hh = (k >> 7) & 1, ww = k >> 8;
-        w5f[k] = o < 6 ? a.f.vW[5][o * 128 + 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
-    }
-    __syncthreads();
-    const int tile = blockIdx.x * 4 + wv;                 // (a wave without points still computes its share of the other tiles)
-    const int i = tile * TILE + (lane & 31);
-    const bool active = i < count;
-    const int n = active ? (a.list ? a.list[i] : i) : 0;
-    const float4 q0 = active ? a.xw[n] : zero4();
-    float x = q0.x, y = q0.y, z = q0.z;
-    const float zw = q0.w;
-    const int ti = a.pt_by_list ? n : i;
-    float tcur = active ? a.pt_t[ti] : 0.f;
-    float off = active ? tcur - a.pt_base[ti] : 0.f;
-    X6V c; b8_t A0[2][3], A[8][3];
-    x6v_setup(c, reinterpret_cast<const b8_t*>(a.img), lb, w5f, tbase, wv, lane, A0, A);
-#pragma unroll 1
-    for (int s = 0; s < a.max_steps; ++s) {
-        const bool live = active && fabsf(off) > 0.f;
-        const float mm = fminf(fabsf(off), a.dt_max);
-        const float dt = off > 0.f ? mm : (off < 0.f ? -mm : 0.f);
-        if (!__syncthreads_or(live)) break;
-        const float hdt = 0.5f * dt;
-        float px = x, py = y, pz = z;
-        float o6[6];
-#pragma unroll 1
-        for (int ev = 0; ev < 2; ++ev) {
-            const float4 q = make_float4(px, py, pz, ev ? tcur - hdt : tcur);
-#ifdef X6V_TIMING
-            c.stamp = (blockIdx.x == 700 && wv == 1 && s == 2 && ev == 0) ? 1 : 0;
-#endif
-            velnet_x6v(c, A0, A, q, o6);
-            if (ev == 0) {
-                float v1[3];
-                vel_from_w(o6, x, y, z, v1);
-                if (gated_out(a.f, x, y, z)) { v1[0] = v1[1] = v1[2] = 0.f; }
-                px = x - hdt * v1[0]; py = y - hdt * v1[1]; pz = z - hdt * v1[2];
-            }
-        }
-        float v2[3];
-        vel_from_w(o6, px, py, pz, v2);
-        if (gated_out(a.f, px, py, pz)) { v2[0] = v2[1] = v2[2] = 0.f; }
-        const float nx = x - dt * v2[0], ny = y - dt * v2[1], nz = z - dt * v2[2];
-        const bool rej = a.f.gate_sur && gated_out(a.f, nx, ny, nz);   // tensorf_keyframe.py:603-605
-        if (live && !rej) { x = nx; y = ny; z = nz; }
-        if (live) { off = off - dt; tcur = tcur - dt; }
-    }
-#ifdef X6V_TIMING
-    if (blockIdx.x == 700 && wv == 1 && lane == 0) {
-        printf("[x6v timing] enc %llu | slots", x6v_ts[1] - x6v_ts[0]);
-        for (int k = 2; k <= 21; ++k) printf(" %llu", x6v_ts[k] - x6v_ts[k - 1]);
-        printf(" | bare epilogue %llu | barrier %llu | out %llu | total %llu\n", x6v_ts[22] - x6v_ts[21], x6v_ts[23] - x6v_ts[22], x6v_ts[24] - x6v_ts[23], x6v_ts[24] - x6v_ts[0]);
-    }
-#endif
-    if (active && h == 0) {
-        if (a.xout3) { float* o = a.xout3 + 3 * (size_t)n; o[0] = x; o[1] = y; o[2] = z; }
-        else a.xw[n] = make_float4(x, y, z, zw);
-    }
-}
-
-// eval-mode render warp (uniform schedule; k_rk2_x6w_uni<false>'s recurrence)
-__global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6v_uni(X6UniArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lb = lds;
-    float* w5f = lb + 6 * 128;
-    b8_t* tbase = reinterpret_cast<b8_t*>(w5f + 4 * 2 * 16 * 8);
-    const Rk2Args& ra = a.r;
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int count = *ra.count;
-    if ((int)blockIdx.x * WG_SAMPLES >= count) return;
-    for (int k = threadIdx.x; k < 6 * 128; k += WG_THREADS) lb[k] = (k & 127) < (k < 640 ? 128 : 6) ? ra.f.vb[k >> 7][k & 127] : 0.f;
-    for (int k = threadIdx.x; k < 4 * 2 * 16 * 8; k += WG_THREADS) {
-        const int o = k & 7, r = (k >> 3) & 15, hh = (k >> 7) & 1, ww = k >> 8;
-        w5f[k] = o < 6 ? ra.f.vW[5][o * 128 + 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
-    }
-    __syncthreads();
-    const size_t tile = (size_t)blockIdx.x * 4 + wv;
-    const int idx = (int)tile * TILE + (lane & 31);
-    const bool active = idx < count;
-    const int n = active ? ra.list[idx] : 0;
-    const float4 q0 = active ? ra.xw[n] : zero4();
-    float x = q0.x, y = q0.y, z = q0.z;
-    const float zw = q0.w;
-    X6V c; b8_t A0[2][3], A[8][3];
-    x6v_setup(c, reinterpret_cast<const b8_t*>(a.img), lb, w5f, tbase, wv, lane, A0, A);
-    const int nsteps = ra.sched ? __float_as_int(ra.sched[2]) : ra.nsteps;
-#pragma unroll 1
-    for (int s = 0; s < nsteps; ++s) {
-        const float dt = RK_DT(ra, s), tcur = RK_TC(ra, s), hdt = 0.5f * dt;
-        float px = x, py = y, pz = z;
-        float o6[6];
-#pragma unroll 1
-        for (int ev = 0; ev < 2; ++ev) {
-            const float4 q = make_float4(px, py, pz, ev ? tcur - hdt : tcur);
-            velnet_x6v(c, A0, A, q, o6);
-            if (ev == 0) {
-                float v1[3];
-                vel_from_w(o6, x, y, z, v1);
-                if (gated_out(ra.f, x, y, z)) { v1[0] = v1[1] = v1[2] = 0.f; }
-                px = x - hdt * v1[0]; py = y - hdt * v1[1]; pz = z - hdt * v1[2];
-            }
-        }
-        float v2[3];
-        vel_from_w(o6, px, py, pz, v2);
-        if (gated_out(ra.f, px, py, pz)) { v2[0] = v2[1] = v2[2] = 0.f; }
-        const float nx = x - dt * v2[0], ny = y - dt * v2[1], nz = z - dt * v2[2];
-        const bool rej = ra.f.gate_sur && gated_out(ra.f, nx, ny, nz);   // tensorf_keyframe.py:603-605
-        if (active && !rej) { x = nx; y = ny; z = nz; }
-    }
-    if (active && h == 0) ra.xw[n] = make_float4(x, y, z, zw);
-}
-
 // (per device: hipFuncSetAttribute applies to the device that is current - one process per GPU never sees a second one, a host that drives
 // several devices from one process does; common.h: DeviceOnce)
-// NVFI_X6V=1 (opt-in, round 6; 3-4 % SLOWER than x6w): the weight-stationary kernels k_rk2_x6v / k_rk2_x6v_uni instead of k_rk2_x6w / k_rk2_x6w_uni<false> (bit-identical)
-static bool x6v_on() { static int v = -1; if (v < 0) { const char* e = getenv("NVFI_X6V"); v = e ? atoi(e) : 0; } return v != 0; }
 template <typename K>
 static int x6w_set_lds(K kernel) {
     HIPCK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6W_LDS_BYTES));
@@ -771,12 +447,7 @@ int launch_rk2_x6w_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipS
     const int64_t groups = (cap_samples + WG_SAMPLES - 1) / WG_SAMPLES;
     if (groups <= 0) return 0;
     static DeviceOnce once;
-    if (once.run([] { return (x6w_set_lds(k_rk2_x6w_uni<true>) || x6w_set_lds(k_rk2_x6w_uni<false>) || x6w_set_lds(k_rk2_x6v_uni)) ? 1 : 0; })) return 1;
-    if (!stash && x6v_on()) {
-        hipLaunchKernelGGL(k_rk2_x6v_uni, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
-        LAUNCHCK();
-        return 0;
-    }
+    if (once.run([] { return (x6w_set_lds(k_rk2_x6w_uni<true>) || x6w_set_lds(k_rk2_x6w_uni<false>)) ? 1 : 0; })) return 1;
     if (stash) hipLaunchKernelGGL(k_rk2_x6w_uni<true>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
     else hipLaunchKernelGGL(k_rk2_x6w_uni<false>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
     LAUNCHCK();
@@ -787,12 +458,7 @@ int launch_rk2_x6w(const X6Args& a, int64_t cap_points, hipStream_t st) {
     const int64_t tiles = (cap_points + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
     static DeviceOnce once;
-    if (once.run([] { return (x6w_set_lds(k_rk2_x6w) || x6w_set_lds(k_rk2_x6v)) ? 1 : 0; })) return 1;
-    if (x6v_on()) {
-        hipLaunchKernelGGL(k_rk2_x6v, dim3((unsigned)((tiles + 3) / 4)), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
-        LAUNCHCK();
-        return 0;
-    }
+    if (once.run([] { return x6w_set_lds(k_rk2_x6w); })) return 1;
     hipLaunchKernelGGL(k_rk2_x6w, dim3((unsigned)((tiles + 3) / 4)), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
     LAUNCHCK();
     return 0;
