@@ -47,6 +47,10 @@ template <int... Is, class F> __device__ __forceinline__ void x6w_for(std::integ
 struct X6WEpi {                    // transient state of one pending epilogue
     float rr[16];
     unsigned pk[3][8];
+    // LAST: the row tile's share of the 128 -> 6 output layer, formed in the same micro-slots (round 6)
+    float p[6];                    // its partial sums: a chain over the tile's 16 activations, as velnet_x6 forms them
+    float4 wa, wb;                 // output-layer weights of the activation whose turn is next (LDS broadcast reads, two micro-slots ahead)
+    float out[6];                  // the evaluation's outputs: bias, then the row tiles in order
 };
 // piece I (0..35) of the epilogue of a row tile: v = its 16 pre-activations; K steps m2, m2 + 1 of the layer output
 // LAST (last hidden layer): the activations themselves go to LDS (rows m2 * 2 .. of the same buffer, as floats) for the output layer
@@ -55,7 +59,9 @@ struct X6WEpi {                    // transient state of one pending epilogue
 //   u = 2 r      E_r: t = exp2(-log2(e) z_r)            u = 2 r + 1   R_r: s = rcp(1 + t)            u = 2 r + 2   M_r: z_r s       (act_f<1>'s arithmetic)
 //   pair p = (2 p, 2 p + 1), complete at u = 4 p + 4:  u = 4 p + 5 .. 4 p + 8: the truncation split in four parts (3, 2, 3, 3 instructions)
 //   u = 22, u = 37: the three 16-byte LDS writes of K step m2 / m2 + 1 of the layer output
-// LAST (last hidden layer): no split - the activations go to LDS as floats (four float4 per tile, at u = 9, 17, 25, 33)
+// LAST (last hidden layer): no split - activation r enters the tile's six output-layer sums behind its SiLU: four FMAs at u = 2 r + 3, two at u = 2 r + 4
+// (weights of r + 1 requested behind them), the two lane halves added at u = 35, 36, the tile added to the outputs at u = 37.  (Rounds 5-6: the
+// activations went to LDS as floats and one pass behind the last tile did all 384 FMAs outside any MFMA's shadow: 6 % of an evaluation.)
 template <int U, bool LAST>
 __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
 #ifndef X6W_PROBE_NO_SILU            // (timing probe: identity activation)
@@ -67,10 +73,35 @@ __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& 
     if constexpr (U >= 2 && U <= 32 && (U & 1) == 0) { constexpr int r = (U - 2) >> 1; v[r] = v[r] * e.rr[r]; }
 #endif
     if constexpr (LAST) {
-        if constexpr (U >= 9 && U <= 33 && ((U - 9) & 7) == 0) {
-            constexpr int k = (U - 9) >> 3;
-            float4* z = reinterpret_cast<float4*>(c.ob) + (size_t)(m2 * 2 + k) * 64;      // (c.ob already carries + lane)
-            *z = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        const float4* wl = c.w5l + ((m2 >> 1) * 2 + c.h) * 32;
+        if constexpr (U == 0) {
+#pragma unroll
+            for (int o = 0; o < 6; ++o) e.p[o] = 0.f;
+        }
+        if constexpr (U == 1) e.wa = wl[0];
+        if constexpr (U == 2) e.wb = wl[1];
+        if constexpr (U >= 3 && U <= 34) {
+            constexpr int r = (U - 3) >> 1;
+            if constexpr (((U - 3) & 1) == 0) {
+                e.p[0] = __builtin_fmaf(v[r], e.wa.x, e.p[0]); e.p[1] = __builtin_fmaf(v[r], e.wa.y, e.p[1]);
+                e.p[2] = __builtin_fmaf(v[r], e.wa.z, e.p[2]); e.p[3] = __builtin_fmaf(v[r], e.wa.w, e.p[3]);
+                if constexpr (r < 15) e.wa = wl[2 * (r + 1)];
+            } else {
+                e.p[4] = __builtin_fmaf(v[r], e.wb.x, e.p[4]); e.p[5] = __builtin_fmaf(v[r], e.wb.y, e.p[5]);
+                if constexpr (r < 15) e.wb = wl[2 * (r + 1) + 1];
+            }
+        }
+        if constexpr (U == 35) {
+#pragma unroll
+            for (int o = 0; o < 6; ++o) e.rr[o] = __shfl_xor(e.p[o], 32);
+        }
+        if constexpr (U == 36) {
+#pragma unroll
+            for (int o = 0; o < 6; ++o) e.p[o] += e.rr[o];
+        }
+        if constexpr (U == 37) {
+#pragma unroll
+            for (int o = 0; o < 6; ++o) e.out[o] += e.p[o];
         }
     } else {
         if constexpr (U >= 5 && U <= 36) {
@@ -240,6 +271,8 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float
     f32x16 bias;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias[r] = c.lb[(r & 3) + 8 * (r >> 2) + 4 * c.h];
+#pragma unroll
+    for (int o = 0; o < 6; ++o) e.out[o] = c.lb[128 * 5 + o];
     // layer 0 (28 -> 128): four row tiles of two K steps
     x6w_tile<0, 0, 0, false, false, STASH>(c, A1, A2, A3, X0, in, va, e, 0, va, bias);
     x6w_tile<2, 0, 32, true, false, STASH>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
@@ -265,35 +298,26 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float
     x6w_tile<112, 2, 544, true, true, STASH>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
     x6w_tile<120, 2, 576, true, true, STASH>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
     x6w_tile<128, 4, 608, true, true, STASH>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
-    // ---- 128 -> 6: fp32 FMAs in velnet_x6's order (per row tile: a chain over its 16 activations, the two lane halves added, then the tiles in order)
-#pragma unroll
-    for (int o = 0; o < 6; ++o) out6[o] = c.lb[128 * 5 + o];
+    // ---- 128 -> 6: fp32 FMAs in velnet_x6's order (per row tile: a chain over its 16 activations, the two lane halves added, then the tiles in order).
+    // Row tiles 0..2 were summed in their epilogues' micro-slots (x6w_micro<LAST>); the last one has no MFMAs behind it
 #ifdef X6W_PROBE_NO_OUT              // (timing probe: no output layer)
+#pragma unroll
+    for (int o = 0; o < 6; ++o) out6[o] = e.out[o];
     out6[0] += vb[0]; out6[1] += vb[5];
     return;
 #endif
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        float zl[16];
-        if (m < 3) {
-            const float4* z = reinterpret_cast<const float4*>(c.ob) + (size_t)(m * 4) * 64;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const float4 t = z[k * 64]; zl[4 * k] = t.x; zl[4 * k + 1] = t.y; zl[4 * k + 2] = t.z; zl[4 * k + 3] = t.w; }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zl[r] = act_f<1>(vb[r]);
-        }
+    {
         float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float4* wl = c.w5l + (m * 2 + c.h) * 32;
+        const float4* wl = c.w5l + (3 * 2 + c.h) * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float4 wa = wl[2 * r], wb = wl[2 * r + 1];
-            const float av = zl[r];
+            const float av = act_f<1>(vb[r]);
             p[0] = __builtin_fmaf(av, wa.x, p[0]); p[1] = __builtin_fmaf(av, wa.y, p[1]); p[2] = __builtin_fmaf(av, wa.z, p[2]);
             p[3] = __builtin_fmaf(av, wa.w, p[3]); p[4] = __builtin_fmaf(av, wb.x, p[4]); p[5] = __builtin_fmaf(av, wb.y, p[5]);
         }
 #pragma unroll
-        for (int o = 0; o < 6; ++o) { p[o] += __shfl_xor(p[o], 32); out6[o] += p[o]; }
+        for (int o = 0; o < 6; ++o) { p[o] += __shfl_xor(p[o], 32); out6[o] = e.out[o] + p[o]; }
     }
 }
 
