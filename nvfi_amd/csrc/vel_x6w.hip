@@ -51,6 +51,7 @@ struct X6WEpi {                    // transient state of one pending epilogue
     float p[6];                    // its partial sums: a chain over the tile's 16 activations, as velnet_x6 forms them
     float4 wa, wb;                 // output-layer weights of the activation whose turn is next (LDS broadcast reads, two micro-slots ahead)
     float out[6];                  // the evaluation's outputs: bias, then the row tiles in order
+    float* zst;                    // STASH: the pending tile's sixteen z rows (+ lane): pre-activation r is stored at u = 2 r, in the MFMAs' shadow
 };
 // piece I (0..35) of the epilogue of a row tile: v = its 16 pre-activations; K steps m2, m2 + 1 of the layer output
 // LAST (last hidden layer): the activations themselves go to LDS (rows m2 * 2 .. of the same buffer, as floats) for the output layer
@@ -62,8 +63,9 @@ struct X6WEpi {                    // transient state of one pending epilogue
 // LAST (last hidden layer): no split - activation r enters the tile's six output-layer sums behind its SiLU: four FMAs at u = 2 r + 3, two at u = 2 r + 4
 // (weights of r + 1 requested behind them), the two lane halves added at u = 35, 36, the tile added to the outputs at u = 37.  (Rounds 5-6: the
 // activations went to LDS as floats and one pass behind the last tile did all 384 FMAs outside any MFMA's shadow: 6 % of an evaluation.)
-template <int U, bool LAST>
+template <int U, bool LAST, bool STASH = false>
 __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
+    if constexpr (STASH && U < 32 && (U & 1) == 0) STASH_ST(e.zst[(U >> 1) * REGF], v[U >> 1]);        // (v[r] is still the pre-activation: SiLU's last step comes at u = 2 r + 2)
 #ifndef X6W_PROBE_NO_SILU            // (timing probe: identity activation)
     if constexpr (U < 32) {
         constexpr int r = U >> 1;
@@ -138,11 +140,11 @@ __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& 
         }
     }
 }
-template <int U0, int N, bool LAST>
+template <int U0, int N, bool LAST, bool STASH = false>
 __device__ __forceinline__ void x6w_micros(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
     x6w_for(std::make_integer_sequence<int, N>{}, [&](auto Uc) {
         constexpr int U = U0 + decltype(Uc)::value;
-        if constexpr (U < 38) x6w_micro<U, LAST>(c, v, e, m2);
+        if constexpr (U < 38) x6w_micro<U, LAST, STASH>(c, v, e, m2);
     });
 }
 __device__ __forceinline__ void x6w_load_in(const X6W& c, b8_t (&in)[8][3], int s) {
@@ -196,12 +198,12 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
 #ifndef X6W_PROBE_NO_EPILOGUE          // (timing probe; NOT the MFMA stream alone: without the epilogue the earlier tiles' MFMAs are dead code and go too)
         if constexpr (HAVE_PE) {
             if constexpr (KIND == 0) {                        // 12 slots: 4 micro-slots in the first two, 3 in the others
-                if constexpr (I < 2) x6w_micros<4 * I, 4, PE_LAST>(c, pv, e, pm2);
-                else x6w_micros<8 + 3 * (I - 2), 3, PE_LAST>(c, pv, e, pm2);
+                if constexpr (I < 2) x6w_micros<4 * I, 4, PE_LAST, STASH>(c, pv, e, pm2);
+                else x6w_micros<8 + 3 * (I - 2), 3, PE_LAST, STASH>(c, pv, e, pm2);
             } else if constexpr (KIND == 1) {                 // done by slot 29: two micro-slots in each of the first eight
-                if constexpr (I < 8) x6w_micros<2 * I, 2, PE_LAST>(c, pv, e, pm2);
-                else if constexpr (I < 30) x6w_micros<I + 8, 1, PE_LAST>(c, pv, e, pm2);
-            } else if constexpr (I < 38) x6w_micros<I, 1, PE_LAST>(c, pv, e, pm2);
+                if constexpr (I < 8) x6w_micros<2 * I, 2, PE_LAST, STASH>(c, pv, e, pm2);
+                else if constexpr (I < 30) x6w_micros<I + 8, 1, PE_LAST, STASH>(c, pv, e, pm2);
+            } else if constexpr (I < 38) x6w_micros<I, 1, PE_LAST, STASH>(c, pv, e, pm2);
         }
 #endif
         if constexpr (KIND == 1 && I == 30) { x6w_load_in(c, in, 6); x6w_load_in(c, in, 7); }
@@ -218,8 +220,10 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
 #pragma unroll
     for (int r = 0; r < 16; ++r) nv[r] = a1[r] + a0[r];
     if constexpr (STASH) {                     // the fp32 pre-activations, rows (l * 64 + 16 m + r) of the evaluation's stash: k_rk2_split_uni<STASH>'s layout
+        if constexpr (KIND == 4) {             // (the evaluation's last tile has no successor whose MFMAs could cover its stores)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) STASH_ST(c.zp[r * REGF], nv[r]);
+            for (int r = 0; r < 16; ++r) STASH_ST(c.zp[r * REGF], nv[r]);
+        } else e.zst = c.zp;                   // round 6: stored row by row from the epilogue's micro-slots (sixteen stores in a row here were 400 uncovered cycles per tile)
         c.zp += 16 * REGF;
         asm volatile("" : "+v"(c.zp));
     }
