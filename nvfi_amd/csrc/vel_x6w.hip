@@ -28,7 +28,31 @@ typedef const b8_t __attribute__((address_space(1))) * x6w_gptr;      // (behind
 #define X6W_OB_H8 (8 * 3 * 64)               // per wave: the layer output on its way to the next layer's input registers, [K step][term][lane]
 #define X6W_LDS_BYTES ((6 * 128 + 4 * 2 * 16 * 8) * 4 + 4 * X6W_OB_H8 * 16)
 
+#ifdef X6W_TIMING                     // shader-clock stamps at the tile boundaries of one evaluation of one wave (printed at the end of k_rk2_x6w)
+__device__ unsigned long long x6w_ts[32];
+#define X6W_STAMP(c, k) do { if ((c).stamp) x6w_ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define X6W_STAMP(c, k) do { } while (0)
+#endif
+// the stream loads: per-lane 64-bit pointers (global_load, the default) - X6W_BUFLD (timing probe): buffer loads, SGPR resource + the lane's offset in one
+// VGPR + a running SGPR offset: the same real cycles per evaluation (46.4 k against 46.6 k) - a weight load costs its ~25 cycles on the return path,
+// not in the address form
+#if defined(X6W_BUFLD)
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+#define X6W_OPAQUE(c) asm volatile("" : "+s"((c).so))
+#define X6W_LD(c, P, E) __builtin_bit_cast(b8_t, __builtin_amdgcn_raw_buffer_load_b128((c).R##P, (int)(c).vo + (E) * 1024, (c).so, 0))
+#define X6W_PTR(img, lane) ((x6w_gptr)(img))
+#else
+#define X6W_OPAQUE(c) asm volatile("" : "+v"((c).W1), "+v"((c).W2), "+v"((c).W3))
+#define X6W_LD(c, P, E) ((c).P[(E) * 64])
+#define X6W_PTR(img, lane) ((x6w_gptr)((img) + (lane)))
+#endif
 struct X6W {
+    int stamp;
+    unsigned vo;                   // lane * 16
+#ifdef X6W_BUFLD
+    __amdgpu_buffer_rsrc_t RW1, RW2, RW3; int so;
+#endif
     x6w_gptr W1, W2, W3;           // per lane, RUNNING: the base of the current group of four stream entries (entry x of the lane at [(x & 3) * 64],
                                    // a 13-bit immediate offset); advanced by 4 KB once per four entries and made opaque, so that the compiler
                                    // neither re-derives 136 x 3 64-bit addresses from the kernel argument nor keeps them (the first build spilled 265)
@@ -49,7 +73,7 @@ struct X6WEpi {                    // transient state of one pending epilogue
     unsigned pk[3][8];
     // LAST: the row tile's share of the 128 -> 6 output layer, formed in the same micro-slots (round 6)
     float p[6];                    // its partial sums: a chain over the tile's 16 activations, as velnet_x6 forms them
-    float4 wa, wb;                 // output-layer weights of the activation whose turn is next (LDS broadcast reads, two micro-slots ahead)
+    float4 wa, wb;                 // output-layer weights of the activation whose turn is next (LDS broadcast reads, two micro-slots ahead; four ahead: no faster)
     float out[6];                  // the evaluation's outputs: bias, then the row tiles in order
     float* zst;                    // STASH: the pending tile's sixteen z rows (+ lane): pre-activation r is stored at u = 2 r, in the MFMAs' shadow
 };
@@ -183,16 +207,20 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
             constexpr int x = en + X6W_RING - 1;
             if constexpr ((x & 3) == 0) {
 #ifndef X6W_PROBE_SAME_ENTRIES      // (timing probe: every wave re-reads the first four entries - 12 KB that stay in the CU's L1)
+#ifdef X6W_BUFLD
+                c.so += 4096;
+#else
                 c.W1 += 256; c.W2 += 256; c.W3 += 256;
 #endif
-                asm volatile("" : "+v"(c.W1), "+v"(c.W2), "+v"(c.W3));
+#endif
+                X6W_OPAQUE(c);
             }
 #if defined(X6W_PROBE_QUARTER_LOADS)     // (timing probe: a quarter of the weight loads; the other ring slots keep what they hold)
-            if constexpr ((x & 3) == 0) { A1[x % X6W_RING] = c.W1[0]; A2[x % X6W_RING] = c.W2[0]; A3[x % X6W_RING] = c.W3[0]; }
+            if constexpr ((x & 3) == 0) { A1[x % X6W_RING] = X6W_LD(c, W1, 0); A2[x % X6W_RING] = X6W_LD(c, W2, 0); A3[x % X6W_RING] = X6W_LD(c, W3, 0); }
 #elif defined(X6W_PROBE_LDS_A)           // (timing probe: the A operands from LDS - this wave's output buffer, garbage - instead of L1)
             A1[x % X6W_RING] = c.ob[((x & 7) * 3 + 0) * 64]; A2[x % X6W_RING] = c.ob[((x & 7) * 3 + 1) * 64]; A3[x % X6W_RING] = c.ob[((x & 7) * 3 + 2) * 64];
 #else
-            A1[x % X6W_RING] = c.W1[(x & 3) * 64]; A2[x % X6W_RING] = c.W2[(x & 3) * 64]; A3[x % X6W_RING] = c.W3[(x & 3) * 64];
+            A1[x % X6W_RING] = X6W_LD(c, W1, x & 3); A2[x % X6W_RING] = X6W_LD(c, W2, x & 3); A3[x % X6W_RING] = X6W_LD(c, W3, x & 3);
 #endif
         }
 #ifndef X6W_PROBE_NO_EPILOGUE          // (timing probe; NOT the MFMA stream alone: without the epilogue the earlier tiles' MFMAs are dead code and go too)
@@ -227,6 +255,7 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
         c.zp += 16 * REGF;
         asm volatile("" : "+v"(c.zp));
     }
+    X6W_STAMP(c, E0 < 8 ? 1 + E0 / 2 : 5 + (E0 - 8) / 8);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -234,8 +263,9 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
 template <bool STASH = false>
 __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float (&out6)[6], float* zst = nullptr, float* x0st = nullptr) {
     X6W c = c0;
+    X6W_STAMP(c, 0);
     c.zp = STASH ? zst + c0.lane : nullptr;                    // (the stream pointers run through one evaluation)
-    asm volatile("" : "+v"(c.W1), "+v"(c.W2), "+v"(c.W3));
+    X6W_OPAQUE(c);
     b8_t X0[2][3], in[8][3];
     b8_t A1[X6W_RING], A2[X6W_RING], A3[X6W_RING];
     X6WEpi e;
@@ -269,8 +299,12 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float
     }
 #pragma unroll
     for (int en = 0; en < X6W_RING - 1; ++en) {
+#ifdef X6W_BUFLD
+        if (en == 4) c.so += 4096;
+#else
         if (en == 4) { c.W1 += 256; c.W2 += 256; c.W3 += 256; }
-        A1[en] = c.W1[(en & 3) * 64]; A2[en] = c.W2[(en & 3) * 64]; A3[en] = c.W3[(en & 3) * 64];
+#endif
+        A1[en] = X6W_LD(c, W1, en & 3); A2[en] = X6W_LD(c, W2, en & 3); A3[en] = X6W_LD(c, W3, en & 3);
     }
     f32x16 bias;
 #pragma unroll
@@ -323,6 +357,7 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float
 #pragma unroll
         for (int o = 0; o < 6; ++o) { p[o] += __shfl_xor(p[o], 32); out6[o] = e.out[o] + p[o]; }
     }
+    X6W_STAMP(c, 21);
 }
 
 // the recurrence of k_rk2_x6 (vel_x6.hip), one wave per tile
@@ -352,9 +387,15 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
     const int ti = a.pt_by_list ? n : i;
     float tcur = active ? a.pt_t[ti] : 0.f;
     float off = active ? tcur - a.pt_base[ti] : 0.f;
-    X6W c;
+    X6W c; c.stamp = 0;
     const b8_t* img = reinterpret_cast<const b8_t*>(a.img);
-    c.W1 = (x6w_gptr)(img + lane); c.W2 = (x6w_gptr)(img + X6_H8 + lane); c.W3 = (x6w_gptr)(img + 2 * X6_H8 + lane);
+    c.W1 = X6W_PTR(img, lane); c.W2 = X6W_PTR(img + X6_H8, lane); c.W3 = X6W_PTR(img + 2 * X6_H8, lane); c.vo = (unsigned)lane * 16u;
+#ifdef X6W_BUFLD
+    c.so = 0;
+    c.RW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<b8_t*>(img), 0, 0x7fffffff, 0x00020000);
+    c.RW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<b8_t*>(img + X6_H8), 0, 0x7fffffff, 0x00020000);
+    c.RW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<b8_t*>(img + 2 * X6_H8), 0, 0x7fffffff, 0x00020000);
+#endif
     c.lb = lb; c.w5l = reinterpret_cast<const float4*>(w5f); c.ob = obase + (size_t)wv * X6W_OB_H8 + lane; c.lane = lane; c.h = h;
 #pragma unroll 1
     for (int s = 0; s < a.max_steps; ++s) {
@@ -369,6 +410,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
 #pragma unroll 1
         for (int ev = 0; ev < 2; ++ev) {
             const float4 q = make_float4(px, py, pz, ev ? tcur - hdt : tcur);
+#ifdef X6W_TIMING
+            c.stamp = (blockIdx.x == 700 && wv == 1 && s == 2 && ev == 0) ? 1 : 0;
+#endif
             velnet_x6w(c, q, o6);
             if (ev == 0) {
                 float v1[3];
@@ -385,6 +429,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
         if (live && !rej) { x = nx; y = ny; z = nz; }
         if (live) { off = off - dt; tcur = tcur - dt; }
     }
+#ifdef X6W_TIMING
+    if (blockIdx.x == 700 && wv == 1 && lane == 0) {
+        printf("[x6w timing] tiles (layer 0: 4, layers 1-4: 4 each), then the last row tile's sums:");
+        for (int k = 1; k <= 21; ++k) printf(" %llu", x6w_ts[k] - x6w_ts[k - 1]);
+        printf(" | total %llu\n", x6w_ts[21] - x6w_ts[0]);
+    }
+#endif
     if (active && h == 0) {
         if (a.xout3) { float* o = a.xout3 + 3 * (size_t)n; o[0] = x; o[1] = y; o[2] = z; }
         else a.xw[n] = make_float4(x, y, z, zw);
@@ -426,9 +477,15 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w_uni(X6UniArgs a) {
     const float4 q0 = active ? ra.xw[n] : zero4();
     float x = q0.x, y = q0.y, z = q0.z;
     const float zw = q0.w;
-    X6W c;
+    X6W c; c.stamp = 0;
     const b8_t* img = reinterpret_cast<const b8_t*>(a.img);
-    c.W1 = (x6w_gptr)(img + lane); c.W2 = (x6w_gptr)(img + X6_H8 + lane); c.W3 = (x6w_gptr)(img + 2 * X6_H8 + lane);
+    c.W1 = X6W_PTR(img, lane); c.W2 = X6W_PTR(img + X6_H8, lane); c.W3 = X6W_PTR(img + 2 * X6_H8, lane); c.vo = (unsigned)lane * 16u;
+#ifdef X6W_BUFLD
+    c.so = 0;
+    c.RW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<b8_t*>(img), 0, 0x7fffffff, 0x00020000);
+    c.RW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<b8_t*>(img + X6_H8), 0, 0x7fffffff, 0x00020000);
+    c.RW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<b8_t*>(img + 2 * X6_H8), 0, 0x7fffffff, 0x00020000);
+#endif
     c.lb = lb; c.w5l = reinterpret_cast<const float4*>(w5f); c.ob = obase + (size_t)wv * X6W_OB_H8 + lane; c.lane = lane; c.h = h; c.zp = nullptr;
     const int nsteps = ra.sched ? __float_as_int(ra.sched[2]) : ra.nsteps;
 #pragma unroll 1
