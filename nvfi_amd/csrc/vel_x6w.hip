@@ -260,14 +260,31 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
 }
 
 // one evaluation of the net for the wave's 32 points
+// the first seven entries of the weight stream into the ring: at kernel start, and by every evaluation for its successor BEFORE its own uncovered
+// tail (the last row tile's sums, the RK2 glue, the next encoder: ~3 k cycles for the L2 round trip - requested at the head of the evaluation the
+// first tile waited 0.6-1 k cycles for them; the ring is idle from the last K step on).  The last evaluation's request is wasted and harmless.
+struct X6WRing { b8_t A1[X6W_RING], A2[X6W_RING], A3[X6W_RING]; };
+__device__ __forceinline__ void x6w_prime(const X6W& c0, X6WRing& R) {
+    X6W c = c0;
+    X6W_OPAQUE(c);
+#pragma unroll
+    for (int en = 0; en < X6W_RING - 1; ++en) {
+#ifdef X6W_BUFLD
+        if (en == 4) c.so += 4096;
+#else
+        if (en == 4) { c.W1 += 256; c.W2 += 256; c.W3 += 256; }
+#endif
+        R.A1[en] = X6W_LD(c, W1, en & 3); R.A2[en] = X6W_LD(c, W2, en & 3); R.A3[en] = X6W_LD(c, W3, en & 3);
+    }
+}
 template <bool STASH = false>
-__device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float (&out6)[6], float* zst = nullptr, float* x0st = nullptr) {
+__device__ __forceinline__ void velnet_x6w(const X6W& c0, X6WRing& R, const float4& q, float (&out6)[6], float* zst = nullptr, float* x0st = nullptr) {
     X6W c = c0;
     X6W_STAMP(c, 0);
     c.zp = STASH ? zst + c0.lane : nullptr;                    // (the stream pointers run through one evaluation)
     X6W_OPAQUE(c);
     b8_t X0[2][3], in[8][3];
-    b8_t A1[X6W_RING], A2[X6W_RING], A3[X6W_RING];
+    b8_t (&A1)[X6W_RING] = R.A1, (&A2)[X6W_RING] = R.A2, (&A3)[X6W_RING] = R.A3;
     X6WEpi e;
     float va[16], vb[16];
     {
@@ -297,15 +314,12 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float
             X0[k][0] = __builtin_bit_cast(b8_t, q1); X0[k][1] = __builtin_bit_cast(b8_t, q2); X0[k][2] = __builtin_bit_cast(b8_t, q3);
         }
     }
-#pragma unroll
-    for (int en = 0; en < X6W_RING - 1; ++en) {
+    // (the ring holds entries 0..6: x6w_prime; the stream pointers continue behind them)
 #ifdef X6W_BUFLD
-        if (en == 4) c.so += 4096;
+    c.so += 4096;
 #else
-        if (en == 4) { c.W1 += 256; c.W2 += 256; c.W3 += 256; }
+    c.W1 += 256; c.W2 += 256; c.W3 += 256;
 #endif
-        A1[en] = X6W_LD(c, W1, en & 3); A2[en] = X6W_LD(c, W2, en & 3); A3[en] = X6W_LD(c, W3, en & 3);
-    }
     f32x16 bias;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias[r] = c.lb[(r & 3) + 8 * (r >> 2) + 4 * c.h];
@@ -336,6 +350,7 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, const float4& q, float
     x6w_tile<112, 2, 544, true, true, STASH>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
     x6w_tile<120, 2, 576, true, true, STASH>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
     x6w_tile<128, 4, 608, true, true, STASH>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
+    x6w_prime(c0, R);
     // ---- 128 -> 6: fp32 FMAs in velnet_x6's order (per row tile: a chain over its 16 activations, the two lane halves added, then the tiles in order).
     // Row tiles 0..2 were summed in their epilogues' micro-slots (x6w_micro<LAST>); the last one has no MFMAs behind it
 #ifdef X6W_PROBE_NO_OUT              // (timing probe: no output layer)
@@ -397,6 +412,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
     c.RW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<b8_t*>(img + 2 * X6_H8), 0, 0x7fffffff, 0x00020000);
 #endif
     c.lb = lb; c.w5l = reinterpret_cast<const float4*>(w5f); c.ob = obase + (size_t)wv * X6W_OB_H8 + lane; c.lane = lane; c.h = h;
+    X6WRing ring;
+    x6w_prime(c, ring);
 #pragma unroll 1
     for (int s = 0; s < a.max_steps; ++s) {
         const bool live = active && fabsf(off) > 0.f;
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
 #ifdef X6W_TIMING
             c.stamp = (blockIdx.x == 700 && wv == 1 && s == 2 && ev == 0) ? 1 : 0;
 #endif
-            velnet_x6w(c, q, o6);
+            velnet_x6w(c, ring, q, o6);
             if (ev == 0) {
                 float v1[3];
                 vel_from_w(o6, x, y, z, v1);
@@ -488,6 +505,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w_uni(X6UniArgs a) {
 #endif
     c.lb = lb; c.w5l = reinterpret_cast<const float4*>(w5f); c.ob = obase + (size_t)wv * X6W_OB_H8 + lane; c.lane = lane; c.h = h; c.zp = nullptr;
     const int nsteps = ra.sched ? __float_as_int(ra.sched[2]) : ra.nsteps;
+    X6WRing ring;
+    x6w_prime(c, ring);
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
         const float dt = RK_DT(ra, s), tcur = RK_TC(ra, s), hdt = 0.5f * dt;
@@ -498,7 +517,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w_uni(X6UniArgs a) {
         for (int ev = 0; ev < 2; ++ev) {
             const size_t e = (size_t)(2 * s + ev) * ra.cap_tiles + tile;
             const float4 q = make_float4(px, py, pz, ev ? tcur - hdt : tcur);
-            velnet_x6w<STASH>(c, q, o6, STASH ? ra.zst + e * (VEL_Z_REGS * REGF) : nullptr, STASH ? ra.x0st + e * (VEL_X0_REGS * REGF) : nullptr);
+            velnet_x6w<STASH>(c, ring, q, o6, STASH ? ra.zst + e * (VEL_Z_REGS * REGF) : nullptr, STASH ? ra.x0st + e * (VEL_X0_REGS * REGF) : nullptr);
             if (ev == 0) {
                 float v1[3];
 #pragma unroll
