@@ -85,8 +85,14 @@ struct X6WEpi {                    // transient state of one pending epilogue
 //   pair p = (2 p, 2 p + 1), complete at u = 4 p + 4:  u = 4 p + 5 .. 4 p + 8: the truncation split in four parts (3, 2, 3, 3 instructions)
 //   u = 22, u = 37: the three 16-byte LDS writes of K step m2 / m2 + 1 of the layer output
 // LAST (last hidden layer): no split - activation r enters the tile's six output-layer sums behind its SiLU: four FMAs at u = 2 r + 3, two at u = 2 r + 4
-// (weights of r + 1 requested behind them), the two lane halves added at u = 35, 36, the tile added to the outputs at u = 37.  (Rounds 5-6: the
+// (weights of r + 1 requested behind them), the two lane halves added at u = 35, 36 (v_permlane32_swap), the tile added to the outputs at u = 37.  (Rounds 5-6: the
 // activations went to LDS as floats and one pass behind the last tile did all 384 FMAs outside any MFMA's shadow: 6 % of an evaluation.)
+// p + (p of the lane 32 away): v_permlane32_swap (gfx950) leaves the low half's value in both halves of one register and the high half's in the other;
+// their sum is __shfl_xor(p, 32)'s bit for bit (an fp32 add commutes) without ds_bpermute's LDS round trip in the middle of an epilogue
+__device__ __forceinline__ float x6w_add_halves(float p) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 template <int U, bool LAST, bool STASH = false>
 __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
     if constexpr (STASH && U < 32 && (U & 1) == 0) STASH_ST(e.zst[(U >> 1) * REGF], v[U >> 1]);        // (v[r] is still the pre-activation: SiLU's last step comes at u = 2 r + 2)
@@ -119,11 +125,11 @@ __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& 
         }
         if constexpr (U == 35) {
 #pragma unroll
-            for (int o = 0; o < 6; ++o) e.rr[o] = __shfl_xor(e.p[o], 32);
+            for (int o = 0; o < 3; ++o) e.p[o] = x6w_add_halves(e.p[o]);
         }
         if constexpr (U == 36) {
 #pragma unroll
-            for (int o = 0; o < 6; ++o) e.p[o] += e.rr[o];
+            for (int o = 3; o < 6; ++o) e.p[o] = x6w_add_halves(e.p[o]);
         }
         if constexpr (U == 37) {
 #pragma unroll
@@ -370,7 +376,7 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, X6WRing& R, const floa
             p[3] = __builtin_fmaf(av, wa.w, p[3]); p[4] = __builtin_fmaf(av, wb.x, p[4]); p[5] = __builtin_fmaf(av, wb.y, p[5]);
         }
 #pragma unroll
-        for (int o = 0; o < 6; ++o) { p[o] += __shfl_xor(p[o], 32); out6[o] = e.out[o] + p[o]; }
+        for (int o = 0; o < 6; ++o) out6[o] = e.out[o] + x6w_add_halves(p[o]);
     }
     X6W_STAMP(c, 21);
 }
