@@ -84,8 +84,8 @@ struct X6WEpi {                    // transient state of one pending epilogue
 //   u = 2 r      E_r: t = exp2(-log2(e) z_r)            u = 2 r + 1   R_r: s = rcp(1 + t)            u = 2 r + 2   M_r: z_r s       (act_f<1>'s arithmetic)
 //   pair p = (2 p, 2 p + 1), complete at u = 4 p + 4:  u = 4 p + 5 .. 4 p + 8: the truncation split in four parts (3, 2, 3, 3 instructions)
 //   u = 22, u = 37: the three 16-byte LDS writes of K step m2 / m2 + 1 of the layer output
-// LAST (last hidden layer): no split - activation r enters the tile's six output-layer sums behind its SiLU: four FMAs at u = 2 r + 3, two at u = 2 r + 4
-// (weights of r + 1 requested behind them), the two lane halves added at u = 35, 36 (v_permlane32_swap), the tile added to the outputs at u = 37.  (Rounds 5-6: the
+// LAST (last hidden layer): no split - activation r enters the tile's six output-layer sums behind its SiLU: two FMAs per micro-slot over slots 3..45
+// (weights of r + 1 requested behind them), the two lane halves added at u = 46, 47 (v_permlane32_swap), the tile added to the outputs at u = 47.  (Rounds 5-6: the
 // activations went to LDS as floats and one pass behind the last tile did all 384 FMAs outside any MFMA's shadow: 6 % of an evaluation.)
 // p + (p of the lane 32 away): v_permlane32_swap (gfx950) leaves the low half's value in both halves of one register and the high half's in the other;
 // their sum is __shfl_xor(p, 32)'s bit for bit (an fp32 add commutes) without ds_bpermute's LDS round trip in the middle of an epilogue
@@ -110,28 +110,31 @@ __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& 
 #pragma unroll
             for (int o = 0; o < 6; ++o) e.p[o] = 0.f;
         }
+        // 48 FMA pairs g = 3 r + j (j = 0: outputs 0, 1; 1: outputs 2, 3; 2: outputs 4, 5) over slots 3..45, two pairs in every eighth slot: slot(g) = 3 + g - g / 8
+        // (>= 2 r + 3: activation r is complete); the 48-slot form evens out what 38 slots carried (2.69 k cycles for such a tile against 2.3 k for one with a split)
         if constexpr (U == 1) e.wa = wl[0];
         if constexpr (U == 2) e.wb = wl[1];
-        if constexpr (U >= 3 && U <= 34) {
-            constexpr int r = (U - 3) >> 1;
-            if constexpr (((U - 3) & 1) == 0) {
-                e.p[0] = __builtin_fmaf(v[r], e.wa.x, e.p[0]); e.p[1] = __builtin_fmaf(v[r], e.wa.y, e.p[1]);
-                e.p[2] = __builtin_fmaf(v[r], e.wa.z, e.p[2]); e.p[3] = __builtin_fmaf(v[r], e.wa.w, e.p[3]);
-                if constexpr (r < 15) e.wa = wl[2 * (r + 1)];
-            } else {
-                e.p[4] = __builtin_fmaf(v[r], e.wb.x, e.p[4]); e.p[5] = __builtin_fmaf(v[r], e.wb.y, e.p[5]);
-                if constexpr (r < 15) e.wb = wl[2 * (r + 1) + 1];
+        x6w_for(std::make_integer_sequence<int, 48>{}, [&](auto Gc) {
+            constexpr int g = decltype(Gc)::value, r = g / 3, j = g % 3;
+            if constexpr (3 + g - g / 8 == U) {
+                if constexpr (j == 0) { e.p[0] = __builtin_fmaf(v[r], e.wa.x, e.p[0]); e.p[1] = __builtin_fmaf(v[r], e.wa.y, e.p[1]); }
+                if constexpr (j == 1) {
+                    e.p[2] = __builtin_fmaf(v[r], e.wa.z, e.p[2]); e.p[3] = __builtin_fmaf(v[r], e.wa.w, e.p[3]);
+                    if constexpr (r < 15) e.wa = wl[2 * (r + 1)];
+                }
+                if constexpr (j == 2) {
+                    e.p[4] = __builtin_fmaf(v[r], e.wb.x, e.p[4]); e.p[5] = __builtin_fmaf(v[r], e.wb.y, e.p[5]);
+                    if constexpr (r < 15) e.wb = wl[2 * (r + 1) + 1];
+                }
             }
-        }
-        if constexpr (U == 35) {
+        });
+        if constexpr (U == 46) {
 #pragma unroll
             for (int o = 0; o < 3; ++o) e.p[o] = x6w_add_halves(e.p[o]);
         }
-        if constexpr (U == 36) {
+        if constexpr (U == 47) {
 #pragma unroll
             for (int o = 3; o < 6; ++o) e.p[o] = x6w_add_halves(e.p[o]);
-        }
-        if constexpr (U == 37) {
 #pragma unroll
             for (int o = 0; o < 6; ++o) e.out[o] += e.p[o];
         }
@@ -174,7 +177,7 @@ template <int U0, int N, bool LAST, bool STASH = false>
 __device__ __forceinline__ void x6w_micros(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
     x6w_for(std::make_integer_sequence<int, N>{}, [&](auto Uc) {
         constexpr int U = U0 + decltype(Uc)::value;
-        if constexpr (U < 38) x6w_micro<U, LAST, STASH>(c, v, e, m2);
+        if constexpr (U < (LAST ? 48 : 38)) x6w_micro<U, LAST, STASH>(c, v, e, m2);
     });
 }
 __device__ __forceinline__ void x6w_load_in(const X6W& c, b8_t (&in)[8][3], int s) {
@@ -237,7 +240,7 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
             } else if constexpr (KIND == 1) {                 // done by slot 29: two micro-slots in each of the first eight
                 if constexpr (I < 8) x6w_micros<2 * I, 2, PE_LAST, STASH>(c, pv, e, pm2);
                 else if constexpr (I < 30) x6w_micros<I + 8, 1, PE_LAST, STASH>(c, pv, e, pm2);
-            } else if constexpr (I < 38) x6w_micros<I, 1, PE_LAST, STASH>(c, pv, e, pm2);
+            } else if constexpr (I < (PE_LAST ? 48 : 38)) x6w_micros<I, 1, PE_LAST, STASH>(c, pv, e, pm2);
         }
 #endif
         if constexpr (KIND == 1 && I == 30) { x6w_load_in(c, in, 6); x6w_load_in(c, in, 7); }
