@@ -12,6 +12,9 @@
 // linear stream of 136 entries (layer 0: 8, layers 1..4: 32 each) through an eight-slot register ring, seven entries ahead.
 // Same products, same order of accumulation as k_rk2_x6 / k_rk2_x6_uni: results are bit-identical (tests/test_gpu_x6.py); DESIGN.md 4.8.2 has the
 // counters of both kernels and what was tried.
+// Round 6 (probes, per-tile stamps, two alternative kernels built and dropped): a tile's time is the wave's ISSUE time - 1.33 k cycles of
+// epilogue VALU + 0.6 k for its 24 weight loads + the MFMAs' own issue = 2.27 k against 1.54 k of matrix time; the output layer's sums ride in the layer-4
+// epilogues, the MFMA is pinned first in its slot, an evaluation sends for its successor's first ring entries before its uncovered tail.
 #include <stdlib.h>
 #include <utility>
 #include "common.h"
@@ -78,7 +81,6 @@ struct X6WEpi {                    // transient state of one pending epilogue
     float* zst;                    // STASH: the pending tile's sixteen z rows (+ lane): pre-activation r is stored at u = 2 r, in the MFMAs' shadow
 };
 // piece I (0..35) of the epilogue of a row tile: v = its 16 pre-activations; K steps m2, m2 + 1 of the layer output
-// LAST (last hidden layer): the activations themselves go to LDS (rows m2 * 2 .. of the same buffer, as floats) for the output layer
 // The epilogue of a row tile as 38 micro-slots of about one transcendental + four plain VALU instructions each - what one 16-bit MFMA leaves
 // room for in the same wave (dual_pipe_probe3; a slot with two transcendentals or six plain instructions costs ~45 cycles instead of 34):
 //   u = 2 r      E_r: t = exp2(-log2(e) z_r)            u = 2 r + 1   R_r: s = rcp(1 + t)            u = 2 r + 2   M_r: z_r s       (act_f<1>'s arithmetic)
