@@ -269,6 +269,28 @@ __device__ __forceinline__ void stash_st16_x4(float* base16, int lane, const f32
 #endif
     }
 }
+__device__ __forceinline__ void stash_st16_x4(float* base16, int lane, const float (&v)[16]) {
+    f32x4s* p = reinterpret_cast<f32x4s*>(base16) + lane;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x4s q = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+#ifdef NVFI_STASH_TEMPORAL
+        p[k * 64] = q;
+#else
+        __builtin_nontemporal_store(q, p + k * 64);
+#endif
+    }
+}
+// rows 4 k .. 4 k + 3 of an x4 block group for this lane (the reader's side of stash_st16_x4)
+__device__ __forceinline__ void stash_ld4_x4(const float* base16, int lane, int k, float* v4) {
+    const f32x4s* p = reinterpret_cast<const f32x4s*>(base16) + lane + k * 64;
+#ifdef NVFI_STASH_TEMPORAL
+    const f32x4s q = *p;
+#else
+    const f32x4s q = __builtin_nontemporal_load(p);
+#endif
+    v4[0] = q[0]; v4[1] = q[1]; v4[2] = q[2]; v4[3] = q[3];
+}
 template <int NR>
 __device__ __forceinline__ void stash_store(float* base, int lane, const float* v) {
 #pragma unroll

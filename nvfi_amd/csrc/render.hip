@@ -144,6 +144,16 @@ __global__ __launch_bounds__(256) void k_fill(int64_t R, int S, const uint8_t* _
 // ---------------------------------------------------------------- round 5: the same lists without the second (and third) launch
 // NVFI_FUSED_LAUNCH (default 1): the producers of the flags place the list entries themselves (look-back, common.h); 0 keeps the
 // count + k_fill launches of rounds 1-4.  Same flags, same order: the lists are identical entry for entry.
+// the training warp's kernel family and what it means for the stash layout (forward and backward must agree, so both ask here):
+// NVFI_RK2_X6 (default 1): the x6 kernels; NVFI_RK2_FUSE (default 1): the adjoint + hidden-layer weight gradients in one persistent kernel - then the z
+// rows of layers 0..3 have ONE reader and travel as x4 stash blocks (a quarter of the stash instructions on both sides; NVFI_RK2_X4=0: row-major)
+static bool warp_x6_on() { static int v = -1; if (v < 0) { const char* e = getenv("NVFI_RK2_X6"); v = e ? atoi(e) : 1; } return v != 0; }
+static bool rk2_fuse_on() { static int v = -1; if (v < 0) { const char* e = getenv("NVFI_RK2_FUSE"); v = e ? atoi(e) : 1; } return v != 0; }
+static bool warp_stash_x4(const nvfi_field_desc* f) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("NVFI_RK2_X4"); v = e ? atoi(e) : 1; }
+    return v != 0 && warp_x6_on() && rk2_fuse_on() && !(f->vel_fp16 & 4);
+}
 bool fused_launch() { static int u = -1; if (u < 0) { const char* e = getenv("NVFI_FUSED_LAUNCH"); u = e ? atoi(e) : 1; } return u != 0; }
 
 // k_sample + the two k_fill launches behind it
@@ -1528,10 +1538,9 @@ static int render_fwd_impl(const nvfi_field_desc* f, int64_t R, const float* ray
         // numbers bit for bit - was retired in round 6)
         // round 5: the warp on the x6 evaluation (vel_x6.hip: the hidden layers' fp32 products formed exactly from three bfloat16 terms per operand
         // on the 16-bit matrix pipe; same stash / records for the fp32 adjoint) unless NVFI_RK2_X6=0 or an fp16-input mode is asked for
-        static int x6 = -1;
-        if (x6 < 0) { const char* e = getenv("NVFI_RK2_X6"); x6 = e ? atoi(e) : 1; }
         const int vf = f->vel_fp16 & 3;
-        if ((x6 && !(train && (f->vel_fp16 & 4)) && (train || vf == 0 || vf == 3)) || (!train && vf == 3)) {
+        if ((warp_x6_on() && !(train && (f->vel_fp16 & 4)) && (train || vf == 0 || vf == 3)) || (!train && vf == 3)) {
+            ra.z_x4 = (train && warp_stash_x4(f)) ? 1 : 0;
             X6UniArgs xa; xa.r = ra; xa.img = cached ? FC.vel_x6 : P.x6img;
             if (!cached && launch_pack_x6(f->vW, P.x6img, st)) return 1;
             if (launch_rk2_x6_uni(xa, N, train, st)) return 1;
@@ -1781,8 +1790,8 @@ extern "C" int nvfi_render_bwd_t(const nvfi_field_desc* f, int64_t R, const floa
         ra.zst = P.zst; ra.x0st = P.x0st; ra.rec = P.rec; ra.gst = P.gst; ra.cap = N; ra.cap_tiles = P.cap_tiles; ra.gxk = P.gxk;
         // NVFI_RK2_FUSE (default 1): vel_fuse.hip - the adjoint AND the four 128 x 128 weight gradients in one persistent kernel (no g_1..g_4
         // stash, no second pass over the z stash); 0: k_rk2_split_bwd + k_wgrad_ring8 over the full adjoint stash
-        static int fuse = -1;
-        if (fuse < 0) { const char* e = getenv("NVFI_RK2_FUSE"); fuse = e ? atoi(e) : 1; }
+        const int fuse = rk2_fuse_on() ? 1 : 0;
+        ra.z_x4 = warp_stash_x4(f) ? 1 : 0;                              // (what the forward wrote: the same predicate)
         float* vslabs = (fork2 || merge_wgrad) ? P.slabs2 : P.slabs;      // (merged launches: the render MLP's slabs in P.slabs are still live)
         int fused_nslab = 0;
         if (fuse) {

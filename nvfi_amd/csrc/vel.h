@@ -35,6 +35,7 @@ struct Rk2Args {
     // stashes (training)
     float* zst; float* x0st; float* rec; float* gst;
     int64_t cap; int64_t cap_tiles;
+    int z_x4;              // the z rows of layers 0..3 are x4 stash blocks (engine.h: stash_st16_x4): written by the x6 warp kernels, read by the fused adjoint only
     // backward
     const float4* gxk;     // (dense, per sample) upstream gradient wrt the warped position
 };

@@ -75,6 +75,7 @@ struct FuseA {
     int xw;              // X buffer that receives the next evaluation's g_4
     b8_t* XS;            // x6: the two split-operand exchange images (+ lane); GT at + 2 images, AT at + 4 images
     const b8_t* imgT;    // x6: transposed images (term stride X6_H8)
+    int z_x4;            // Rk2Args::z_x4 (wave-uniform)
     b8_t I0, I1;         // x6: the selection matrices of the transposing MFMAs (K step 0 / 1 of a row tile -> columns p' = 2 r + h)
 };
 #ifdef FUSE_TIMING
@@ -100,6 +101,19 @@ struct FuseT { unsigned long long ft[64]; unsigned long long t0; };
 #else
 #define FUSE_WAIT_PARK() asm volatile("s_waitcnt vmcnt(16)" ::: "memory")
 #endif
+// the sixteen z rows of this wave's row tile of a layer 0..3: row-major rows, or - Rk2Args::z_x4, the x6 warp kernels wrote them so - x4 stash blocks
+// (four 16-byte loads; engine.h: stash_st16_x4).  Layer 4's rows stay row-major: k_wgrad_ring8 reads them too.
+#define FUSE_LD_Z16(zr, x4)                                                                                     \
+    do {                                                                                                        \
+        if (x4) {                                                                                               \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                     \
+                const f32x4s q4 = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f32x4s*>(zr) + k * 64 + lane);   \
+                zp[4 * k] = q4[0]; zp[4 * k + 1] = q4[1]; zp[4 * k + 2] = q4[2]; zp[4 * k + 3] = q4[3];      \
+            }                                                                                                   \
+        } else {                                                                                                \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);              \
+        }                                                                                                       \
+    } while (0)
 template <class Hook>
 __device__ __forceinline__ void fuse_velnet_bwd(FuseA& A, const float4* const* t4, const float (&r4)[4], const float* zs, float* gs,
                                                 const float* zn, f32x4v& w5, f32x4v (&wq)[16], float (&zp)[16], float (&ge)[16], Hook hook FT_ARG) {
@@ -130,8 +144,7 @@ __device__ __forceinline__ void fuse_velnet_bwd(FuseA& A, const float4* const* t
     for (int r = 0; r < 16; ++r) gv[r] = acc[r] * act_d1<1>(zp[r]);
     {
         gcfp zr = opaque_u(zs + (size_t)(3 * 64 + 16 * w) * REGF);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+        FUSE_LD_Z16(zr, A.z_x4);
     }
     int xc = A.xw;                                        // buffer of g_l for the dgrad of iteration l
     {
@@ -192,8 +205,7 @@ __device__ __forceinline__ void fuse_velnet_bwd(FuseA& A, const float4* const* t
             // keep two generations of z rows live: 16 registers the kernel does not have)
             __builtin_amdgcn_sched_barrier(0);
             gcfp zr = opaque_u(zs + (size_t)((l - 2) * 64 + 16 * w) * REGF);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+            FUSE_LD_Z16(zr, A.z_x4);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -322,8 +334,7 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
     for (int r = 0; r < 16; ++r) gv[r] = acc[r] * act_d1<1>(zp[r]);
     {
         gcfp zr = opaque_u(zs + (size_t)(3 * 64 + 16 * w) * REGF);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+        FUSE_LD_Z16(zr, A.z_x4);
     }
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
@@ -400,8 +411,7 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
         __builtin_amdgcn_sched_barrier(0);
         if (l >= 2) {
             gcfp zr = opaque_u(zs + (size_t)((l - 2) * 64 + 16 * w) * REGF);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);
+            FUSE_LD_Z16(zr, A.z_x4);
         }
         // the contraction waves' B operands of layer l: a_{l-1} (this wave's 32 columns) transposed
 #pragma unroll
@@ -498,7 +508,7 @@ __device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* 
     float* const park0 = X6 ? reinterpret_cast<float*>(xs0 + 6 * FUSE_XS_H8) : bc0 + 4 * 16 * 64;
     float* const bc = X6 ? reinterpret_cast<float*>(xs0 + FUSE_XS_H8) : bc0;
     FuseA A; A.X = X; A.Y = Y; A.bc = bc; A.w = w; A.lane = lane; A.h = lane >> 5; A.xw = 0;
-    A.XS = xs0 + lane; A.imgT = reinterpret_cast<const b8_t*>(a.imgT);
+    A.XS = xs0 + lane; A.imgT = reinterpret_cast<const b8_t*>(a.imgT); A.z_x4 = a.r.z_x4;
     if (X6) {       // selection matrices: element j of lane (n, kg) of K step ks is 1.0 where n = p' = 16 ks + 2 j + kg (row r = 8 ks + j of half kg)
         typedef unsigned fi_u32x4 __attribute__((ext_vector_type(4)));
         const int n = lane & 31, kg = lane >> 5;

@@ -105,7 +105,7 @@ __device__ __forceinline__ void x6_step(const b8_t& A1, const b8_t& A2, const b8
 // slots go to the per-(evaluation, tile) stash in the layout of k_rk2_split_uni<STASH> (vel_split.hip): the fp32 adjoint kernels read it unchanged
 template <int NT, bool STASH = false>
 __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xch, float4* part, const float4* w5l, int w, int lane, int h,
-                                          const float4* q, const float* lb, float (&out6)[NT][6], float* const* zst = nullptr, float* const* x0st = nullptr) {
+                                          const float4* q, const float* lb, float (&out6)[NT][6], float* const* zst = nullptr, float* const* x0st = nullptr, bool z_x4 = false) {
     const b8_t* W1 = img; const b8_t* W2 = img + X6_H8; const b8_t* W3 = img + 2 * X6_H8;
     f32x16 a0[NT], a1[NT];
     b8_t Bf[NT][8][3];
@@ -162,9 +162,13 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
         for (int s = 0; s < 3; ++s) { A1[s] = P1[s * 64]; A2[s] = P2[s * 64]; A3[s] = P3[s * 64]; }
         if (STASH) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
+                if (z_x4) stash_st16_x4(zst[t] + (size_t)(l * 64 + 16 * w) * REGF, lane, v[t]);      // (Rk2Args::z_x4: four 16-byte stores instead of sixteen rows)
+                else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) STASH_ST(zst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane], v[t][r]);
+                    for (int r = 0; r < 16; ++r) STASH_ST(zst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane], v[t][r]);
+                }
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6_uni(X6Un
         float4 q[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur);
-        velnet_x6<NT, STASH>(img, xch, part, w5l, w, lane, h, q, lb, o6, z1, x1);
+        velnet_x6<NT, STASH>(img, xch, part, w5l, w, lane, h, q, lb, o6, z1, x1, ra.z_x4 != 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v1[3];
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6_uni(X6Un
             px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
             q[t] = make_float4(px[t], py[t], pz[t], tcur - hdt);
         }
-        velnet_x6<NT, STASH>(img, xch, part, w5l, w, lane, h, q, lb, o6, z2, x2);
+        velnet_x6<NT, STASH>(img, xch, part, w5l, w, lane, h, q, lb, o6, z2, x2, ra.z_x4 != 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v2[3];

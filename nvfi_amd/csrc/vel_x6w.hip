@@ -52,6 +52,7 @@ typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 #endif
 struct X6W {
     int stamp;
+    int z_x4;                      // STASH: Rk2Args::z_x4
     unsigned vo;                   // lane * 16
 #ifdef X6W_BUFLD
     __amdgpu_buffer_rsrc_t RW1, RW2, RW3; int so;
@@ -79,6 +80,7 @@ struct X6WEpi {                    // transient state of one pending epilogue
     float4 wa, wb;                 // output-layer weights of the activation whose turn is next (LDS broadcast reads, two micro-slots ahead; four ahead: no faster)
     float out[6];                  // the evaluation's outputs: bias, then the row tiles in order
     float* zst;                    // STASH: the pending tile's sixteen z rows (+ lane): pre-activation r is stored at u = 2 r, in the MFMAs' shadow
+    int x4;                        // ... as x4 stash blocks (this tile belongs to layers 0..3 and Rk2Args::z_x4 is set)
 };
 // piece I (0..35) of the epilogue of a row tile: v = its 16 pre-activations; K steps m2, m2 + 1 of the layer output
 // The epilogue of a row tile as 38 micro-slots of about one transcendental + four plain VALU instructions each - what one 16-bit MFMA leaves
@@ -97,7 +99,14 @@ __device__ __forceinline__ float x6w_add_halves(float p) {
 }
 template <int U, bool LAST, bool STASH = false>
 __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
-    if constexpr (STASH && U < 32 && (U & 1) == 0) STASH_ST(e.zst[(U >> 1) * REGF], v[U >> 1]);        // (v[r] is still the pre-activation: SiLU's last step comes at u = 2 r + 2)
+    if constexpr (STASH && U < 32 && (U & 1) == 0) {       // (v[r] is still the pre-activation: SiLU's last step comes at u = 2 r + 2)
+        if (e.x4) {                                        // Rk2Args::z_x4, layers 0..3: rows 4 k .. 4 k + 3 as one 16-byte store at u = 8 k (row 4 k changes at u = 8 k + 2)
+            if constexpr ((U & 7) == 0) {
+                const f32x4s q = {v[U >> 1], v[(U >> 1) + 1], v[(U >> 1) + 2], v[(U >> 1) + 3]};
+                __builtin_nontemporal_store(q, reinterpret_cast<f32x4s*>(e.zst - c.lane) + c.lane + (U >> 3) * 64);
+            }
+        } else STASH_ST(e.zst[(U >> 1) * REGF], v[U >> 1]);
+    }
 #ifndef X6W_PROBE_NO_SILU            // (timing probe: identity activation)
     if constexpr (U < 32) {
         constexpr int r = U >> 1;
@@ -262,7 +271,7 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
         if constexpr (KIND == 4) {             // (the evaluation's last tile has no successor whose MFMAs could cover its stores)
 #pragma unroll
             for (int r = 0; r < 16; ++r) STASH_ST(c.zp[r * REGF], nv[r]);
-        } else e.zst = c.zp;                   // round 6: stored row by row from the epilogue's micro-slots (sixteen stores in a row here were 400 uncovered cycles per tile)
+        } else { e.zst = c.zp; e.x4 = (c.z_x4 && LROW < 512) ? 1 : 0; }      // round 6: stored from the epilogue's micro-slots (sixteen stores in a row here were 400 uncovered cycles per tile)
         c.zp += 16 * REGF;
         asm volatile("" : "+v"(c.zp));
     }
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
     const int ti = a.pt_by_list ? n : i;
     float tcur = active ? a.pt_t[ti] : 0.f;
     float off = active ? tcur - a.pt_base[ti] : 0.f;
-    X6W c; c.stamp = 0;
+    X6W c; c.stamp = 0; c.z_x4 = 0;
     const b8_t* img = reinterpret_cast<const b8_t*>(a.img);
     c.W1 = X6W_PTR(img, lane); c.W2 = X6W_PTR(img + X6_H8, lane); c.W3 = X6W_PTR(img + 2 * X6_H8, lane); c.vo = (unsigned)lane * 16u;
 #ifdef X6W_BUFLD
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w_uni(X6UniArgs a) {
     const float4 q0 = active ? ra.xw[n] : zero4();
     float x = q0.x, y = q0.y, z = q0.z;
     const float zw = q0.w;
-    X6W c; c.stamp = 0;
+    X6W c; c.stamp = 0; c.z_x4 = STASH ? ra.z_x4 : 0;
     const b8_t* img = reinterpret_cast<const b8_t*>(a.img);
     c.W1 = X6W_PTR(img, lane); c.W2 = X6W_PTR(img + X6_H8, lane); c.W3 = X6W_PTR(img + 2 * X6_H8, lane); c.vo = (unsigned)lane * 16u;
 #ifdef X6W_BUFLD
