@@ -52,7 +52,6 @@ typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 #endif
 struct X6W {
     int stamp;
-    int z_x4;                      // STASH: Rk2Args::z_x4
     unsigned vo;                   // lane * 16
 #ifdef X6W_BUFLD
     __amdgpu_buffer_rsrc_t RW1, RW2, RW3; int so;
@@ -80,7 +79,6 @@ struct X6WEpi {                    // transient state of one pending epilogue
     float4 wa, wb;                 // output-layer weights of the activation whose turn is next (LDS broadcast reads, two micro-slots ahead; four ahead: no faster)
     float out[6];                  // the evaluation's outputs: bias, then the row tiles in order
     float* zst;                    // STASH: the pending tile's sixteen z rows (+ lane): pre-activation r is stored at u = 2 r, in the MFMAs' shadow
-    int x4;                        // ... as x4 stash blocks (this tile belongs to layers 0..3 and Rk2Args::z_x4 is set)
 };
 // piece I (0..35) of the epilogue of a row tile: v = its 16 pre-activations; K steps m2, m2 + 1 of the layer output
 // The epilogue of a row tile as 38 micro-slots of about one transcendental + four plain VALU instructions each - what one 16-bit MFMA leaves
@@ -97,10 +95,11 @@ __device__ __forceinline__ float x6w_add_halves(float p) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-template <int U, bool LAST, bool STASH = false>
+// STASH: 0 no stash | 1 row-major z rows | 2 x4 blocks for the row tiles of layers 0..3 (Rk2Args::z_x4); PX4: the PENDING tile is one of those
+template <int U, bool LAST, int STASH = 0, bool PX4 = false>
 __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
     if constexpr (STASH && U < 32 && (U & 1) == 0) {       // (v[r] is still the pre-activation: SiLU's last step comes at u = 2 r + 2)
-        if (e.x4) {                                        // Rk2Args::z_x4, layers 0..3: rows 4 k .. 4 k + 3 as one 16-byte store at u = 8 k (row 4 k changes at u = 8 k + 2)
+        if constexpr (PX4) {                               // rows 4 k .. 4 k + 3 as one 16-byte store at u = 8 k (row 4 k changes at u = 8 k + 2)
             if constexpr ((U & 7) == 0) {
                 const f32x4s q = {v[U >> 1], v[(U >> 1) + 1], v[(U >> 1) + 2], v[(U >> 1) + 3]};
                 __builtin_nontemporal_store(q, reinterpret_cast<f32x4s*>(e.zst - c.lane) + c.lane + (U >> 3) * 64);
@@ -184,11 +183,11 @@ __device__ __forceinline__ void x6w_micro(const X6W& c, float (&v)[16], X6WEpi& 
         }
     }
 }
-template <int U0, int N, bool LAST, bool STASH = false>
+template <int U0, int N, bool LAST, int STASH = 0, bool PX4 = false>
 __device__ __forceinline__ void x6w_micros(const X6W& c, float (&v)[16], X6WEpi& e, int m2) {
     x6w_for(std::make_integer_sequence<int, N>{}, [&](auto Uc) {
         constexpr int U = U0 + decltype(Uc)::value;
-        if constexpr (U < (LAST ? 48 : 38)) x6w_micro<U, LAST, STASH>(c, v, e, m2);
+        if constexpr (U < (LAST ? 48 : 38)) x6w_micro<U, LAST, STASH, PX4>(c, v, e, m2);
     });
 }
 __device__ __forceinline__ void x6w_load_in(const X6W& c, b8_t (&in)[8][3], int s) {
@@ -211,7 +210,7 @@ __device__ __forceinline__ void x6w_mfma(const b8_t& A1, const b8_t& A2, const b
 // previous layer's last tile: its 38 micro-slots in slots 0..29, its K steps 6, 7 pulled into `in` at slot 30, read at slot 36) | 2 middle tile |
 // 3 last tile of a hidden layer that has a successor (releases in[s] K step by K step and pulls the next layer's input in behind) | 4 last tile
 // of the last hidden layer
-template <int E0, int KIND, int LROW, bool HAVE_PE, bool PE_LAST, bool STASH = false>
+template <int E0, int KIND, int LROW, bool HAVE_PE, bool PE_LAST, int STASH = 0>
 __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2)[X6W_RING], b8_t (&A3)[X6W_RING], const b8_t (&X0)[2][3], b8_t (&in)[8][3],
                                          float (&pv)[16], X6WEpi& e, int pm2, float (&nv)[16], f32x16& bias) {
     constexpr int NS = KIND == 0 ? 2 : 8;
@@ -246,12 +245,12 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
 #ifndef X6W_PROBE_NO_EPILOGUE          // (timing probe; NOT the MFMA stream alone: without the epilogue the earlier tiles' MFMAs are dead code and go too)
         if constexpr (HAVE_PE) {
             if constexpr (KIND == 0) {                        // 12 slots: 4 micro-slots in the first two, 3 in the others
-                if constexpr (I < 2) x6w_micros<4 * I, 4, PE_LAST, STASH>(c, pv, e, pm2);
-                else x6w_micros<8 + 3 * (I - 2), 3, PE_LAST, STASH>(c, pv, e, pm2);
+                if constexpr (I < 2) x6w_micros<4 * I, 4, PE_LAST, STASH, (STASH == 2 && LROW >= 32 && LROW - 32 < 512)>(c, pv, e, pm2);
+                else x6w_micros<8 + 3 * (I - 2), 3, PE_LAST, STASH, (STASH == 2 && LROW >= 32 && LROW - 32 < 512)>(c, pv, e, pm2);
             } else if constexpr (KIND == 1) {                 // done by slot 29: two micro-slots in each of the first eight
-                if constexpr (I < 8) x6w_micros<2 * I, 2, PE_LAST, STASH>(c, pv, e, pm2);
-                else if constexpr (I < 30) x6w_micros<I + 8, 1, PE_LAST, STASH>(c, pv, e, pm2);
-            } else if constexpr (I < (PE_LAST ? 48 : 38)) x6w_micros<I, 1, PE_LAST, STASH>(c, pv, e, pm2);
+                if constexpr (I < 8) x6w_micros<2 * I, 2, PE_LAST, STASH, (STASH == 2 && LROW >= 32 && LROW - 32 < 512)>(c, pv, e, pm2);
+                else if constexpr (I < 30) x6w_micros<I + 8, 1, PE_LAST, STASH, (STASH == 2 && LROW >= 32 && LROW - 32 < 512)>(c, pv, e, pm2);
+            } else if constexpr (I < (PE_LAST ? 48 : 38)) x6w_micros<I, 1, PE_LAST, STASH, (STASH == 2 && LROW >= 32 && LROW - 32 < 512)>(c, pv, e, pm2);
         }
 #endif
         if constexpr (KIND == 1 && I == 30) { x6w_load_in(c, in, 6); x6w_load_in(c, in, 7); }
@@ -271,7 +270,7 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
         if constexpr (KIND == 4) {             // (the evaluation's last tile has no successor whose MFMAs could cover its stores)
 #pragma unroll
             for (int r = 0; r < 16; ++r) STASH_ST(c.zp[r * REGF], nv[r]);
-        } else { e.zst = c.zp; e.x4 = (c.z_x4 && LROW < 512) ? 1 : 0; }      // round 6: stored from the epilogue's micro-slots (sixteen stores in a row here were 400 uncovered cycles per tile)
+        } else e.zst = c.zp;                   // round 6: stored from the epilogue's micro-slots (sixteen stores in a row here were 400 uncovered cycles per tile)
         c.zp += 16 * REGF;
         asm volatile("" : "+v"(c.zp));
     }
@@ -297,7 +296,7 @@ __device__ __forceinline__ void x6w_prime(const X6W& c0, X6WRing& R) {
         R.A1[en] = X6W_LD(c, W1, en & 3); R.A2[en] = X6W_LD(c, W2, en & 3); R.A3[en] = X6W_LD(c, W3, en & 3);
     }
 }
-template <bool STASH = false>
+template <int STASH = 0>
 __device__ __forceinline__ void velnet_x6w(const X6W& c0, X6WRing& R, const float4& q, float (&out6)[6], float* zst = nullptr, float* x0st = nullptr) {
     X6W c = c0;
     X6W_STAMP(c, 0);
@@ -422,7 +421,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w(X6Args a) {
     const int ti = a.pt_by_list ? n : i;
     float tcur = active ? a.pt_t[ti] : 0.f;
     float off = active ? tcur - a.pt_base[ti] : 0.f;
-    X6W c; c.stamp = 0; c.z_x4 = 0;
+    X6W c; c.stamp = 0;
     const b8_t* img = reinterpret_cast<const b8_t*>(a.img);
     c.W1 = X6W_PTR(img, lane); c.W2 = X6W_PTR(img + X6_H8, lane); c.W3 = X6W_PTR(img + 2 * X6_H8, lane); c.vo = (unsigned)lane * 16u;
 #ifdef X6W_BUFLD
@@ -489,7 +488,7 @@ static int x6w_set_lds(K kernel) {
 }
 // ---------------------------------------------------------------- render warp (uniform schedule; k_rk2_x6_uni of vel_x6.hip, one wave per tile)
 // A workgroup = four consecutive tiles = one 128-sample group of the stash geometry (training: the adjoint walks whole groups)
-template <bool STASH>
+template <int STASH>
 __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w_uni(X6UniArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lb = lds;
@@ -514,7 +513,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_rk2_x6w_uni(X6UniArgs a) {
     const float4 q0 = active ? ra.xw[n] : zero4();
     float x = q0.x, y = q0.y, z = q0.z;
     const float zw = q0.w;
-    X6W c; c.stamp = 0; c.z_x4 = STASH ? ra.z_x4 : 0;
+    X6W c; c.stamp = 0;
     const b8_t* img = reinterpret_cast<const b8_t*>(a.img);
     c.W1 = X6W_PTR(img, lane); c.W2 = X6W_PTR(img + X6_H8, lane); c.W3 = X6W_PTR(img + 2 * X6_H8, lane); c.vo = (unsigned)lane * 16u;
 #ifdef X6W_BUFLD
@@ -571,9 +570,10 @@ int launch_rk2_x6w_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipS
     const int64_t groups = (cap_samples + WG_SAMPLES - 1) / WG_SAMPLES;
     if (groups <= 0) return 0;
     static DeviceOnce once;
-    if (once.run([] { return (x6w_set_lds(k_rk2_x6w_uni<true>) || x6w_set_lds(k_rk2_x6w_uni<false>)) ? 1 : 0; })) return 1;
-    if (stash) hipLaunchKernelGGL(k_rk2_x6w_uni<true>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL(k_rk2_x6w_uni<false>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
+    if (once.run([] { return (x6w_set_lds(k_rk2_x6w_uni<2>) || x6w_set_lds(k_rk2_x6w_uni<1>) || x6w_set_lds(k_rk2_x6w_uni<0>)) ? 1 : 0; })) return 1;
+    if (stash && a.r.z_x4) hipLaunchKernelGGL(k_rk2_x6w_uni<2>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
+    else if (stash) hipLaunchKernelGGL(k_rk2_x6w_uni<1>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(k_rk2_x6w_uni<0>, dim3((unsigned)groups), dim3(WG_THREADS), X6W_LDS_BYTES, st, a);
     LAUNCHCK();
     return 0;
 }
