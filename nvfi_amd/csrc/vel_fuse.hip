@@ -75,7 +75,6 @@ struct FuseA {
     int xw;              // X buffer that receives the next evaluation's g_4
     b8_t* XS;            // x6: the two split-operand exchange images (+ lane); GT at + 2 images, AT at + 4 images
     const b8_t* imgT;    // x6: transposed images (term stride X6_H8)
-    int z_x4;            // Rk2Args::z_x4 (wave-uniform)
     b8_t I0, I1;         // x6: the selection matrices of the transposing MFMAs (K step 0 / 1 of a row tile -> columns p' = 2 r + h)
 };
 #ifdef FUSE_TIMING
@@ -114,7 +113,7 @@ struct FuseT { unsigned long long ft[64]; unsigned long long t0; };
             _Pragma("unroll") for (int r = 0; r < 16; ++r) zp[r] = STASH_LD(zr[r * REGF + lane]);              \
         }                                                                                                       \
     } while (0)
-template <class Hook>
+template <bool X4, class Hook>
 __device__ __forceinline__ void fuse_velnet_bwd(FuseA& A, const float4* const* t4, const float (&r4)[4], const float* zs, float* gs,
                                                 const float* zn, f32x4v& w5, f32x4v (&wq)[16], float (&zp)[16], float (&ge)[16], Hook hook FT_ARG) {
     const int w = A.w, lane = A.lane;
@@ -144,7 +143,7 @@ __device__ __forceinline__ void fuse_velnet_bwd(FuseA& A, const float4* const* t
     for (int r = 0; r < 16; ++r) gv[r] = acc[r] * act_d1<1>(zp[r]);
     {
         gcfp zr = opaque_u(zs + (size_t)(3 * 64 + 16 * w) * REGF);
-        FUSE_LD_Z16(zr, A.z_x4);
+        FUSE_LD_Z16(zr, X4);
     }
     int xc = A.xw;                                        // buffer of g_l for the dgrad of iteration l
     {
@@ -205,7 +204,7 @@ __device__ __forceinline__ void fuse_velnet_bwd(FuseA& A, const float4* const* t
             // keep two generations of z rows live: 16 registers the kernel does not have)
             __builtin_amdgcn_sched_barrier(0);
             gcfp zr = opaque_u(zs + (size_t)((l - 2) * 64 + 16 * w) * REGF);
-            FUSE_LD_Z16(zr, A.z_x4);
+            FUSE_LD_Z16(zr, X4);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -301,7 +300,7 @@ __device__ __forceinline__ void fuse_x6_transpose(const FuseA& A, const b8_t& p0
     dst[0] = __builtin_bit_cast(b8_t, lo);
     dst[3 * 64] = __builtin_bit_cast(b8_t, hi);
 }
-template <class Hook>
+template <bool X4, class Hook>
 __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const* t4, const float (&r4)[4], const float* zs, float* gs,
                                                    const float* zn, f32x4v& w5, float (&zp)[16], float (&ge)[16], Hook hook FT_ARG) {
     const int w = A.w, lane = A.lane;
@@ -334,7 +333,7 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
     for (int r = 0; r < 16; ++r) gv[r] = acc[r] * act_d1<1>(zp[r]);
     {
         gcfp zr = opaque_u(zs + (size_t)(3 * 64 + 16 * w) * REGF);
-        FUSE_LD_Z16(zr, A.z_x4);
+        FUSE_LD_Z16(zr, X4);
     }
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
@@ -411,7 +410,7 @@ __device__ __forceinline__ void fuse_velnet_bwd_x6(FuseA& A, const float4* const
         __builtin_amdgcn_sched_barrier(0);
         if (l >= 2) {
             gcfp zr = opaque_u(zs + (size_t)((l - 2) * 64 + 16 * w) * REGF);
-            FUSE_LD_Z16(zr, A.z_x4);
+            FUSE_LD_Z16(zr, X4);
         }
         // the contraction waves' B operands of layer l: a_{l-1} (this wave's 32 columns) transposed
 #pragma unroll
@@ -500,7 +499,7 @@ __device__ __forceinline__ void fuse_park_rec(const Rk2Args& ra, int s, int e, i
     }
 }
 
-template <bool X6>
+template <bool X6, bool X4>
 __device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* X, float4* Y, float* bc0, int w, int lane, int ntiles) {
     const Rk2Args& ra = a.r;
     // fp32 variant: X | Y | bc | parking areas.  x6 variant (X is the start of LDS): XS0 | XS1 = bc | GT0 | GT1 | AT0 | AT1 | parking areas
@@ -508,7 +507,7 @@ __device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* 
     float* const park0 = X6 ? reinterpret_cast<float*>(xs0 + 6 * FUSE_XS_H8) : bc0 + 4 * 16 * 64;
     float* const bc = X6 ? reinterpret_cast<float*>(xs0 + FUSE_XS_H8) : bc0;
     FuseA A; A.X = X; A.Y = Y; A.bc = bc; A.w = w; A.lane = lane; A.h = lane >> 5; A.xw = 0;
-    A.XS = xs0 + lane; A.imgT = reinterpret_cast<const b8_t*>(a.imgT); A.z_x4 = a.r.z_x4;
+    A.XS = xs0 + lane; A.imgT = reinterpret_cast<const b8_t*>(a.imgT);
     if (X6) {       // selection matrices: element j of lane (n, kg) of K step ks is 1.0 where n = p' = 16 ks + 2 j + kg (row r = 8 ks + j of half kg)
         typedef unsigned fi_u32x4 __attribute__((ext_vector_type(4)));
         const int n = lane & 31, kg = lane >> 5;
@@ -619,8 +618,8 @@ __device__ __forceinline__ void fuse_role_adjoint(const FuseBwdArgs& a, float4* 
                         for (int c = 0; c < 3; ++c) glds4(reinterpret_cast<const float*>(ra.gxk) + c, list_t * 16, park_lds + (10 + c) * 256);
                     }
                 };
-                if constexpr (X6) fuse_velnet_bwd_x6(A, a.t4, r4, ra.zst + es * zt, ra.gst + es * gt, zn, w5, zp, ge, prefetch FT_PASS);
-                else fuse_velnet_bwd(A, a.t4, r4, ra.zst + es * zt, ra.gst + es * gt, zn, w5, wq, zp, ge, prefetch FT_PASS);
+                if constexpr (X6) fuse_velnet_bwd_x6<X4>(A, a.t4, r4, ra.zst + es * zt, ra.gst + es * gt, zn, w5, zp, ge, prefetch FT_PASS);
+                else fuse_velnet_bwd<X4>(A, a.t4, r4, ra.zst + es * zt, ra.gst + es * gt, zn, w5, wq, zp, ge, prefetch FT_PASS);
                 const float4 gq = fuse_encode_bwd(make_float4(p[0], p[1], p[2], te), ge, h);
                 gloc[0] += gq.x; gloc[1] += gq.y; gloc[2] += gq.z;
 #pragma unroll
@@ -828,7 +827,9 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_rk2_fuse_bwd(FuseBwdArgs a) {
     if (wave < 4) {
 #endif
         __builtin_amdgcn_s_setprio(3);
-        fuse_role_adjoint<X6>(a, X, Y, bc, wave, lane, ntiles);
+        // (Rk2Args::z_x4 picks the stash-load form once, here: a branch inside the hand-scheduled phases would split them)
+        if (a.r.z_x4) fuse_role_adjoint<X6, true>(a, X, Y, bc, wave, lane, ntiles);
+        else fuse_role_adjoint<X6, false>(a, X, Y, bc, wave, lane, ntiles);
     } else {
         if constexpr (X6) fuse_role_contract_x6(a, reinterpret_cast<const b8_t*>(lds), wave - 4, lane, ntiles);
         else fuse_role_contract(a, lds, lds + FUSE_NX * FUSE_XB * 4, wave - 4, lane, ntiles);
