@@ -222,14 +222,17 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
         // the MFMA first in its slot: left to itself the scheduler puts it last in one region and first in the next - two MFMAs back to back behind
         // two epilogue slots in a row (round 6: -1.2 % per evaluation)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (j == 5 && en + X6W_RING - 1 < X6W_ENTRIES) {
+        // the stream WRAPS: behind the last tile's K steps the ring takes entries 0..6 of the next evaluation (136 = 17 x 8: the slots they belong in), in the
+        // MFMAs' shadow and a whole uncovered tail ahead of their use (the last evaluation's are wasted and harmless)
+        if constexpr (j == 5 && en + X6W_RING - 1 < X6W_ENTRIES + X6W_RING - 1) {
             constexpr int x = en + X6W_RING - 1;
             if constexpr ((x & 3) == 0) {
 #ifndef X6W_PROBE_SAME_ENTRIES      // (timing probe: every wave re-reads the first four entries - 12 KB that stay in the CU's L1)
 #ifdef X6W_BUFLD
-                c.so += 4096;
+                c.so += (x == X6W_ENTRIES) ? -(X6W_ENTRIES / 4 - 1) * 4096 : 4096;
 #else
-                c.W1 += 256; c.W2 += 256; c.W3 += 256;
+                constexpr int adv = (x == X6W_ENTRIES) ? -(X6W_ENTRIES / 4 - 1) * 256 : 256;
+                c.W1 += adv; c.W2 += adv; c.W3 += adv;
 #endif
 #endif
                 X6W_OPAQUE(c);
@@ -279,9 +282,8 @@ __device__ __forceinline__ void x6w_tile(X6W& c, b8_t (&A1)[X6W_RING], b8_t (&A2
 }
 
 // one evaluation of the net for the wave's 32 points
-// the first seven entries of the weight stream into the ring: at kernel start, and by every evaluation for its successor BEFORE its own uncovered
-// tail (the last row tile's sums, the RK2 glue, the next encoder: ~3 k cycles for the L2 round trip - requested at the head of the evaluation the
-// first tile waited 0.6-1 k cycles for them; the ring is idle from the last K step on).  The last evaluation's request is wasted and harmless.
+// the first seven entries of the weight stream into the ring at kernel start; every evaluation then requests its successor's behind its own last K steps
+// (x6w_tile: the stream wraps) - requested at the head of the evaluation the first tile waited 0.6-1 k cycles for them.
 struct X6WRing { b8_t A1[X6W_RING], A2[X6W_RING], A3[X6W_RING]; };
 __device__ __forceinline__ void x6w_prime(const X6W& c0, X6WRing& R) {
     X6W c = c0;
@@ -369,7 +371,6 @@ __device__ __forceinline__ void velnet_x6w(const X6W& c0, X6WRing& R, const floa
     x6w_tile<112, 2, 544, true, true, STASH>(c, A1, A2, A3, X0, in, va, e, 0, vb, bias);
     x6w_tile<120, 2, 576, true, true, STASH>(c, A1, A2, A3, X0, in, vb, e, 2, va, bias);
     x6w_tile<128, 4, 608, true, true, STASH>(c, A1, A2, A3, X0, in, va, e, 4, vb, bias);
-    x6w_prime(c0, R);
     // ---- 128 -> 6: fp32 FMAs in velnet_x6's order (per row tile: a chain over its 16 activations, the two lane halves added, then the tiles in order).
     // Row tiles 0..2 were summed in their epilogues' micro-slots (x6w_micro<LAST>); the last one has no MFMAs behind it
 #ifdef X6W_PROBE_NO_OUT              // (timing probe: no output layer)
