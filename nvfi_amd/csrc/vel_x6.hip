@@ -103,9 +103,9 @@ __device__ __forceinline__ void x6_step(const b8_t& A1, const b8_t& A2, const b8
 // overwriting an MFMA's A or B registers straight behind its issue is harmless on gfx950.
 // STASH (training render): the fp32 pre-activations z of the five hidden layers (wave w = rows 16 w .. 16 w + 15 of each layer) and the encoder
 // slots go to the per-(evaluation, tile) stash in the layout of k_rk2_split_uni<STASH> (vel_split.hip): the fp32 adjoint kernels read it unchanged
-template <int NT, bool STASH = false>
+template <int NT, bool STASH = false, bool X4 = false>     // X4 (with STASH): Rk2Args::z_x4, the z rows of layers 0..3 as x4 stash blocks
 __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xch, float4* part, const float4* w5l, int w, int lane, int h,
-                                          const float4* q, const float* lb, float (&out6)[NT][6], float* const* zst = nullptr, float* const* x0st = nullptr, bool z_x4 = false) {
+                                          const float4* q, const float* lb, float (&out6)[NT][6], float* const* zst = nullptr, float* const* x0st = nullptr) {
     const b8_t* W1 = img; const b8_t* W2 = img + X6_H8; const b8_t* W3 = img + 2 * X6_H8;
     f32x16 a0[NT], a1[NT];
     b8_t Bf[NT][8][3];
@@ -163,7 +163,7 @@ __device__ __forceinline__ void velnet_x6(const b8_t* __restrict__ img, b8_t* xc
         if (STASH) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (z_x4) stash_st16_x4(zst[t] + (size_t)(l * 64 + 16 * w) * REGF, lane, v[t]);      // (Rk2Args::z_x4: four 16-byte stores instead of sixteen rows)
+                if constexpr (X4) stash_st16_x4(zst[t] + (size_t)(l * 64 + 16 * w) * REGF, lane, v[t]);      // (four 16-byte stores instead of sixteen rows)
                 else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) STASH_ST(zst[t][(size_t)(l * 64 + 16 * w + r) * REGF + lane], v[t][r]);
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6(X6Args a
 
 // ---------------------------------------------------------------- render warp: every sample takes the same (dt_s, t_s) sequence
 // (rk2_split_uni_body of vel_split.hip on the x6 evaluation: same compact list, same in-place update, same stash and records)
-template <int NT, bool STASH>
+template <int NT, bool STASH, bool X4 = false>
 __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6_uni(X6UniArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     b8_t* xch = reinterpret_cast<b8_t*>(lds);
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6_uni(X6Un
         float4 q[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) q[t] = make_float4(x[t], y[t], z[t], tcur);
-        velnet_x6<NT, STASH>(img, xch, part, w5l, w, lane, h, q, lb, o6, z1, x1, ra.z_x4 != 0);
+        velnet_x6<NT, STASH, X4>(img, xch, part, w5l, w, lane, h, q, lb, o6, z1, x1);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v1[3];
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(WG_THREADS, NT == 1 ? 2 : 1) void k_rk2_x6_uni(X6Un
             px[t] = x[t] - hdt * v1[0]; py[t] = y[t] - hdt * v1[1]; pz[t] = z[t] - hdt * v1[2];
             q[t] = make_float4(px[t], py[t], pz[t], tcur - hdt);
         }
-        velnet_x6<NT, STASH>(img, xch, part, w5l, w, lane, h, q, lb, o6, z2, x2, ra.z_x4 != 0);
+        velnet_x6<NT, STASH, X4>(img, xch, part, w5l, w, lane, h, q, lb, o6, z2, x2);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float v2[3];
@@ -459,7 +459,7 @@ int launch_rk2_x6_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipSt
     const int64_t tiles = (cap_samples + TILE - 1) / TILE;
     if (tiles <= 0) return 0;
     static DeviceOnce once;
-    if (once.run([] { return (x6_set_lds(k_rk2_x6_uni<1, true>) || x6_set_lds(k_rk2_x6_uni<1, false>)) ? 1 : 0; })) return 1;
+    if (once.run([] { return (x6_set_lds(k_rk2_x6_uni<1, true, true>) || x6_set_lds(k_rk2_x6_uni<1, true>) || x6_set_lds(k_rk2_x6_uni<1, false>)) ? 1 : 0; })) return 1;
     ProfScope ps(PK_RK2_FWD, st);
     // NVFI_X6W_UNI: 1 (default) eval renders on the one-wave-per-tile kernel of vel_x6w.hip (bit-identical; an 800 x 800 test frame 134 -> 120 ms),
     // 2 training renders too (same stash and records; no faster there: 0.35 against 0.37 ms, the stash stores are not hidden), 0 neither
@@ -467,7 +467,8 @@ int launch_rk2_x6_uni(const X6UniArgs& a, int64_t cap_samples, bool stash, hipSt
     if (wuni < 0) { const char* e = getenv("NVFI_X6W_UNI"); wuni = e ? atoi(e) : 1; }
     if ((wuni >= 1 && !stash) || wuni >= 2) return launch_rk2_x6w_uni(a, cap_samples, stash, st);
     // (round 6: the two-tiles-per-workgroup variants - NVFI_X6_NT=2 - are retired: never a default, 8 % slower)
-    if (stash) hipLaunchKernelGGL((k_rk2_x6_uni<1, true>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
+    if (stash && a.r.z_x4) hipLaunchKernelGGL((k_rk2_x6_uni<1, true, true>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
+    else if (stash) hipLaunchKernelGGL((k_rk2_x6_uni<1, true>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
     else hipLaunchKernelGGL((k_rk2_x6_uni<1, false>), dim3((unsigned)tiles), dim3(WG_THREADS), x6_lds_nt1(), st, a);
     LAUNCHCK();
     return 0;
